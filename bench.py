@@ -1,0 +1,236 @@
+#!/usr/bin/env python
+"""Benchmark of the Hamilton-product hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+
+Default workload = BASELINE.json configs[1]: ONE QuaternionConv1D(64, 3, padding='same',
+activation='relu') layer, forward + backward (d input, d kernel, d bias) + the Keras-Adam update
+of the compact kernel, on a synthetic TIMIT-shape batch x (64, 200, 160) channels_last fp32
+(40 mel x 4 quaternion components, 200 frames), batch 64 PER GPU (weak scaling).  A "step" is one
+such pass over one batch already resident in HBM.  Data-parallel: every rank holds a replica, the
+only exchange is one RCCL sum all-reduce of the flat fp32 gradient buffer per step, issued right
+after backward-weight so it overlaps backward-data.
+
+Prints ONE JSON line on rank 0 (see the contract in the task description): value = whole-job
+samples/s; `roofline` = the dominant kernel's algorithmic FLOPs / its average duration measured
+with HIP events on the launch stream, against the fp32-MFMA peak; `cpu_baseline` = the
+reference's CPU op sequence (oracle/ref_port.py, torch-CPU) timed on this host (N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.realpath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_TFLOPS = {'fp32': 157.3, 'bf16': 2500.0, 'fp16': 2500.0}   # MI355X_MICROARCH.md dense MFMA peaks
+TORCH_DT = {'fp32': torch.float32, 'bf16': torch.bfloat16, 'fp16': torch.float16}
+
+WORKLOADS = {
+    # BASELINE.json configs[1]
+    'cfg2_qconv1d_timit_b64_fp32': dict(kind='conv', rank=1, batch=64, spatial=(200,), cq=40, filters=64,
+                                        kernel=(3,), dtype='fp32'),
+    # the Hamilton GEMM the 40 % MFMA target is quoted on: config-3 stage-2 body conv
+    'cfg3_body_qconv2d_b256_bf16': dict(kind='conv', rank=2, batch=256, spatial=(14, 200), cq=64, filters=64,
+                                        kernel=(3, 5), dtype='bf16'),
+    'cfg3_body_qconv2d_b256_fp32': dict(kind='conv', rank=2, batch=256, spatial=(14, 200), cq=64, filters=64,
+                                        kernel=(3, 5), dtype='fp32'),
+}
+
+
+class LayerTrainStep(object):
+    """fwd -> bwd-weight(+bias) -> [all-reduce] -> bwd-data -> Adam on static buffers."""
+
+    def __init__(self, cfg, dev, rank, world):
+        import qcnn_amd
+        from qcnn_amd import dp, functional as F
+        from qcnn_amd.complexnn.init import qconv_init
+        self.F, self.dp, self.world = F, dp, world
+        self.cfg = cfg
+        dt = TORCH_DT[cfg['dtype']]
+        B, sp, cq, fq, ks = cfg['batch'], tuple(cfg['spatial']), cfg['cq'], cfg['filters'], tuple(cfg['kernel'])
+        gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+        self.x = torch.randn((B,) + sp + (4 * cq,), device=dev, generator=gen).to(dt)
+        np.random.seed(0)      # identical replicas: the reference init is host-side and seeded
+        w0 = qconv_init(kernel_size=ks, input_dim=cq, weight_dim=len(ks), nb_filters=fq, criterion='he')()
+        kernel = torch.nn.Parameter(torch.tensor(w0, dtype=torch.float32, device=dev))
+        bias = torch.nn.Parameter(torch.zeros(4 * fq, device=dev))
+        self.flat = dp.FlatParams([kernel, bias])
+        dp.broadcast_params(self.flat)
+        self.kernel, self.bias = kernel, bias
+        self.m = torch.zeros_like(self.flat.param)
+        self.v = torch.zeros_like(self.flat.param)
+        self.call = F.conv_call(tuple(self.x.shape), tuple(kernel.shape), dt, len(ks), 1, 'same',
+                                'channels_last', 1, 'relu', True)
+        self.call.static_buffers = True
+        self.y = torch.empty(self.call.y_shape, dtype=dt, device=dev)
+        self.dy = torch.randn(self.call.y_shape, device=dev, generator=gen).to(dt)
+        self.dx = torch.empty_like(self.x)
+        self.dw, self.db = self.flat.grad_view(0), self.flat.grad_view(1)
+        self.t = 0
+        M = B * int(np.prod(sp))
+        self.gemm = dict(M=M, N=4 * fq, K=int(np.prod(ks)) * 4 * cq)
+        self.flops_per_kernel = 2.0 * M * 4 * fq * int(np.prod(ks)) * 4 * cq
+
+    # the three hot kernels, individually callable for event timing
+    def k_fwd(self):
+        self.call.fwd(self.x, self.kernel.data, self.bias.data, out=self.y)
+
+    def k_bwd_weight(self):
+        self.call.bwd_weight(self.x, self.dy, self.y, True, out=(self.dw, self.db))
+
+    def k_bwd_data(self):
+        self.call.bwd_data(self.dy, self.y, self.kernel.data, out=self.dx)
+
+    def step(self):
+        self.t += 1
+        self.k_fwd()
+        self.k_bwd_weight()
+        work = self.dp.allreduce_sum_(self.flat.grad, async_op=True)   # overlaps bwd-data
+        self.k_bwd_data()
+        if work is not None:
+            work.wait()
+        self.F.adam_step(self.flat.param, self.flat.grad, self.m, self.v, self.t, lr=5e-4,
+                         grad_scale=1.0 / self.world)
+
+
+def event_time_ms(fn, stream, reps=20, rounds=5):
+    """Average duration of `fn`'s launches: `reps` back-to-back launches between two HIP events
+    recorded on the launch stream; best of `rounds`."""
+    best = None
+    for _ in range(rounds):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(reps):
+            fn()
+        e1.record(stream)
+        e1.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        best = ms if best is None else min(best, ms)
+    return best
+
+
+def cpu_baseline(cfg, seconds):
+    """The reference's per-step CPU op sequence (expand kernel by concat -> one real conv ->
+    bias -> relu; autograd backward) on this host's cores, fp32, bounded to ~`seconds`."""
+    from oracle import ref_port
+    from qcnn_amd.complexnn.init import qconv_init
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    B, sp, cq, fq, ks = cfg['batch'], tuple(cfg['spatial']), cfg['cq'], cfg['filters'], tuple(cfg['kernel'])
+    torch.manual_seed(0)
+    np.random.seed(0)
+    x = torch.randn((B,) + sp + (4 * cq,), requires_grad=True)
+    w = torch.tensor(qconv_init(ks, cq, len(ks), fq, 'he')(), dtype=torch.float32, requires_grad=True)
+    b = torch.zeros(4 * fq, requires_grad=True)
+    dy = None
+    n, t_total = 0, 0.0
+    for it in range(1000):
+        t0 = time.perf_counter()
+        y = ref_port.conv_forward(x, w, b, len(ks), 1, 'same', 'channels_last', 1, 'relu')
+        if dy is None:
+            dy = torch.randn_like(y)
+        gx, gw, gb = torch.autograd.grad(y, (x, w, b), dy)
+        dt = time.perf_counter() - t0
+        if it >= 2:            # two warm-up passes
+            n += 1
+            t_total += dt
+            if t_total >= seconds or n >= 200:
+                break
+    ms = 1e3 * t_total / n
+    return {'value': B / (ms * 1e-3), 'unit': 'samples/s', 'cores': cores, 'kind': 'port',
+            'ms_per_step': ms,
+            'sample': '%d timed fwd+bwd passes of the same workload (batch %d) through the reference op '
+                      'sequence on torch-CPU/oneDNN, fp32, no optimizer' % (n, B)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=300)
+    ap.add_argument('--warmup', type=int, default=30)
+    ap.add_argument('--workload', default='cfg2_qconv1d_timit_b64_fp32', choices=sorted(WORKLOADS))
+    ap.add_argument('--cpu-seconds', type=float, default=12.0)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-timing', action='store_true')
+    args = ap.parse_args()
+
+    import qcnn_amd  # noqa: F401  (fails loudly if libqk_hip.so is missing)
+    from qcnn_amd import dp
+    import torch.distributed as dist
+
+    rank, world, local = dp.init_from_env()
+    if world != args.gpus:
+        if rank == 0:
+            sys.stderr.write('warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE\n' % (args.gpus, world))
+    assert torch.cuda.is_available(), 'bench.py needs a GPU'
+    dev = torch.device('cuda', local)
+    torch.cuda.set_device(dev)
+    cfg = WORKLOADS[args.workload]
+    job = LayerTrainStep(cfg, dev, rank, world)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        job.step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        job.step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ms_per_step = 1e3 * elapsed / args.steps
+    samples_per_s = world * cfg['batch'] * args.steps / elapsed
+
+    out = {
+        'metric': 'quaternion-conv samples/sec (fwd+bwd+Adam of one QuaternionConv layer)',
+        'value': samples_per_s, 'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': cfg['dtype'], 'data': 'synthetic',
+        'config': {'workload': args.workload, 'per_gpu_batch': cfg['batch'],
+                   'global_batch': cfg['batch'] * world, 'input': list(job.x.shape),
+                   'filters': cfg['filters'], 'kernel_size': list(cfg['kernel']), 'padding': 'same',
+                   'activation': 'relu', 'gemm_view': job.gemm, 'parallelism': 'dp%d' % world,
+                   'optimizer': 'adam(5e-4)'},
+    }
+
+    if rank == 0 and not args.no_kernel_timing:
+        stream = torch.cuda.current_stream(dev)
+        kernels = {}
+        for name, fn in (('fwd', job.k_fwd), ('bwd_weight', job.k_bwd_weight), ('bwd_data', job.k_bwd_data)):
+            ms = event_time_ms(fn, stream)
+            kernels[name] = {'ms': ms, 'tflops': job.flops_per_kernel / (ms * 1e-3) / 1e12}
+        dom = max(kernels, key=lambda k: kernels[k]['ms'])
+        peak = PEAK_TFLOPS[cfg['dtype']]
+        out['roofline'] = {'bound': 'mfma', 'kernel': dom, 'achieved': kernels[dom]['tflops'], 'peak': peak,
+                           'unit': 'TFLOP/s', 'frac': kernels[dom]['tflops'] / peak, 'traffic': None,
+                           'flops_per_launch': job.flops_per_kernel, 'avg_launch_ms': kernels[dom]['ms']}
+        out['kernels'] = kernels
+        step_flops = 3 * job.flops_per_kernel
+        out['step_tflops'] = step_flops / (ms_per_step * 1e-3) / 1e12
+    if world > 1:
+        dist.barrier()
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline(cfg, args.cpu_seconds)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

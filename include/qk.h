@@ -1,0 +1,148 @@
+/*
+ * qk.h -- C-ABI of the MI355X (gfx950) quaternion-layer engine (libqk_hip.so).
+ *
+ * This is the drop-in boundary for the Hamilton-product hot path of
+ * Orkis-Research/Quaternion-CNN-for-E2E-ASR.  The reference has no FFI of its own: the path
+ * is ~60 lines of Keras-backend calls inside two Layer.call bodies.  Each entry point below
+ * names the reference code it replaces (paths relative to the reference checkout):
+ *
+ *   qk_conv_fwd          QuaternionConv.call      complexnn/conv.py:288-345
+ *                        (slices :294-307, signed concat :327-331, K.conv{1,2,3}d :334,
+ *                         K.bias_add :336-341, activation :342-343) -- all fused in one launch,
+ *                         the 4x-expanded kernel is never materialised.
+ *   qk_conv_bwd_data     TF autodiff of the above w.r.t. the layer input
+ *   qk_conv_bwd_weight   TF autodiff of the above w.r.t. `kernel` (conv.py:175-181) and
+ *                        `bias` (conv.py:270-278): the 16 expanded blocks are folded back onto
+ *                        the 4 compact parts inside the kernel.
+ *   qk_dense_fwd         QuaternionDense.call     complexnn/dense.py:126-164
+ *                        (signed concat :139-143 == TRANSPOSED table => conj(W) (x) x,
+ *                         K.dot :149, bias/activation :159-162)
+ *   qk_dense_bwd_data / qk_dense_bwd_weight       TF autodiff of dense.py:126-164
+ *   qk_adam_step         the Keras Adam update the reference trains with
+ *                        (working_example.py:106, keras.optimizers.Adam defaults) applied to a
+ *                        flat fp32 parameter buffer -- used by the data-parallel step.
+ *
+ * Conventions (identical to the reference):
+ *   - quaternion components r,i,j,k are four CONTIGUOUS channel blocks: input channel
+ *     a*Cq+c, output channel b*F+f, bias index b*F+f;
+ *   - compact kernel layout (*kernel_size, Cq, 4F) with last axis p*F+f (conv.py:165,
+ *     init.py:91); dense kernel (in_q, 4*q_units) (dense.py:98, init.py:153);
+ *   - activations are channels_last (N, *spatial, 4C) or channels_first (N, 4C, *spatial),
+ *     dense activations are (M, 4C) row-major;
+ *   - cross-correlation (no kernel flip), explicit low-side padding per axis (the caller
+ *     resolves 'valid' / 'same' / 'causal' with TensorFlow's rule and passes pad_lo and the
+ *     output extents).
+ *
+ * Ownership / threading: the caller owns EVERY buffer including the workspace; the library
+ * never allocates or frees device memory and never keeps a pointer past the call.  All work is
+ * enqueued on the hipStream_t passed in (no host synchronisation); the functions are
+ * re-entrant.  Kernel / bias / their gradients are always float32 (Keras floatx); activations
+ * (x, y, dy, dx) are float32, bfloat16 or float16 with float32 accumulation.
+ *
+ * Errors: every function returns 0 on success or a negative qk_status_t; qk_last_error()
+ * returns a thread-local message.  Nothing throws across this boundary.
+ */
+#ifndef QK_H_
+#define QK_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QK_VERSION 100 /* major*10000 + minor*100 + patch */
+
+typedef enum {
+    QK_OK = 0,
+    QK_ERR_INVALID_ARG = -1,   /* bad descriptor / null pointer                      */
+    QK_ERR_UNSUPPORTED = -2,   /* valid request this build has no kernel for         */
+    QK_ERR_WORKSPACE = -3,     /* workspace missing or too small                     */
+    QK_ERR_LAUNCH = -4         /* HIP runtime reported an error on launch            */
+} qk_status_t;
+
+typedef enum { QK_F32 = 0, QK_BF16 = 1, QK_F16 = 2 } qk_dtype_t;
+typedef enum { QK_CH_LAST = 0, QK_CH_FIRST = 1 } qk_layout_t;
+typedef enum { QK_ACT_LINEAR = 0, QK_ACT_RELU = 1 } qk_act_t;
+typedef enum { QK_OP_FWD = 0, QK_OP_BWD_DATA = 1, QK_OP_BWD_WEIGHT = 2 } qk_op_t;
+
+/* One quaternion convolution call (QuaternionConv.__init__/build state, conv.py:93-286). */
+typedef struct {
+    int32_t rank;            /* 1, 2 or 3 spatial axes                                        */
+    int32_t batch;           /* N                                                             */
+    int32_t in_spatial[3];   /* input extents; trailing unused axes must be 1                 */
+    int32_t out_spatial[3];  /* conv_utils.conv_output_length per axis (conv.py:347-372)      */
+    int32_t cq;              /* quaternion input channels  = input channels / 4 (conv.py:164) */
+    int32_t fq;              /* `filters`: quaternion filters, output channels = 4*fq         */
+    int32_t kernel[3];       /* kernel_size                                                   */
+    int32_t stride[3];       /* strides                                                       */
+    int32_t dilation[3];     /* dilation_rate                                                 */
+    int32_t pad_lo[3];       /* zeros in front of each axis ('same': total/2, 'causal': d(k-1)) */
+    int32_t layout;          /* qk_layout_t of x / y / dy / dx                                */
+    int32_t dtype;           /* qk_dtype_t  of x / y / dy / dx                                */
+    int32_t activation;      /* qk_act_t fused into fwd; bwd masks dy with (y > 0) for RELU   */
+    int32_t has_bias;        /* use_bias                                                      */
+    int32_t conj;            /* 0: W (x) x  (conv.py:327-331);  1: conj(W) (x) x (dense table) */
+} qk_conv_desc_t;
+
+/* One quaternion dense call (QuaternionDense state, dense.py:58-124). */
+typedef struct {
+    int32_t rows;            /* M: batch rows (B, or B*T under TimeDistributed)               */
+    int32_t in_q;            /* input_dim = in_features / 4          (dense.py:96)            */
+    int32_t q_units;         /* units / 4                            (dense.py:75)            */
+    int32_t dtype;           /* qk_dtype_t of x / y / dy / dx                                 */
+    int32_t activation;      /* qk_act_t                                                      */
+    int32_t has_bias;
+} qk_dense_desc_t;
+
+/* Library / diagnostics ------------------------------------------------------------------ */
+int qk_version(void);
+const char *qk_last_error(void);
+
+/* Bytes of caller-owned device workspace `op` needs for this descriptor (0 = none). */
+size_t qk_conv_workspace_bytes(const qk_conv_desc_t *desc, int op /* qk_op_t */);
+size_t qk_dense_workspace_bytes(const qk_dense_desc_t *desc, int op /* qk_op_t */);
+
+/* Convolution ----------------------------------------------------------------------------
+ * x      [N, *in_spatial, 4*cq]  (or channels_first)        desc->dtype
+ * w      [*kernel, cq, 4*fq]                                float32, compact r|i|j|k
+ * bias   [4*fq] or NULL                                     float32
+ * y      [N, *out_spatial, 4*fq] (or channels_first)        desc->dtype
+ * stream hipStream_t (passed as void* so this header needs no HIP include)
+ */
+int qk_conv_fwd(const qk_conv_desc_t *desc, const void *x, const float *w, const float *bias,
+                void *y, void *workspace, size_t workspace_bytes, void *stream);
+
+/* dx = d loss / d x.  `y` (the forward output) is read only when activation == RELU. */
+int qk_conv_bwd_data(const qk_conv_desc_t *desc, const void *dy, const void *y, const float *w,
+                     void *dx, void *workspace, size_t workspace_bytes, void *stream);
+
+/* dw [*kernel, cq, 4*fq] and dbias [4*fq] (NULL when !has_bias) are OVERWRITTEN. */
+int qk_conv_bwd_weight(const qk_conv_desc_t *desc, const void *x, const void *dy, const void *y,
+                       float *dw, float *dbias, void *workspace, size_t workspace_bytes,
+                       void *stream);
+
+/* Dense ---------------------------------------------------------------------------------
+ * x [rows, 4*in_q], w [in_q, 4*q_units] float32, bias [4*q_units], y [rows, 4*q_units]
+ */
+int qk_dense_fwd(const qk_dense_desc_t *desc, const void *x, const float *w, const float *bias,
+                 void *y, void *workspace, size_t workspace_bytes, void *stream);
+int qk_dense_bwd_data(const qk_dense_desc_t *desc, const void *dy, const void *y, const float *w,
+                      void *dx, void *workspace, size_t workspace_bytes, void *stream);
+int qk_dense_bwd_weight(const qk_dense_desc_t *desc, const void *x, const void *dy, const void *y,
+                        float *dw, float *dbias, void *workspace, size_t workspace_bytes,
+                        void *stream);
+
+/* Optimiser step on a flat fp32 buffer (Keras Adam: working_example.py:106).
+ *   m = b1*m + (1-b1)*g ; v = b2*v + (1-b2)*g^2
+ *   p -= lr * sqrt(1-b2^t)/(1-b1^t) * m / (sqrt(v) + eps)          (Keras 2.x form)
+ * `grad_scale` multiplies g first (1/world_size after a sum all-reduce). */
+int qk_adam_step(float *param, const float *grad, float *m, float *v, size_t n, float lr,
+                 float beta1, float beta2, float eps, int32_t step, float grad_scale,
+                 void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QK_H_ */

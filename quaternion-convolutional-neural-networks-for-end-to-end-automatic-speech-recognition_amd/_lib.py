@@ -1,0 +1,72 @@
+"""ctypes binding of libqk_hip.so -- the C-ABI declared in include/qk.h.
+
+The product path has NO fallback: if the library is missing or a call fails, a RuntimeError
+is raised.  (The CPU oracle under oracle/ is test infrastructure and is never imported here.)
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.realpath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libqk_hip.so')
+
+QK_F32, QK_BF16, QK_F16 = 0, 1, 2
+QK_CH_LAST, QK_CH_FIRST = 0, 1
+QK_ACT_LINEAR, QK_ACT_RELU = 0, 1
+QK_OP_FWD, QK_OP_BWD_DATA, QK_OP_BWD_WEIGHT = 0, 1, 2
+
+I32 = ctypes.c_int32
+
+
+class ConvDesc(ctypes.Structure):
+    _fields_ = [('rank', I32), ('batch', I32), ('in_spatial', I32 * 3), ('out_spatial', I32 * 3),
+                ('cq', I32), ('fq', I32), ('kernel', I32 * 3), ('stride', I32 * 3),
+                ('dilation', I32 * 3), ('pad_lo', I32 * 3), ('layout', I32), ('dtype', I32),
+                ('activation', I32), ('has_bias', I32), ('conj', I32)]
+
+
+class DenseDesc(ctypes.Structure):
+    _fields_ = [('rows', I32), ('in_q', I32), ('q_units', I32), ('dtype', I32),
+                ('activation', I32), ('has_bias', I32)]
+
+
+# every symbol include/qk.h declares: name -> (restype, argtypes)
+_VP, _FP, _SZ = ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t
+_CD, _DD = ctypes.POINTER(ConvDesc), ctypes.POINTER(DenseDesc)
+SYMBOLS = {
+    'qk_version': (ctypes.c_int, []),
+    'qk_last_error': (ctypes.c_char_p, []),
+    'qk_conv_workspace_bytes': (_SZ, [_CD, ctypes.c_int]),
+    'qk_dense_workspace_bytes': (_SZ, [_DD, ctypes.c_int]),
+    'qk_conv_fwd': (ctypes.c_int, [_CD, _VP, _FP, _FP, _VP, _VP, _SZ, _VP]),
+    'qk_conv_bwd_data': (ctypes.c_int, [_CD, _VP, _VP, _FP, _VP, _VP, _SZ, _VP]),
+    'qk_conv_bwd_weight': (ctypes.c_int, [_CD, _VP, _VP, _VP, _FP, _FP, _VP, _SZ, _VP]),
+    'qk_dense_fwd': (ctypes.c_int, [_DD, _VP, _FP, _FP, _VP, _VP, _SZ, _VP]),
+    'qk_dense_bwd_data': (ctypes.c_int, [_DD, _VP, _VP, _FP, _VP, _VP, _SZ, _VP]),
+    'qk_dense_bwd_weight': (ctypes.c_int, [_DD, _VP, _VP, _VP, _FP, _FP, _VP, _SZ, _VP]),
+    'qk_adam_step': (ctypes.c_int, [_FP, _FP, _FP, _FP, _SZ, ctypes.c_float, ctypes.c_float,
+                                    ctypes.c_float, ctypes.c_float, I32, ctypes.c_float, _VP]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises RuntimeError (never falls back) when it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                'libqk_hip.so is not built (%s). Run `python -c "import __graft_entry__ as g; '
+                'g.build()"` -- the quaternion layers have no CPU or eager fallback.' % LIB_PATH)
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(handle, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().qk_last_error()
+        raise RuntimeError('%s failed (status %d): %s' % (what, rc, msg.decode() if msg else ''))

@@ -1,0 +1,340 @@
+// C-ABI front end (include/qk.h): descriptor validation, geometry, kernel selection.
+// No device allocation, no host synchronisation, nothing retained after return.
+#include <limits.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "qk_common.h"
+
+namespace qk {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+#define QK_DECL(sfx)                                                                              \
+    int launch_hgemm_##sfx(const void *, const void *, const float *, const float *, void *,      \
+                           const GemmGeom &, bool, hipStream_t);                                  \
+    int launch_wgrad_##sfx(const void *, const void *, const void *, float *, float *,            \
+                           const WgradGeom &, bool, hipStream_t);
+QK_DECL(f32)
+QK_DECL(bf16)
+QK_DECL(f16)
+#undef QK_DECL
+
+// 16-bit-input MFMA fast path (qk_hgemm_bf16mfma.hip); returns 1 when it took the call
+int try_hgemm_16(int dtype, const void *in, const void *mask, const float *w_f32, const float *bias,
+                 void *out, const GemmGeom &g, bool w_is_transposed, void *ws, size_t ws_bytes,
+                 hipStream_t stream);
+
+int launch_hgemm(int dtype, const void *in, const void *mask, const float *wk, const float *bias,
+                 void *out, const GemmGeom &g, bool vec_ok, hipStream_t stream)
+{
+    switch (dtype) {
+    case QK_F32: return launch_hgemm_f32(in, mask, wk, bias, out, g, vec_ok, stream);
+    case QK_BF16: return launch_hgemm_bf16(in, mask, wk, bias, out, g, vec_ok, stream);
+    case QK_F16: return launch_hgemm_f16(in, mask, wk, bias, out, g, vec_ok, stream);
+    }
+    return QK_ERR_INVALID_ARG;
+}
+
+int launch_wgrad(int dtype, const void *x, const void *dy, const void *ymask, float *dw,
+                 float *dbias, WgradGeom g, bool vec_ok, hipStream_t stream)
+{
+    switch (dtype) {
+    case QK_F32: return launch_wgrad_f32(x, dy, ymask, dw, dbias, g, vec_ok, stream);
+    case QK_BF16: return launch_wgrad_bf16(x, dy, ymask, dw, dbias, g, vec_ok, stream);
+    case QK_F16: return launch_wgrad_f16(x, dy, ymask, dw, dbias, g, vec_ok, stream);
+    }
+    return QK_ERR_INVALID_ARG;
+}
+
+namespace {
+
+size_t elem_bytes(int dtype) { return dtype == QK_F32 ? 4 : 2; }
+
+bool aligned(const void *p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+// 4-element vector loads need 16 B (f32) / 8 B (16-bit) alignment
+bool vec_aligned(const void *p, int dtype) { return aligned(p, 4 * elem_bytes(dtype)); }
+
+int validate(const qk_conv_desc_t *d, bool allow_rank0)
+{
+    if (!d) { set_error("descriptor is NULL"); return QK_ERR_INVALID_ARG; }
+    if (d->rank < (allow_rank0 ? 0 : 1) || d->rank > 3) {
+        set_error("rank %d not in [1,3]", d->rank); return QK_ERR_INVALID_ARG;
+    }
+    if (d->batch <= 0 || d->cq <= 0 || d->fq <= 0) {
+        set_error("batch/cq/fq must be positive (got %d/%d/%d)", d->batch, d->cq, d->fq);
+        return QK_ERR_INVALID_ARG;
+    }
+    long long si = 1, so = 1, taps = 1;
+    for (int i = 0; i < 3; ++i) {
+        if (d->in_spatial[i] <= 0 || d->out_spatial[i] <= 0 || d->kernel[i] <= 0 ||
+            d->stride[i] <= 0 || d->dilation[i] <= 0 || d->pad_lo[i] < 0) {
+            set_error("axis %d: extents/kernel/stride/dilation must be > 0 and pad_lo >= 0", i);
+            return QK_ERR_INVALID_ARG;
+        }
+        if (i >= d->rank && (d->in_spatial[i] != 1 || d->out_spatial[i] != 1 || d->kernel[i] != 1 ||
+                             d->stride[i] != 1 || d->dilation[i] != 1 || d->pad_lo[i] != 0)) {
+            set_error("axis %d is beyond rank %d and must be the identity (1,1,1,1,1,0)", i, d->rank);
+            return QK_ERR_INVALID_ARG;
+        }
+        si *= d->in_spatial[i]; so *= d->out_spatial[i]; taps *= d->kernel[i];
+    }
+    if (si * d->batch > INT_MAX || so * d->batch > INT_MAX || taps * d->cq * 4LL * d->fq > INT_MAX) {
+        set_error("problem too large for 32-bit row indices"); return QK_ERR_UNSUPPORTED;
+    }
+    if (d->layout != QK_CH_LAST && d->layout != QK_CH_FIRST) { set_error("bad layout %d", d->layout); return QK_ERR_INVALID_ARG; }
+    if (d->dtype != QK_F32 && d->dtype != QK_BF16 && d->dtype != QK_F16) { set_error("bad dtype %d", d->dtype); return QK_ERR_INVALID_ARG; }
+    if (d->activation != QK_ACT_LINEAR && d->activation != QK_ACT_RELU) { set_error("bad activation %d", d->activation); return QK_ERR_INVALID_ARG; }
+    return 0;
+}
+
+struct Strides { long long sn, ss[3], sc; long long flat_ss; };
+
+// element strides of an activation tensor with `ch` channels and spatial extents sp
+Strides act_strides(const int32_t *sp, int ch, int layout)
+{
+    Strides s;
+    const long long S = (long long)sp[0] * sp[1] * sp[2];
+    if (layout == QK_CH_LAST) {
+        s.sc = 1; s.ss[2] = ch; s.ss[1] = (long long)sp[2] * ch; s.ss[0] = (long long)sp[1] * sp[2] * ch;
+        s.sn = S * ch; s.flat_ss = ch;
+    } else {
+        s.sc = S; s.ss[2] = 1; s.ss[1] = sp[2]; s.ss[0] = (long long)sp[1] * sp[2];
+        s.sn = S * ch; s.flat_ss = 1;
+    }
+    return s;
+}
+
+int taps_of(const qk_conv_desc_t *d) { return d->kernel[0] * d->kernel[1] * d->kernel[2]; }
+
+size_t w_floats(const qk_conv_desc_t *d) { return (size_t)taps_of(d) * d->cq * 4 * d->fq; }
+
+size_t ws_bytes_impl(const qk_conv_desc_t *d, int op)
+{
+    // bwd-data: per-tap transposed fp32 copy of the compact kernel
+    // 16-bit fast path (fwd / bwd-data): 16-bit re-laid-out copy of the compact kernel
+    size_t n = 0;
+    if (op == QK_OP_BWD_DATA) n = w_floats(d) * sizeof(float);
+    if (d->dtype != QK_F32 && (op == QK_OP_FWD || op == QK_OP_BWD_DATA)) n += w_floats(d) * 2 + 256;
+    return n;
+}
+
+int conv_fwd_impl(const qk_conv_desc_t *d, const void *x, const float *w, const float *bias, void *y,
+                  void *ws, size_t wsb, hipStream_t stream)
+{
+    if (!x || !w || !y) { set_error("x/w/y must not be NULL"); return QK_ERR_INVALID_ARG; }
+    if (d->has_bias && !bias) { set_error("has_bias set but bias is NULL"); return QK_ERR_INVALID_ARG; }
+    GemmGeom g;
+    memset(&g, 0, sizeof(g));
+    const Strides xs = act_strides(d->in_spatial, 4 * d->cq, d->layout);
+    const Strides ys = act_strides(d->out_spatial, 4 * d->fq, d->layout);
+    g.batch = d->batch;
+    g.M = d->batch * d->out_spatial[0] * d->out_spatial[1] * d->out_spatial[2];
+    g.Q = d->cq; g.J = d->fq; g.taps = taps_of(d);
+    for (int i = 0; i < 3; ++i) {
+        g.osp[i] = d->out_spatial[i]; g.isp[i] = d->in_spatial[i]; g.ks[i] = d->kernel[i];
+        g.pa[i] = d->stride[i]; g.pb[i] = d->dilation[i]; g.pc[i] = -d->pad_lo[i]; g.pd[i] = 1;
+        g.in_ss[i] = xs.ss[i];
+    }
+    g.in_sn = xs.sn; g.in_sc = xs.sc;
+    g.out_sn = ys.sn; g.out_ss = ys.flat_ss; g.out_sc = ys.sc;
+    g.sign_tbl = d->conj ? kSignConj : kSignConv;
+    g.relu = d->activation == QK_ACT_RELU;
+    g.has_bias = d->has_bias ? 1 : 0;
+    g.has_mask = 0;
+    if (d->dtype != QK_F32) {
+        const int r = try_hgemm_16(d->dtype, x, nullptr, w, bias, y, g, false, ws, wsb, stream);
+        if (r != 0) return r < 0 ? r : 0;
+    }
+    const bool vec = d->layout == QK_CH_LAST && d->cq % 4 == 0 && d->fq % 4 == 0 &&
+                     vec_aligned(x, d->dtype) && aligned(w, 16);
+    return launch_hgemm(d->dtype, x, nullptr, w, bias, y, g, vec, stream);
+}
+
+int conv_bwd_data_impl(const qk_conv_desc_t *d, const void *dy, const void *y, const float *w, void *dx,
+                       void *ws, size_t wsb, hipStream_t stream)
+{
+    if (!dy || !w || !dx) { set_error("dy/w/dx must not be NULL"); return QK_ERR_INVALID_ARG; }
+    const bool mask = d->activation == QK_ACT_RELU;
+    if (mask && !y) { set_error("activation is RELU: the forward output y is required"); return QK_ERR_INVALID_ARG; }
+    const size_t need = w_floats(d) * sizeof(float);
+    if (!ws || wsb < ws_bytes_impl(d, QK_OP_BWD_DATA)) {
+        set_error("bwd_data needs %zu workspace bytes, got %zu", ws_bytes_impl(d, QK_OP_BWD_DATA), wsb);
+        return QK_ERR_WORKSPACE;
+    }
+    if (!aligned(ws, 16)) { set_error("workspace must be 16-byte aligned"); return QK_ERR_WORKSPACE; }
+    GemmGeom g;
+    memset(&g, 0, sizeof(g));
+    const Strides dys = act_strides(d->out_spatial, 4 * d->fq, d->layout);
+    const Strides dxs = act_strides(d->in_spatial, 4 * d->cq, d->layout);
+    g.batch = d->batch;
+    g.M = d->batch * d->in_spatial[0] * d->in_spatial[1] * d->in_spatial[2];
+    g.Q = d->fq; g.J = d->cq; g.taps = taps_of(d);
+    for (int i = 0; i < 3; ++i) {
+        g.osp[i] = d->in_spatial[i]; g.isp[i] = d->out_spatial[i]; g.ks[i] = d->kernel[i];
+        g.pa[i] = 1; g.pb[i] = -d->dilation[i]; g.pc[i] = d->pad_lo[i]; g.pd[i] = d->stride[i];
+        g.in_ss[i] = dys.ss[i];
+    }
+    g.in_sn = dys.sn; g.in_sc = dys.sc;
+    g.out_sn = dxs.sn; g.out_ss = dxs.flat_ss; g.out_sc = dxs.sc;
+    g.sign_tbl = d->conj ? kSignConv : kSignConj;   // transposed table
+    g.relu = 0; g.has_bias = 0; g.has_mask = mask ? 1 : 0;
+    if (d->dtype != QK_F32) {
+        void *ws16 = static_cast<char *>(ws) + need;
+        const int r = try_hgemm_16(d->dtype, dy, mask ? y : nullptr, w, nullptr, dx, g, true, ws16,
+                                   wsb - need, stream);
+        if (r != 0) return r < 0 ? r : 0;
+    }
+    float *wt = static_cast<float *>(ws);
+    int rc = launch_transpose_w(w, wt, g.taps, d->cq, d->fq, stream);
+    if (rc) { set_error("transpose_w launch failed"); return rc; }
+    const bool vec = d->layout == QK_CH_LAST && d->cq % 4 == 0 && d->fq % 4 == 0 &&
+                     vec_aligned(dy, d->dtype) && (!mask || vec_aligned(y, d->dtype));
+    return launch_hgemm(d->dtype, dy, mask ? y : nullptr, wt, nullptr, dx, g, vec, stream);
+}
+
+int conv_bwd_weight_impl(const qk_conv_desc_t *d, const void *x, const void *dy, const void *y, float *dw,
+                         float *dbias, void *, size_t, hipStream_t stream)
+{
+    if (!x || !dy || !dw) { set_error("x/dy/dw must not be NULL"); return QK_ERR_INVALID_ARG; }
+    const bool mask = d->activation == QK_ACT_RELU;
+    if (mask && !y) { set_error("activation is RELU: the forward output y is required"); return QK_ERR_INVALID_ARG; }
+    if (d->has_bias && !dbias) { set_error("has_bias set but dbias is NULL"); return QK_ERR_INVALID_ARG; }
+    WgradGeom g;
+    memset(&g, 0, sizeof(g));
+    const Strides xs = act_strides(d->in_spatial, 4 * d->cq, d->layout);
+    const Strides dys = act_strides(d->out_spatial, 4 * d->fq, d->layout);
+    g.batch = d->batch;
+    g.M = d->batch * d->out_spatial[0] * d->out_spatial[1] * d->out_spatial[2];
+    g.Cq = d->cq; g.F = d->fq; g.taps = taps_of(d);
+    for (int i = 0; i < 3; ++i) {
+        g.osp[i] = d->out_spatial[i]; g.isp[i] = d->in_spatial[i]; g.ks[i] = d->kernel[i];
+        g.pa[i] = d->stride[i]; g.pb[i] = d->dilation[i]; g.pc[i] = -d->pad_lo[i];
+        g.x_ss[i] = xs.ss[i];
+    }
+    g.x_sn = xs.sn; g.x_sc = xs.sc;
+    g.dy_sn = dys.sn; g.dy_ss = dys.flat_ss; g.dy_sc = dys.sc;
+    g.sign_tbl = d->conj ? kSignConj : kSignConv;
+    g.has_mask = mask ? 1 : 0;
+    g.want_dbias = (d->has_bias && dbias) ? 1 : 0;
+    if (hipMemsetAsync(dw, 0, w_floats(d) * sizeof(float), stream) != hipSuccess) { set_error("memset dw failed"); return QK_ERR_LAUNCH; }
+    if (g.want_dbias && hipMemsetAsync(dbias, 0, 4 * (size_t)d->fq * sizeof(float), stream) != hipSuccess) {
+        set_error("memset dbias failed"); return QK_ERR_LAUNCH;
+    }
+    const bool vec = d->layout == QK_CH_LAST && d->cq % 4 == 0 && d->fq % 4 == 0 &&
+                     vec_aligned(x, d->dtype) && vec_aligned(dy, d->dtype) && (!mask || vec_aligned(y, d->dtype));
+    return launch_wgrad(d->dtype, x, dy, mask ? y : nullptr, dw, dbias, g, vec, stream);
+}
+
+qk_conv_desc_t dense_as_conv(const qk_dense_desc_t *d)
+{
+    qk_conv_desc_t c;
+    memset(&c, 0, sizeof(c));
+    c.rank = 0; c.batch = d->rows; c.cq = d->in_q; c.fq = d->q_units;
+    for (int i = 0; i < 3; ++i) {
+        c.in_spatial[i] = c.out_spatial[i] = c.kernel[i] = c.stride[i] = c.dilation[i] = 1;
+        c.pad_lo[i] = 0;
+    }
+    c.layout = QK_CH_LAST; c.dtype = d->dtype; c.activation = d->activation;
+    c.has_bias = d->has_bias; c.conj = 1;     // dense.py:139-143 is the transposed table
+    return c;
+}
+
+int check_launch(int rc, const char *what)
+{
+    if (rc == QK_ERR_LAUNCH) set_error("%s: kernel launch failed: %s", what, hipGetErrorString(hipGetLastError()));
+    return rc;
+}
+
+}  // namespace
+}  // namespace qk
+
+using namespace qk;
+
+extern "C" {
+
+int qk_version(void) { return QK_VERSION; }
+
+const char *qk_last_error(void) { return g_err; }
+
+size_t qk_conv_workspace_bytes(const qk_conv_desc_t *desc, int op)
+{
+    if (validate(desc, false)) return 0;
+    return ws_bytes_impl(desc, op);
+}
+
+size_t qk_dense_workspace_bytes(const qk_dense_desc_t *desc, int op)
+{
+    if (!desc) return 0;
+    const qk_conv_desc_t c = dense_as_conv(desc);
+    if (validate(&c, true)) return 0;
+    return ws_bytes_impl(&c, op);
+}
+
+int qk_conv_fwd(const qk_conv_desc_t *desc, const void *x, const float *w, const float *bias, void *y,
+                void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (int rc = validate(desc, false)) return rc;
+    return check_launch(conv_fwd_impl(desc, x, w, bias, y, workspace, workspace_bytes, (hipStream_t)stream), "qk_conv_fwd");
+}
+
+int qk_conv_bwd_data(const qk_conv_desc_t *desc, const void *dy, const void *y, const float *w, void *dx,
+                     void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (int rc = validate(desc, false)) return rc;
+    return check_launch(conv_bwd_data_impl(desc, dy, y, w, dx, workspace, workspace_bytes, (hipStream_t)stream), "qk_conv_bwd_data");
+}
+
+int qk_conv_bwd_weight(const qk_conv_desc_t *desc, const void *x, const void *dy, const void *y, float *dw,
+                       float *dbias, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (int rc = validate(desc, false)) return rc;
+    return check_launch(conv_bwd_weight_impl(desc, x, dy, y, dw, dbias, workspace, workspace_bytes, (hipStream_t)stream), "qk_conv_bwd_weight");
+}
+
+int qk_dense_fwd(const qk_dense_desc_t *desc, const void *x, const float *w, const float *bias, void *y,
+                 void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!desc) { set_error("descriptor is NULL"); return QK_ERR_INVALID_ARG; }
+    const qk_conv_desc_t c = dense_as_conv(desc);
+    if (int rc = validate(&c, true)) return rc;
+    return check_launch(conv_fwd_impl(&c, x, w, bias, y, workspace, workspace_bytes, (hipStream_t)stream), "qk_dense_fwd");
+}
+
+int qk_dense_bwd_data(const qk_dense_desc_t *desc, const void *dy, const void *y, const float *w, void *dx,
+                      void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!desc) { set_error("descriptor is NULL"); return QK_ERR_INVALID_ARG; }
+    const qk_conv_desc_t c = dense_as_conv(desc);
+    if (int rc = validate(&c, true)) return rc;
+    return check_launch(conv_bwd_data_impl(&c, dy, y, w, dx, workspace, workspace_bytes, (hipStream_t)stream), "qk_dense_bwd_data");
+}
+
+int qk_dense_bwd_weight(const qk_dense_desc_t *desc, const void *x, const void *dy, const void *y, float *dw,
+                        float *dbias, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!desc) { set_error("descriptor is NULL"); return QK_ERR_INVALID_ARG; }
+    const qk_conv_desc_t c = dense_as_conv(desc);
+    if (int rc = validate(&c, true)) return rc;
+    return check_launch(conv_bwd_weight_impl(&c, x, dy, y, dw, dbias, workspace, workspace_bytes, (hipStream_t)stream), "qk_dense_bwd_weight");
+}
+
+int qk_adam_step(float *param, const float *grad, float *m, float *v, size_t n, float lr, float beta1,
+                 float beta2, float eps, int32_t step, float grad_scale, void *stream)
+{
+    if (!param || !grad || !m || !v) { set_error("adam: NULL buffer"); return QK_ERR_INVALID_ARG; }
+    if (step < 1) { set_error("adam: step must be >= 1"); return QK_ERR_INVALID_ARG; }
+    return check_launch(launch_adam(param, grad, m, v, n, lr, beta1, beta2, eps, step, grad_scale, (hipStream_t)stream), "qk_adam_step");
+}
+
+}  // extern "C"

@@ -1,0 +1,135 @@
+// Internal definitions shared by the gfx950 kernels and the C-ABI front end (include/qk.h).
+// CDNA4 only: 64-wide wavefronts, MFMA, LDS.  No portability layer.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/qk.h"
+
+namespace qk {
+
+// ---------------------------------------------------------------------------------------
+// Hamilton sign tables.  Bit (a*4 + b) set  <=>  the product of GATHERED component a with
+// compact part (a ^ b) enters PRODUCED component b with a minus sign.
+//   conv.py:327-331   rows a (input), cols b (output):  [[+,+,+,+],[-,+,+,-],[-,-,+,+],[-,+,-,+]]
+//   dense.py:139-143  is the transpose.
+// ---------------------------------------------------------------------------------------
+constexpr unsigned kSignConv = 0x5390u;   // negatives at (1,0) (2,0) (3,0) (2,1) (3,2) (1,3)
+constexpr unsigned kSignConj = 0x284Eu;   // transpose: (0,1) (0,2) (0,3) (1,2) (2,3) (3,1)
+
+// ---------------------------------------------------------------------------------------
+// Implicit-GEMM geometry shared by forward and backward-data.
+//
+//   Out[m, b*J + j] = act( bias[b*J+j] + sum_{t, a, q} sgn(a,b) * In[pos(m,t), a*Q + q]
+//                                                      * Wk[((t*Q + q)*4 + (a^b))*J + j] )
+//
+//   forward : In = x,  Q = Cq, J = F,  Wk = the compact kernel as stored (conv.py:165)
+//   bwd-data: In = dy, Q = F,  J = Cq, Wk = per-tap transposed copy [t][f][p][c], sign table
+//             transposed, and the position map inverted (pd = stride).
+//
+// pos(m, t): m -> (n, o0, o1, o2); per axis num = o*pa + t*pb + pc; the tap contributes iff
+// num >= 0, num % pd == 0 and num/pd < isp (zero padding otherwise).
+// ---------------------------------------------------------------------------------------
+struct GemmGeom {
+    int M;              // batch * prod(osp)
+    int batch;
+    int osp[3];         // extents m decomposes into (the produced tensor's spatial extents)
+    int isp[3];         // spatial extents of the gathered tensor
+    int Q;              // gathered channels per component
+    int J;              // produced channels per component
+    int ks[3];
+    int taps;
+    int pa[3], pb[3], pc[3], pd[3];
+    long long in_sn, in_ss[3], in_sc;     // element strides of the gathered tensor
+    long long out_sn, out_ss, out_sc;     // produced tensor: n*out_sn + s*out_ss + ch*out_sc
+    unsigned sign_tbl;
+    int relu;           // epilogue activation
+    int has_bias;
+    int has_mask;       // gathered value is zeroed where mask[same index] <= 0 (relu backward)
+};
+
+// Backward-weight geometry:  dW[t, c, p, f] = sum_{a^b=p} sgn(a,b) sum_m x_a[pos(m,t), c] * dy_b[m, f]
+struct WgradGeom {
+    int M;
+    int batch;
+    int osp[3];         // dy spatial extents (m decomposes into these)
+    int isp[3];         // x spatial extents
+    int Cq, F;
+    int ks[3];
+    int taps;
+    int pa[3], pb[3], pc[3];              // forward position map (pd == 1)
+    long long x_sn, x_ss[3], x_sc;
+    long long dy_sn, dy_ss, dy_sc;
+    unsigned sign_tbl;
+    int has_mask;
+    int want_dbias;
+    int m_per_split;    // rows of M each blockIdx.x reduces (multiple of the kernel's K step)
+};
+
+// ---------------------------------------------------------------------------------------
+// Element types in HBM.  Accumulation is always fp32.
+// ---------------------------------------------------------------------------------------
+struct bf16 { uint16_t x; };
+typedef _Float16 f16;
+
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(bf16 v) { return __uint_as_float(((uint32_t)v.x) << 16); }
+__device__ __forceinline__ float to_f32(f16 v) { return (float)v; }
+
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16 from_f32<bf16>(float v)
+{
+    // round-to-nearest-even, NaN kept quiet
+    uint32_t u = __float_as_uint(v);
+    bf16 r;
+    if ((u & 0x7fffffffu) > 0x7f800000u) { r.x = (uint16_t)((u >> 16) | 0x40u); return r; }
+    u += 0x7fffu + ((u >> 16) & 1u);
+    r.x = (uint16_t)(u >> 16);
+    return r;
+}
+template <> __device__ __forceinline__ f16 from_f32<f16>(float v) { return (f16)v; }
+
+// 4 consecutive elements -> 4 floats (16 B for f32, 8 B for the 16-bit types)
+__device__ __forceinline__ void load4(const float *p, float (&o)[4])
+{
+    const float4 v = *reinterpret_cast<const float4 *>(p);
+    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+}
+__device__ __forceinline__ void load4(const bf16 *p, float (&o)[4])
+{
+    const uint2 v = *reinterpret_cast<const uint2 *>(p);
+    o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
+    o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+}
+__device__ __forceinline__ void load4(const f16 *p, float (&o)[4])
+{
+    typedef f16 h4 __attribute__((ext_vector_type(4)));
+    const h4 v = *reinterpret_cast<const h4 *>(p);
+    o[0] = (float)v[0]; o[1] = (float)v[1]; o[2] = (float)v[2]; o[3] = (float)v[3];
+}
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+// row of accumulator register r of a 32x32 MFMA tile held by `lane` (column = lane & 31)
+__device__ __forceinline__ int mfma32_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+// ---------------------------------------------------------------------------------------
+// host-side launch entry points implemented in the .hip files
+// ---------------------------------------------------------------------------------------
+// fp32-MFMA Hamilton implicit GEMM (forward and backward-data)
+int launch_hgemm(int dtype, const void *in, const void *mask, const float *wk, const float *bias,
+                 void *out, const GemmGeom &g, bool vec_ok, hipStream_t stream);
+// fp32-MFMA Hamilton backward-weight (+ fused bias gradient); dw/dbias must be zeroed before
+int launch_wgrad(int dtype, const void *x, const void *dy, const void *ymask, float *dw,
+                 float *dbias, WgradGeom g, bool vec_ok, hipStream_t stream);
+// aux: dst[t][f][p][c] = src[t][c][p][f]
+int launch_transpose_w(const float *src, float *dst, int taps, int Cq, int F, hipStream_t stream);
+int launch_adam(float *p, const float *g, float *m, float *v, size_t n, float lr, float b1,
+                float b2, float eps, int step, float gscale, hipStream_t stream);
+
+void set_error(const char *fmt, ...);
+
+}  // namespace qk

@@ -1,0 +1,102 @@
+"""Data-parallel training plumbing: one process per GPU, RCCL gradient all-reduce over xGMI.
+
+The reference has no distributed path at all (an unused `multi_gpu_model`
+import, models/interspeech_model.py:25); BASELINE.json's north star asks for pure data
+parallelism on one 8xMI355X node.  The hot path shards by batch rows (independent samples),
+every rank holds a full replica of the small compact weights, and the only exchange per
+step is ONE sum all-reduce of the flat fp32 compact-gradient buffer:
+
+  * all parameters / gradients of the quaternion layers live in two flat fp32 buffers
+    (`FlatParams`), so the exchange is a single collective (xGMI is point-to-point, 7 links
+    x ~153 GB/s per GPU: a ring all-reduce of S bytes is bound by 2*(N-1)/N * S / link-BW,
+    and for these <= 150 MB buffers latency, not bandwidth, is what matters -> one big
+    message, not per-layer messages);
+  * the 1/world_size averaging is folded into the fused Adam kernel (`grad_scale`);
+  * `torch.distributed` backend "nccl" IS RCCL on ROCm; "gloo" is used by the CPU tests.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun).
+    Returns (rank, world_size, local_rank).  World size 1 needs no process group."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        if backend == 'nccl':
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend, rank=rank, world_size=world,
+                                    device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+class FlatParams(object):
+    """Re-homes a list of parameters into ONE flat fp32 buffer (+ a flat gradient buffer).
+
+    After construction every parameter's `.data` is a view into `self.param` and `.grad` a view
+    into `self.grad`, so an optimizer step / all-reduce touches two tensors, not 2*len(params)."""
+
+    def __init__(self, params):
+        self.params = [p for p in params]
+        if not self.params:
+            raise ValueError('no parameters')
+        dev = self.params[0].device
+        sizes = [p.numel() for p in self.params]
+        # 64-element (256 B) alignment keeps every view usable for 16-byte vector access
+        self.offsets, off = [], 0
+        for n in sizes:
+            self.offsets.append(off)
+            off += (n + 63) // 64 * 64
+        self.numel = off
+        self.param = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(off, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for p, o in zip(self.params, self.offsets):
+                n = p.numel()
+                self.param[o:o + n].copy_(p.detach().reshape(-1).float())
+                p.data = self.param[o:o + n].view(p.shape)
+                p.grad = self.grad[o:o + n].view(p.shape)
+
+    def grad_view(self, i):
+        p, o = self.params[i], self.offsets[i]
+        return self.grad[o:o + p.numel()].view(p.shape)
+
+    def zero_grad(self):
+        self.grad.zero_()
+
+
+def broadcast_params(flat, src=0, group=None):
+    """Identical replicas: rank `src`'s weights win (the reference init is host-side and seeded,
+    so ranks usually agree already; this makes it unconditional)."""
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.broadcast(flat.param, src=src, group=group)
+
+
+def allreduce_sum_(tensor, group=None, async_op=False):
+    """Sum all-reduce of the flat gradient buffer (RCCL on GPUs).  Returns the work handle when
+    async_op; no-op for world size 1."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return None
+    return dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+
+
+def world_size(group=None):
+    return dist.get_world_size(group) if dist.is_initialized() else 1
+
+
+def shard_rows(n_rows, rank, world):
+    """Contiguous batch shard of `rank` (weak scaling keeps per-rank rows fixed instead)."""
+    per = (n_rows + world - 1) // world
+    lo = min(n_rows, rank * per)
+    return lo, min(n_rows, lo + per)

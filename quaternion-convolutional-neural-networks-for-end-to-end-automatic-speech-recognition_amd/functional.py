@@ -1,0 +1,235 @@
+"""torch.autograd bindings of the HIP Hamilton-product kernels (through the C-ABI only).
+
+`quaternion_conv` / `quaternion_dense` compute what QuaternionConv.call
+(complexnn/conv.py:288-345) and QuaternionDense.call (complexnn/dense.py:126-164) of the
+reference compute, with the backward TF autodiff would produce -- on MI355X, from the
+compact kernel, without materialising the 4x-expanded real kernel.
+
+PyTorch is plumbing here: it owns the device buffers (caching allocator), supplies the
+current HIP stream and chains the backward calls.  There is NO CPU or eager fallback:
+a CPU tensor or a missing libqk_hip.so raises.
+"""
+import ctypes
+
+import torch
+
+from . import _lib as L
+from ._shape import conv_output_length, normalize_tuple, tf_pads
+
+_DTYPES = {torch.float32: L.QK_F32, torch.bfloat16: L.QK_BF16, torch.float16: L.QK_F16}
+
+
+def _require_device(t, what):
+    if not t.is_cuda:
+        raise RuntimeError('%s: got a CPU tensor. The quaternion layers run only on the MI355X HIP '
+                           'path (libqk_hip.so); there is no CPU fallback.' % what)
+    if t.dtype not in _DTYPES:
+        raise TypeError('%s: unsupported dtype %s (float32, bfloat16, float16)' % (what, t.dtype))
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+class _Call(object):
+    """One layer invocation: descriptor + the three C-ABI entry points it uses."""
+
+    def __init__(self, desc, names, ws_fn, x_shape, y_shape, w_shape, relu):
+        self.desc, self.names, self.ws_fn = desc, names, ws_fn
+        self.x_shape, self.y_shape, self.w_shape, self.relu = x_shape, y_shape, w_shape, relu
+        self.static_buffers = False      # True: keep workspaces (graph capture / bench loops)
+        self._ws_cache = {}
+
+    def _ws(self, op, like):
+        n = int(getattr(L.lib(), self.ws_fn)(ctypes.byref(self.desc), op))
+        if n == 0:
+            return None, 0
+        if self.static_buffers:
+            buf = self._ws_cache.get(op)
+            if buf is None:
+                buf = self._ws_cache[op] = torch.empty(n, dtype=torch.uint8, device=like.device)
+            return buf, n
+        return torch.empty(n, dtype=torch.uint8, device=like.device), n
+
+    def fwd(self, x, w, bias, out=None):
+        y = out if out is not None else torch.empty(self.y_shape, dtype=x.dtype, device=x.device)
+        ws, n = self._ws(L.QK_OP_FWD, x)
+        with torch.cuda.device(x.device):
+            rc = getattr(L.lib(), self.names[0])(ctypes.byref(self.desc), _ptr(x), _ptr(w), _ptr(bias),
+                                                 _ptr(y), _ptr(ws), n, _stream(x))
+        L.check(rc, self.names[0])
+        return y
+
+    def bwd_data(self, dy, y, w, out=None):
+        dx = out if out is not None else torch.empty(self.x_shape, dtype=dy.dtype, device=dy.device)
+        ws, n = self._ws(L.QK_OP_BWD_DATA, dy)
+        with torch.cuda.device(dy.device):
+            rc = getattr(L.lib(), self.names[1])(ctypes.byref(self.desc), _ptr(dy), _ptr(y), _ptr(w),
+                                                 _ptr(dx), _ptr(ws), n, _stream(dy))
+        L.check(rc, self.names[1])
+        return dx
+
+    def bwd_weight(self, x, dy, y, has_bias, out=None):
+        if out is not None:
+            dw, db = out
+        else:
+            dw = torch.empty(self.w_shape, dtype=torch.float32, device=x.device)
+            db = torch.empty((self.w_shape[-1],), dtype=torch.float32, device=x.device) if has_bias else None
+        ws, n = self._ws(L.QK_OP_BWD_WEIGHT, x)
+        with torch.cuda.device(x.device):
+            rc = getattr(L.lib(), self.names[2])(ctypes.byref(self.desc), _ptr(x), _ptr(dy), _ptr(y),
+                                                 _ptr(dw), _ptr(db), _ptr(ws), n, _stream(x))
+        L.check(rc, self.names[2])
+        return dw, db
+
+
+class _HamiltonFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, bias, call):
+        y = call.fwd(x, w, bias)
+        ctx.call = call
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, w, y if call.relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        call = ctx.call
+        dy = dy.contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = call.bwd_data(dy, y, w)
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dw, db = call.bwd_weight(x, dy, y, ctx.has_bias)
+        return dx, dw, db, None
+
+
+def _act_code(activation):
+    if activation in (None, 'linear'):
+        return L.QK_ACT_LINEAR
+    if activation == 'relu':
+        return L.QK_ACT_RELU
+    raise ValueError('fused activation must be None/"linear"/"relu", got %r' % (activation,))
+
+
+def _check_weights(w, bias, n_out):
+    if w.dtype != torch.float32 or (bias is not None and bias.dtype != torch.float32):
+        raise TypeError('kernel / bias must be float32 (Keras floatx); activations may be 16-bit')
+    if bias is not None and tuple(bias.shape) != (n_out,):
+        raise ValueError('bias must have shape (%d,), got %s' % (n_out, tuple(bias.shape)))
+
+
+def conv_call(x_shape, w_shape, dtype, rank, strides=1, padding='valid', layout='channels_last',
+              dilation_rate=1, activation=None, use_bias=True, conj=False):
+    """Descriptor for one conv call on a PHYSICAL layout (`layout` describes the buffer)."""
+    st = normalize_tuple(strides, rank, 'strides')
+    dl = normalize_tuple(dilation_rate, rank, 'dilation_rate')
+    if len(x_shape) != rank + 2 or len(w_shape) != rank + 2:
+        raise ValueError('rank %d conv needs %d-D input and kernel' % (rank, rank + 2))
+    if layout == 'channels_first':
+        ci, sp = x_shape[1], tuple(x_shape[2:])
+    else:
+        ci, sp = x_shape[-1], tuple(x_shape[1:-1])
+    cq, fq = w_shape[-2], w_shape[-1] // 4
+    if ci != 4 * cq or w_shape[-1] != 4 * fq:
+        raise ValueError('input channels %d / kernel shape %s are not quaternion-consistent'
+                         % (ci, tuple(w_shape)))
+    d = L.ConvDesc()
+    d.rank, d.batch, d.cq, d.fq = rank, x_shape[0], cq, fq
+    out_sp = []
+    for i in range(3):
+        if i < rank:
+            k = w_shape[i]
+            d.in_spatial[i], d.kernel[i], d.stride[i], d.dilation[i] = sp[i], k, st[i], dl[i]
+            d.pad_lo[i] = tf_pads(sp[i], k, st[i], dl[i], padding)[0]
+            d.out_spatial[i] = conv_output_length(sp[i], k, padding, st[i], dl[i])
+            if d.out_spatial[i] <= 0:
+                raise ValueError('convolution output would be empty on axis %d' % i)
+            out_sp.append(d.out_spatial[i])
+        else:
+            d.in_spatial[i] = d.out_spatial[i] = d.kernel[i] = d.stride[i] = d.dilation[i] = 1
+            d.pad_lo[i] = 0
+    d.layout = L.QK_CH_FIRST if layout == 'channels_first' else L.QK_CH_LAST
+    d.dtype = _DTYPES[dtype]
+    d.activation = _act_code(activation)
+    d.has_bias = int(bool(use_bias))
+    d.conj = int(bool(conj))
+    if layout == 'channels_first':
+        y_shape = (x_shape[0], 4 * fq) + tuple(out_sp)
+    else:
+        y_shape = (x_shape[0],) + tuple(out_sp) + (4 * fq,)
+    return _Call(d, ('qk_conv_fwd', 'qk_conv_bwd_data', 'qk_conv_bwd_weight'),
+                 'qk_conv_workspace_bytes', tuple(x_shape), y_shape, tuple(w_shape),
+                 d.activation == L.QK_ACT_RELU)
+
+
+def dense_call(x_shape, w_shape, dtype, activation=None, use_bias=True):
+    if len(x_shape) != 2 or len(w_shape) != 2:
+        raise ValueError('quaternion dense needs 2-D input and kernel')
+    in_q, units = w_shape
+    if x_shape[1] != 4 * in_q or units % 4:
+        raise ValueError('input width %d / kernel shape %s are not quaternion-consistent'
+                         % (x_shape[1], tuple(w_shape)))
+    d = L.DenseDesc()
+    d.rows, d.in_q, d.q_units = x_shape[0], in_q, units // 4
+    d.dtype = _DTYPES[dtype]
+    d.activation = _act_code(activation)
+    d.has_bias = int(bool(use_bias))
+    return _Call(d, ('qk_dense_fwd', 'qk_dense_bwd_data', 'qk_dense_bwd_weight'),
+                 'qk_dense_workspace_bytes', tuple(x_shape), (x_shape[0], units), tuple(w_shape),
+                 d.activation == L.QK_ACT_RELU)
+
+
+def quaternion_conv(x, kernel, bias=None, strides=1, padding='valid', data_format='channels_last',
+                    dilation_rate=1, activation=None, conj=False, internal_layout='channels_last'):
+    """y = act(W (x) x + b): Hamilton-product convolution of rank kernel.dim()-2.
+
+    x       (N, *spatial, 4Cq) or (N, 4Cq, *spatial) -- component-planar channels (r|i|j|k)
+    kernel  (*kernel_size, Cq, 4F) float32 compact kernel (conv.py:165, init.py:91)
+    For data_format='channels_first' and internal_layout='channels_last' (default) the data is
+    kept PHYSICALLY channels-last (a strided view with the logical channels_first shape is
+    returned, torch.channels_last style): MFMA operands want the reduction axis contiguous.
+    internal_layout='native' runs the channels_first buffers as they are.
+    """
+    _require_device(x, 'quaternion_conv')
+    rank = kernel.dim() - 2
+    _check_weights(kernel, bias, kernel.shape[-1])
+    ch_first = data_format == 'channels_first'
+    if ch_first and internal_layout == 'channels_last':
+        xp = x.movedim(1, -1).contiguous()
+        layout = 'channels_last'
+    else:
+        xp = x.contiguous()
+        layout = data_format
+    call = conv_call(tuple(xp.shape), tuple(kernel.shape), xp.dtype, rank, strides, padding, layout,
+                     dilation_rate, activation, bias is not None, conj)
+    y = _HamiltonFn.apply(xp, kernel.contiguous(), bias, call)
+    if ch_first and internal_layout == 'channels_last':
+        y = y.movedim(-1, 1)
+    return y
+
+
+def quaternion_dense(x, kernel, bias=None, activation=None):
+    """y = act(conj(W) (x) x + b) -- the table dense.py:139-143 builds (transpose of conv's)."""
+    _require_device(x, 'quaternion_dense')
+    _check_weights(kernel, bias, kernel.shape[-1])
+    xp = x.contiguous()
+    call = dense_call(tuple(xp.shape), tuple(kernel.shape), xp.dtype, activation, bias is not None)
+    return _HamiltonFn.apply(xp, kernel.contiguous(), bias, call)
+
+
+def adam_step(param, grad, m, v, step, lr=0.001, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0):
+    """Fused Keras-Adam update of a flat float32 buffer (qk_adam_step)."""
+    for t in (param, grad, m, v):
+        if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
+            raise RuntimeError('adam_step needs contiguous float32 device buffers')
+    n = param.numel()
+    with torch.cuda.device(param.device):
+        rc = L.lib().qk_adam_step(_ptr(param), _ptr(grad), _ptr(m), _ptr(v), n, lr, beta1, beta2, eps,
+                                  int(step), grad_scale, _stream(param))
+    L.check(rc, 'qk_adam_step')

@@ -1,0 +1,212 @@
+"""GPU parity: the HIP path (through the C-ABI, via qcnn_amd.functional) against
+  (1) the committed golden fixtures generated from the reference's own layer code, and
+  (2) the CPU oracle on seeded inputs at sizes the oracle finishes in seconds.
+
+Tolerances (stated per BASELINE.json north_star: fwd/bwd within 1e-4 relative, fp32):
+  fp32 : max|got-want| <= 1e-4 * max|want|        (observed ~1e-6: the fp32 MFMA is an fmaf chain)
+  bf16 : inputs are rounded to bf16 first and the oracle runs on the ROUNDED inputs in float64;
+         16-bit outputs (y, dx) carry one bf16 rounding -> 1e-2 * max|want|; fp32 outputs
+         (dkernel, dbias) -> 2e-3 (y feeding the relu mask is itself bf16-rounded)
+  fp16 : same scheme, 2e-3 / 1e-3.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_layer_files, layer_kwargs, load_golden
+
+pytestmark = pytest.mark.gpu
+
+FILES = golden_layer_files()
+IDS = [os.path.basename(f)[:-4] for f in FILES]
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    return torch.device('cuda:0')
+
+
+def _rel_err(got, want):
+    want = np.asarray(want, dtype=np.float64)
+    got = np.asarray(got, dtype=np.float64)
+    assert got.shape == want.shape, (got.shape, want.shape)
+    return float(np.abs(got - want).max()) / max(float(np.abs(want).max()), 1e-30)
+
+
+def _run_layer(F, rec_x, rec_w, rec_b, rec_dy, rank, kw, dtype, internal_layout='channels_last'):
+    dev = _dev()
+    x = torch.tensor(rec_x, device=dev).to(dtype).requires_grad_(True)
+    w = torch.tensor(rec_w, device=dev, dtype=torch.float32).requires_grad_(True)
+    b = None
+    if rec_b is not None:
+        b = torch.tensor(rec_b, device=dev, dtype=torch.float32).requires_grad_(True)
+    if rank == 0:
+        y = F.quaternion_dense(x, w, b, activation=kw['activation'])
+    else:
+        y = F.quaternion_conv(x, w, b, internal_layout=internal_layout, **kw)
+    dy = torch.tensor(rec_dy, device=dev).to(dtype)
+    y.backward(dy)
+    torch.cuda.synchronize()
+    out = dict(y=y.detach().float().cpu().numpy(), dx=x.grad.float().cpu().numpy(),
+               dkernel=w.grad.cpu().numpy())
+    if b is not None:
+        out['dbias'] = b.grad.cpu().numpy()
+    return out
+
+
+@pytest.mark.parametrize('layout', ['channels_last', 'native'])
+@pytest.mark.parametrize('path', FILES, ids=IDS)
+def test_fp32_matches_reference_golden(path, layout):
+    import qcnn_amd
+    rec, cfg = load_golden(path)
+    rank, kw = layer_kwargs(cfg)
+    if layout == 'native' and kw.get('data_format', 'channels_last') != 'channels_first':
+        pytest.skip('native == channels_last for this case')
+    got = _run_layer(qcnn_amd.functional, rec['x'], rec['kernel'], rec.get('bias'), rec['dy'], rank, kw,
+                     torch.float32, layout)
+    for k, v in got.items():
+        err = _rel_err(v, rec[k])
+        assert err <= 1e-4, '%s: rel err %.3g' % (k, err)
+
+
+def _oracle_case(rank, x_shape, w_shape, kw, seed, dtype=torch.float32, use_bias=True):
+    from oracle import oracle
+    rng = np.random.RandomState(seed)
+    x = rng.randn(*x_shape).astype(np.float32)
+    w = (rng.randn(*w_shape) / np.sqrt(np.prod(w_shape[:-1]) * 4)).astype(np.float32)
+    b = (0.1 * rng.randn(w_shape[-1])).astype(np.float32) if use_bias else None
+    if dtype != torch.float32:
+        x = torch.tensor(x).to(dtype).float().numpy()
+    y = oracle.forward(x, w, b, rank, **kw)
+    dy = rng.randn(*y.shape).astype(np.float32)
+    if dtype != torch.float32:
+        dy = torch.tensor(dy).to(dtype).float().numpy()
+        # the GPU masks relu' with ITS y (rounded to 16 bit); positions where the rounding
+        # flips the sign of a ~0 output are excluded by construction: y==0 after rounding only
+        # if |y| underflows, which cannot happen at these magnitudes.
+    dx, dw, db = oracle.backward(x, w, b, dy, rank, y=y, **kw)
+    want = dict(y=y, dx=dx, dkernel=dw)
+    if use_bias:
+        want['dbias'] = db
+    return x, w, b, dy, want
+
+
+ORACLE_CASES = [
+    # id, rank, x_shape, w_shape, kwargs
+    ('cfg2_conv1d_b8_f64', 1, (8, 200, 160), (3, 40, 256),
+     dict(padding='same', activation='relu')),
+    ('cfg2_conv1d_b64_f32', 1, (64, 200, 160), (3, 40, 128),
+     dict(padding='same', activation='relu')),
+    ('conv1d_odd_channels', 1, (5, 37, 28), (5, 7, 36),
+     dict(padding='same', strides=2, activation='relu')),
+    ('conv2d_body_small', 2, (2, 14, 40, 128), (3, 5, 32, 128),
+     dict(padding='same', activation='relu')),
+    ('conv2d_chfirst_body_small', 2, (2, 128, 14, 40), (3, 5, 32, 128),
+     dict(padding='same', activation='relu', data_format='channels_first')),
+    ('conv2d_first_layer', 2, (3, 4, 41, 50), (3, 5, 1, 128),
+     dict(padding='same', activation='relu', data_format='channels_first')),
+    ('conv2d_stride_dil', 2, (2, 19, 23, 16), (3, 2, 4, 48),
+     dict(padding='same', strides=(2, 1), activation=None)),
+    ('conv3d_small', 3, (2, 6, 7, 5, 16), (2, 3, 2, 4, 32),
+     dict(padding='same', activation='relu')),
+    ('dense_qdnn0', 0, (32, 1000), (250, 512), dict(activation='relu')),
+    ('dense_timit_head', 0, (300, 3584), (896, 256), dict(activation='relu')),
+    ('dense_wide', 0, (130, 512), (128, 1024), dict(activation=None)),
+]
+
+
+@pytest.mark.parametrize('case', ORACLE_CASES, ids=[c[0] for c in ORACLE_CASES])
+def test_fp32_matches_oracle(case):
+    import qcnn_amd
+    _, rank, xs, ws, kw = case
+    x, w, b, dy, want = _oracle_case(rank, xs, ws, kw, seed=7)
+    got = _run_layer(qcnn_amd.functional, x, w, b, dy, rank, kw, torch.float32)
+    for k, v in got.items():
+        err = _rel_err(v, want[k])
+        assert err <= 1e-4, '%s: rel err %.3g' % (k, err)
+
+
+HALF_CASES = [c for c in ORACLE_CASES if c[0] in (
+    'cfg2_conv1d_b8_f64', 'conv1d_odd_channels', 'conv2d_body_small', 'conv2d_chfirst_body_small',
+    'conv2d_first_layer', 'dense_timit_head')]
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16], ids=['bf16', 'fp16'])
+@pytest.mark.parametrize('case', HALF_CASES, ids=[c[0] for c in HALF_CASES])
+def test_half_matches_oracle_on_rounded_inputs(case, dtype):
+    import qcnn_amd
+    _, rank, xs, ws, kw = case
+    x, w, b, dy, want = _oracle_case(rank, xs, ws, kw, seed=11, dtype=dtype)
+    got = _run_layer(qcnn_amd.functional, x, w, b, dy, rank, kw, dtype)
+    tol16, tol32 = (1e-2, 2e-3) if dtype == torch.bfloat16 else (2e-3, 1e-3)
+    for k, v in got.items():
+        err = _rel_err(v, want[k])
+        tol = tol16 if k in ('y', 'dx') else tol32
+        assert err <= tol, '%s: rel err %.3g > %.1g' % (k, err, tol)
+
+
+def test_cpu_tensor_raises_no_fallback():
+    import qcnn_amd
+    x = torch.randn(2, 10, 8)
+    w = torch.randn(3, 2, 8)
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        qcnn_amd.functional.quaternion_conv(x, w)
+
+
+def test_layer_api_on_device_matches_golden():
+    """The Keras-style layer objects (build/call) drive the same path."""
+    from qcnn_amd.complexnn import QuaternionConv2D, QuaternionDense
+    dev = _dev()
+    rec, cfg = load_golden([f for f in FILES if 'g06_' in f][0])
+    layer = QuaternionConv2D(4, (3, 5), padding='same', data_format='channels_first', activation='relu')
+    x = torch.tensor(rec['x'], device=dev)
+    layer(x)
+    with torch.no_grad():
+        layer.kernel.copy_(torch.tensor(rec['kernel'], device=dev))
+        layer.bias.copy_(torch.tensor(rec['bias'], device=dev))
+    y = layer(x)
+    assert tuple(y.shape) == tuple(rec['y'].shape)
+    assert _rel_err(y.detach().cpu().numpy(), rec['y']) <= 1e-4
+    rec, cfg = load_golden([f for f in FILES if 'g10_' in f][0])
+    d = QuaternionDense(12, activation='relu')
+    x = torch.tensor(rec['x'], device=dev)
+    d(x)
+    with torch.no_grad():
+        d.r.copy_(torch.tensor(rec['kernel'], device=dev))
+        d.bias.copy_(torch.tensor(rec['bias'], device=dev))
+    assert _rel_err(d(x).detach().cpu().numpy(), rec['y']) <= 1e-4
+
+
+@pytest.mark.parametrize('dtype,tol', [(torch.float32, 2e-4), (torch.bfloat16, 3e-2)], ids=['fp32', 'bf16'])
+def test_full_size_properties_cfg3_body(dtype, tol):
+    """BASELINE config-3 body layer at full size (B=256 would take the oracle hours): size-independent
+    properties -- linearity in x, and the adjoint identities <dy, A x> = <A^T dy, x> = <dW(x,dy), W>."""
+    import qcnn_amd
+    F = qcnn_amd.functional
+    dev = _dev()
+    g = torch.Generator(device=dev).manual_seed(0)
+    B = 32
+    x1 = torch.randn(B, 14, 200, 128, device=dev, generator=g)
+    x2 = torch.randn(B, 14, 200, 128, device=dev, generator=g)
+    w = (torch.randn(3, 5, 32, 128, device=dev, generator=g) / 40).requires_grad_(True)
+    kw = dict(padding='same', activation=None)
+    y1 = F.quaternion_conv(x1.to(dtype), w, None, **kw).float()
+    y2 = F.quaternion_conv(x2.to(dtype), w, None, **kw).float()
+    x12 = (x1.to(dtype).float() + 2 * x2.to(dtype).float())
+    if dtype == torch.float32:
+        y12 = F.quaternion_conv(x12, w, None, **kw)
+        lin = (y12 - (y1 + 2 * y2)).abs().max() / y12.abs().max()
+        assert float(lin) <= tol, 'linearity %.3g' % float(lin)
+    xa = x1.to(dtype).requires_grad_(True)
+    y = F.quaternion_conv(xa, w, None, **kw)
+    dy = torch.randn(y.shape, device=dev, generator=g).to(dtype)
+    y.backward(dy)
+    lhs = float((y.double() * dy.double()).sum())
+    rhs_x = float((xa.grad.double() * xa.detach().double()).sum())
+    rhs_w = float((w.grad.double() * w.detach().double()).sum())
+    scale = float(y.double().norm() * dy.double().norm())
+    assert abs(lhs - rhs_x) / scale <= tol, ('adjoint x', lhs, rhs_x, scale)
+    assert abs(lhs - rhs_w) / scale <= tol, ('adjoint w', lhs, rhs_w, scale)
