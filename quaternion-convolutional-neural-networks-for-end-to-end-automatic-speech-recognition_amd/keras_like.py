@@ -103,11 +103,66 @@ def _compute_fans(shape, data_format='channels_last'):
     return shape[-2] * receptive_field_size, shape[-1] * receptive_field_size
 
 
+class RandomNormal(Initializer):
+    def __init__(self, mean=0., stddev=0.05, seed=None):
+        self.mean, self.stddev, self.seed = mean, stddev, seed
+
+    def __call__(self, shape, dtype=None):
+        return np.random.RandomState(self.seed).normal(self.mean, self.stddev, shape)
+
+    def get_config(self):
+        return {'mean': self.mean, 'stddev': self.stddev, 'seed': self.seed}
+
+
+class RandomUniform(Initializer):
+    def __init__(self, minval=-0.05, maxval=0.05, seed=None):
+        self.minval, self.maxval, self.seed = minval, maxval, seed
+
+    def __call__(self, shape, dtype=None):
+        return np.random.RandomState(self.seed).uniform(self.minval, self.maxval, shape)
+
+    def get_config(self):
+        return {'minval': self.minval, 'maxval': self.maxval, 'seed': self.seed}
+
+
+class VarianceScaling(Initializer):
+    """keras.initializers.VarianceScaling (glorot / he / lecun families) for the real-valued
+    weights that sit next to the quaternion layers (e.g. a bias or a softmax Dense)."""
+
+    def __init__(self, scale=1.0, mode='fan_in', distribution='normal', seed=None):
+        self.scale, self.mode, self.distribution, self.seed = scale, mode, distribution, seed
+
+    def __call__(self, shape, dtype=None):
+        fan_in, fan_out = _compute_fans(shape) if len(shape) >= 2 else (shape[0], shape[0])
+        n = {'fan_in': fan_in, 'fan_out': fan_out, 'fan_avg': (fan_in + fan_out) / 2.}[self.mode]
+        scale = self.scale / max(1., n)
+        rng = np.random.RandomState(self.seed)
+        if self.distribution == 'normal':
+            return rng.normal(0., np.sqrt(scale), shape)
+        limit = np.sqrt(3. * scale)
+        return rng.uniform(-limit, limit, shape)
+
+    def get_config(self):
+        return {'scale': self.scale, 'mode': self.mode, 'distribution': self.distribution,
+                'seed': self.seed}
+
+
+def _vs(scale, mode, distribution):
+    return lambda seed=None: VarianceScaling(scale, mode, distribution, seed)
+
+
 class initializers(object):
     Initializer, Zeros, Ones, Constant = Initializer, Zeros, Ones, Constant
+    RandomNormal, RandomUniform, VarianceScaling = RandomNormal, RandomUniform, VarianceScaling
     _compute_fans = staticmethod(_compute_fans)
     _by_name = {'zeros': Zeros, 'ones': Ones, 'constant': Constant,
-                'Zeros': Zeros, 'Ones': Ones, 'Constant': Constant}
+                'Zeros': Zeros, 'Ones': Ones, 'Constant': Constant,
+                'random_normal': RandomNormal, 'RandomNormal': RandomNormal, 'normal': RandomNormal,
+                'random_uniform': RandomUniform, 'RandomUniform': RandomUniform, 'uniform': RandomUniform,
+                'VarianceScaling': VarianceScaling,
+                'glorot_uniform': _vs(1., 'fan_avg', 'uniform'), 'glorot_normal': _vs(1., 'fan_avg', 'normal'),
+                'he_uniform': _vs(2., 'fan_in', 'uniform'), 'he_normal': _vs(2., 'fan_in', 'normal'),
+                'lecun_uniform': _vs(1., 'fan_in', 'uniform'), 'lecun_normal': _vs(1., 'fan_in', 'normal')}
 
     @staticmethod
     def get(identifier):

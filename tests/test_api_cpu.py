@@ -1,0 +1,253 @@
+"""CPU: the drop-in surface against facts captured from the reference
+(tests/golden/g00_api.json, g12_init.npz), the C-ABI library's symbols, and host logic."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import qcnn_amd
+from qcnn_amd import _lib, _shape, functional
+from qcnn_amd.complexnn import (QuaternionConv, QuaternionConv1D, QuaternionConv2D, QuaternionConv3D,
+                                QuaternionConvolution1D, QuaternionConvolution2D, QuaternionConvolution3D,
+                                QuaternionDense, GetRFirst, GetIFirst, GetJFirst, GetKFirst,
+                                get_rpart_first, get_ipart_first, get_jpart_first, get_kpart_first,
+                                getpart_quaternion_output_shape_first, qconv_init, qdense_init, sqrt_init)
+from conftest import GOLDEN, ROOT
+
+
+@pytest.fixture(scope='module')
+def api():
+    with open(os.path.join(GOLDEN, 'g00_api.json')) as f:
+        return json.load(f)
+
+
+# ---- C-ABI ----------------------------------------------------------------------------------
+def test_library_loads_and_exports_every_declared_symbol():
+    lib = _lib.lib()
+    header = open(os.path.join(ROOT, 'include', 'qk.h')).read()
+    declared = set(re.findall(r'\b(qk_[a-z_0-9]+)\s*\(', header))
+    declared -= {n for n in declared if n.endswith('_t')}
+    assert declared == set(_lib.SYMBOLS), (declared ^ set(_lib.SYMBOLS))
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.qk_version() == 100
+
+
+def test_descriptor_struct_matches_header_field_order():
+    header = open(os.path.join(ROOT, 'include', 'qk.h')).read()
+    body = header[header.index('typedef struct {'):header.index('} qk_conv_desc_t;')]
+    fields = re.findall(r'int32_t\s+([a-z_]+)', body)
+    assert fields == [f[0] for f in _lib.ConvDesc._fields_]
+    assert ctypes.sizeof(_lib.ConvDesc) == 4 * (2 + 6 + 2 + 12 + 5)
+    body = header[header.index('} qk_conv_desc_t;'):header.index('} qk_dense_desc_t;')]
+    fields = re.findall(r'int32_t\s+([a-z_]+)', body)
+    assert fields == [f[0] for f in _lib.DenseDesc._fields_]
+
+
+def test_invalid_descriptor_is_rejected_without_gpu():
+    lib = _lib.lib()
+    d = _lib.ConvDesc()          # all zeros: rank 0 is not a public conv rank
+    assert lib.qk_conv_fwd(ctypes.byref(d), None, None, None, None, None, 0, None) == -1
+    assert b'rank' in lib.qk_last_error()
+    call = functional.conv_call((2, 10, 8), (3, 2, 8), torch.float32, 1, padding='same')
+    assert lib.qk_conv_workspace_bytes(ctypes.byref(call.desc), _lib.QK_OP_FWD) == 0
+    assert lib.qk_conv_workspace_bytes(ctypes.byref(call.desc), _lib.QK_OP_BWD_DATA) == 3 * 2 * 8 * 4
+    assert lib.qk_conv_fwd(ctypes.byref(call.desc), None, None, None, None, None, 0, None) == -1
+    assert b'NULL' in lib.qk_last_error()
+
+
+def test_cpu_tensors_raise_instead_of_falling_back():
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        QuaternionConv1D(2, 3)(torch.randn(1, 5, 8))
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        QuaternionDense(8)(torch.randn(3, 8))
+
+
+def test_product_package_never_imports_the_oracle():
+    import glob
+    pkg = os.path.dirname(qcnn_amd.__file__)
+    for path in glob.glob(os.path.join(pkg, '**', '*.py'), recursive=True) + \
+            glob.glob(os.path.join(pkg, 'csrc', '*')):
+        if os.path.isdir(path):
+            continue
+        src = open(path, errors='ignore').read()
+        assert not re.search(r'^\s*(from|import)\s+oracle', src, re.M), path
+        assert 'qk_oracle' not in src, path
+
+
+# ---- shapes / names / config ------------------------------------------------------------------
+def test_conv_weight_names_shapes_match_reference(api):
+    c = QuaternionConv2D(4, (3, 5), padding='same', data_format='channels_first')
+    c.build((None, 12, 41, None))
+    assert [n for n, _ in c.weights] == api['conv2d_weight_names']
+    assert [list(p.shape) for _, p in c.weights] == api['conv2d_weight_shapes']
+    assert list(c.kernel_shape) == api['conv2d_kernel_shape_attr']
+    assert list(c.compute_output_shape((None, 12, 41, None))) == api['conv2d_output_shape']
+
+
+def test_conv1d_output_shapes_match_reference(api):
+    for rec in api['conv1d_output_shapes']:
+        layer = QuaternionConv1D(**rec['kwargs'])
+        assert list(layer.compute_output_shape(tuple(rec['input_shape']))) == rec['output_shape']
+
+
+def test_dense_surface_matches_reference(api):
+    np.random.seed(5)
+    d = QuaternionDense(12, activation='relu', seed=3)
+    d.build((None, 28))
+    cfg = d.get_config()
+    assert sorted(cfg.keys()) == api['dense_config_keys']
+    for k, v in api['dense_config_scalars'].items():
+        assert cfg[k] == v, k
+    assert [n for n, _ in d.weights] == api['dense_weight_names']
+    assert [list(p.shape) for _, p in d.weights] == api['dense_weight_shapes']
+    assert list(d.compute_output_shape((None, 28))) == api['dense_output_shape']
+    assert d.kernel is d.r and isinstance(cfg['kernel_initializer'], qdense_init)
+
+
+def test_exception_types_match_reference(api):
+    errs = api['errors']
+    with pytest.raises(ValueError):
+        QuaternionConv1D(3, 3).build((None, 10, None))
+    assert errs['conv_none_channel'] == 'ValueError'
+    with pytest.raises(KeyError):
+        QuaternionConv1D(3, 3, kernel_initializer='glorot_uniform').build((None, 10, 8))
+    assert errs['conv_bad_initializer'] in ('KeyError', 'ValueError')
+    with pytest.raises(AssertionError):
+        QuaternionDense(8).build((None, 3, 8))
+    assert errs['dense_rank3'] == 'AssertionError'
+    with pytest.raises(ValueError):
+        QuaternionDense(8, init_criterion='foo').build((None, 8))
+    assert errs['dense_bad_criterion'] == 'ValueError'
+    with pytest.raises(AssertionError):
+        qconv_init(kernel_size=(3,), input_dim=2, weight_dim=2, nb_filters=2)
+    assert errs['qconv_init_dim_mismatch'] == 'AssertionError'
+    with pytest.raises(TypeError):
+        QuaternionDense(8, not_a_keras_kwarg=1)
+
+
+def test_conv_get_config_keys_and_roundtrip(api):
+    # the reference raises NameError here (conv.py:809); the intended keys are implemented
+    assert api['conv2d_get_config_error'] == 'NameError'
+    c = QuaternionConv2D(4, (3, 5), strides=(1, 2), padding='same', data_format='channels_first',
+                         activation='relu', init_criterion='glorot')
+    cfg = c.get_config()
+    expect = {'name', 'trainable', 'filters', 'kernel_size', 'strides', 'padding', 'data_format',
+              'dilation_rate', 'activation', 'use_bias', 'normalize_weight', 'kernel_initializer',
+              'bias_initializer', 'gamma_diag_initializer', 'gamma_off_initializer', 'kernel_regularizer',
+              'bias_regularizer', 'gamma_diag_regularizer', 'gamma_off_regularizer', 'activity_regularizer',
+              'kernel_constraint', 'bias_constraint', 'gamma_diag_constraint', 'gamma_off_constraint',
+              'init_criterion', 'spectral_parametrization'}
+    assert set(cfg) == expect                       # 'rank' popped (conv.py:655-658)
+    assert cfg['kernel_initializer'] == 'quaternion' and cfg['gamma_diag_initializer'] == 'sqrt_init'
+    c2 = QuaternionConv2D.from_config(cfg)
+    assert c2.get_config() == cfg
+    c1 = QuaternionConv1D(2, 3)
+    assert 'data_format' not in c1.get_config() and 'rank' not in c1.get_config()   # conv.py:520-524
+    assert QuaternionConv(rank=1, filters=2, kernel_size=3).get_config()['rank'] == 1
+    assert QuaternionConvolution1D is QuaternionConv1D and QuaternionConvolution2D is QuaternionConv2D
+    assert QuaternionConvolution3D is QuaternionConv3D
+
+
+def test_normalize_weight_creates_unused_gammas():
+    c = QuaternionConv(rank=1, filters=3, kernel_size=3, normalize_weight=True)
+    c.build((None, 10, 8))
+    names = [n for n, _ in c.weights]
+    assert names[0] == 'kernel' and names[-1] == 'bias' and len(names) == 12
+    assert tuple(c.gamma_rr.shape) == (2 * 3,)
+    assert float(c.gamma_rr[0].detach()) == pytest.approx(1 / np.sqrt(2)) and float(c.gamma_ri[0].detach()) == 0.0
+    assert float(c.gamma_jk[0].detach()) == pytest.approx(1 / np.sqrt(2))     # conv.py:246 quirk
+
+
+def test_layer_names_follow_keras_snake_case():
+    assert re.match(r'quaternion_conv1d_\d+$', QuaternionConv1D(2, 3).name)
+    assert re.match(r'quaternion_dense_\d+$', QuaternionDense(8).name)
+    assert QuaternionDense(8, name='head').name == 'head'
+
+
+def test_regularizer_and_constraint_hooks():
+    from qcnn_amd.keras_like import regularizers
+    d = QuaternionDense(8, kernel_regularizer=regularizers.l2(0.5),
+                        kernel_constraint=lambda w: w.clamp(-0.01, 0.01))
+    d.build((None, 8))
+    (loss,) = d.regularization_losses()
+    assert float(loss) == pytest.approx(0.5 * float((d.r ** 2).sum()))
+    d.apply_constraints()
+    assert float(d.r.abs().max()) <= 0.01 + 1e-7
+    assert d.get_config()['kernel_regularizer']['class_name'] == 'L1L2'
+
+
+# ---- initialisers -----------------------------------------------------------------------------
+def test_initialisers_reproduce_reference_draws_bit_exactly():
+    z = np.load(os.path.join(GOLDEN, 'g12_init.npz'))
+    meta = json.loads(str(z['config']))
+    for m in meta:
+        kw = {k: (tuple(v) if isinstance(v, list) else v) for k, v in m['kwargs'].items()}
+        np.random.seed(m['np_seed'])
+        w = qconv_init(**kw)() if m['kind'] == 'qconv' else qdense_init(**kw)()
+        want = z[m['name']]
+        assert w.shape == want.shape and w.dtype == np.float64
+        assert np.array_equal(w, want), (m['name'], np.abs(w - want).max())
+
+
+def test_initialiser_statistics_and_seed_semantics():
+    np.random.seed(1)
+    a = qconv_init((3,), 32, 1, 64, 'he')()
+    np.random.seed(2)
+    b = qconv_init((3,), 32, 1, 64, 'he')()
+    s = 1 / np.sqrt(2 * 32 * 3)
+    r_a, r_b = a[..., :64], b[..., :64]
+    assert np.array_equal(r_a, r_b)              # modulus/phase come from RandomState(1337)
+    assert not np.array_equal(a[..., 64:], b[..., 64:])   # imaginary axis from the global RNG
+    assert r_a.std() == pytest.approx(s, rel=0.05)
+    # all-positive octant (init.py:70-78): the three imaginary parts share the sign of sin(phase)
+    assert (a[..., 64:128] * a[..., 128:192]).min() >= 0 and (a[..., 64:128] * a[..., 192:]).min() >= 0
+    assert np.all(sqrt_init()((5,)) == 1 / np.sqrt(2))
+
+
+# ---- host shape logic -------------------------------------------------------------------------
+def test_tf_padding_rules():
+    assert _shape.tf_pads(17, 4, 2, 1, 'same') == (1, 2)
+    assert _shape.tf_pads(41, 3, 1, 1, 'same') == (1, 1)
+    assert _shape.tf_pads(15, 3, 1, 2, 'causal') == (4, 0)
+    assert _shape.tf_pads(15, 3, 1, 2, 'valid') == (0, 0)
+    assert _shape.conv_output_length(None, 3, 'same', 1) is None
+    with pytest.raises(ValueError):
+        _shape.normalize_padding('full')
+    with pytest.raises(ValueError):
+        _shape.normalize_tuple((1, 2, 3), 2, 'strides')
+    assert _shape.normalize_data_format(None) == 'channels_last'
+
+
+def test_call_descriptor_geometry():
+    call = functional.conv_call((2, 4, 41, 13), (3, 5, 1, 32), torch.bfloat16, 2, padding='same',
+                                layout='channels_first', activation='relu')
+    d = call.desc
+    assert (d.rank, d.batch, d.cq, d.fq) == (2, 2, 1, 8)
+    assert list(d.in_spatial) == [41, 13, 1] and list(d.out_spatial) == [41, 13, 1]
+    assert list(d.pad_lo) == [1, 2, 0] and d.layout == _lib.QK_CH_FIRST and d.dtype == _lib.QK_BF16
+    assert call.y_shape == (2, 32, 41, 13) and call.relu
+    dc = functional.dense_call((5, 28), (7, 12), torch.float32, 'relu')
+    assert (dc.desc.rows, dc.desc.in_q, dc.desc.q_units) == (5, 7, 3)
+    with pytest.raises(ValueError):
+        functional.conv_call((2, 10, 6), (3, 2, 8), torch.float32, 1)       # 6 != 4*2 channels
+    with pytest.raises(ValueError):
+        functional.conv_call((2, 10, 8), (3, 2, 8), torch.float32, 1, activation='tanh')
+
+
+# ---- component getters (complexnn/utils.py) -----------------------------------------------------
+def test_component_getters_follow_reference_axis_rule():
+    x4 = torch.arange(2 * 8 * 3 * 5.).reshape(2, 8, 3, 5)
+    assert torch.equal(get_rpart_first(x4), x4[:, :2]) and torch.equal(get_kpart_first(x4), x4[:, 6:])
+    x3 = torch.arange(2 * 5 * 8.).reshape(2, 5, 8)          # 3-D tensors are sliced on the LAST axis
+    assert torch.equal(get_ipart_first(x3), x3[:, :, 2:4]) and torch.equal(get_jpart_first(x3), x3[:, :, 4:6])
+    x2 = torch.arange(3 * 8.).reshape(3, 8)
+    assert torch.equal(GetJFirst()(x2), x2[:, 4:6]) and torch.equal(GetIFirst()(x2), x2[:, 2:4])
+    assert torch.equal(GetRFirst()(x2), x2[:, :2]) and torch.equal(GetKFirst()(x2), x2[:, 6:])
+    assert getpart_quaternion_output_shape_first((None, 8, 3, 5)) == (None, 2, 3, 5)
+    assert getpart_quaternion_output_shape_first((None, 5, 8)) == (None, 5, 2)
+    assert GetRFirst().compute_output_shape((None, 8)) == (None, 2)
