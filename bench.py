@@ -67,7 +67,7 @@ class LayerTrainStep(object):
         self.m = torch.zeros_like(self.flat.param)
         self.v = torch.zeros_like(self.flat.param)
         self.call = F.conv_call(tuple(self.x.shape), tuple(kernel.shape), dt, len(ks), 1, 'same',
-                                'channels_last', 1, 'relu', True)
+                                'channels_last', 1, cfg.get('activation', 'relu'), True)
         self.call.static_buffers = True
         self.y = torch.empty(self.call.y_shape, dtype=dt, device=dev)
         self.dy = torch.randn(self.call.y_shape, device=dev, generator=gen).to(dt)
@@ -159,6 +159,7 @@ def main():
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
+    ap.add_argument('--activation', default='relu', choices=['relu', 'linear'], help='diagnostic: linear drops the relu mask')
     args = ap.parse_args()
 
     import qcnn_amd  # noqa: F401  (fails loudly if libqk_hip.so is missing)
@@ -172,7 +173,7 @@ def main():
     assert torch.cuda.is_available(), 'bench.py needs a GPU'
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
-    cfg = WORKLOADS[args.workload]
+    cfg = dict(WORKLOADS[args.workload], activation=args.activation)
     job = LayerTrainStep(cfg, dev, rank, world)
 
     def barrier():
@@ -203,7 +204,7 @@ def main():
         'config': {'workload': args.workload, 'per_gpu_batch': cfg['batch'],
                    'global_batch': cfg['batch'] * world, 'input': list(job.x.shape),
                    'filters': cfg['filters'], 'kernel_size': list(cfg['kernel']), 'padding': 'same',
-                   'activation': 'relu', 'gemm_view': job.gemm, 'parallelism': 'dp%d' % world,
+                   'activation': cfg['activation'], 'gemm_view': job.gemm, 'parallelism': 'dp%d' % world,
                    'optimizer': 'adam(5e-4)'},
     }
 

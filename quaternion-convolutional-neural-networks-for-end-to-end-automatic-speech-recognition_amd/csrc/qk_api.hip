@@ -89,8 +89,10 @@ int validate(const qk_conv_desc_t *d, bool allow_rank0)
         }
         si *= d->in_spatial[i]; so *= d->out_spatial[i]; taps *= d->kernel[i];
     }
-    if (si * d->batch > INT_MAX || so * d->batch > INT_MAX || taps * d->cq * 4LL * d->fq > INT_MAX) {
-        set_error("problem too large for 32-bit row indices"); return QK_ERR_UNSUPPORTED;
+    // kernels index rows and elements with 32-bit integers
+    if (si * d->batch * 4LL * d->cq > INT_MAX || so * d->batch * 4LL * d->fq > INT_MAX ||
+        taps * d->cq * 4LL * d->fq > INT_MAX) {
+        set_error("tensor with >= 2^31 elements: split the batch"); return QK_ERR_UNSUPPORTED;
     }
     if (d->layout != QK_CH_LAST && d->layout != QK_CH_FIRST) { set_error("bad layout %d", d->layout); return QK_ERR_INVALID_ARG; }
     if (d->dtype != QK_F32 && d->dtype != QK_BF16 && d->dtype != QK_F16) { set_error("bad dtype %d", d->dtype); return QK_ERR_INVALID_ARG; }

@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/qk.h"
 
@@ -47,6 +48,7 @@ struct GemmGeom {
     int relu;           // epilogue activation
     int has_bias;
     int has_mask;       // gathered value is zeroed where mask[same index] <= 0 (relu backward)
+    int ablate;         // profiling only (env QK_ABLATE): 4 = skip the MFMA loop, 8 = skip the epilogue
 };
 
 // Backward-weight geometry:  dW[t, c, p, f] = sum_{a^b=p} sgn(a,b) sum_m x_a[pos(m,t), c] * dy_b[m, f]
@@ -65,6 +67,7 @@ struct WgradGeom {
     int has_mask;
     int want_dbias;
     int m_per_split;    // rows of M each blockIdx.x reduces (multiple of the kernel's K step)
+    int ablate;         // profiling only (env QK_ABLATE): 1 = skip fold + atomics, 2 = skip HBM atomics
 };
 
 // ---------------------------------------------------------------------------------------
