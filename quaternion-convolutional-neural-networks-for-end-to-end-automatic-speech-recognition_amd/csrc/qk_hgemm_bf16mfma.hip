@@ -1,13 +1,305 @@
-// 16-bit-input MFMA Hamilton implicit GEMM (bf16 / fp16 fast path) -- placeholder until the
-// v_mfma_f32_32x32x16_{bf16,f16} kernels land; returning 0 routes the call to the fp32-MFMA path.
+// Hamilton implicit GEMM on the 16-bit-input matrix cores (v_mfma_f32_32x32x16_{bf16,f16}), gfx950.
+// Forward and backward-data of the quaternion convolution / dense layers for bfloat16 / float16
+// activations, fp32 accumulation.  (Backward-weight for 16-bit data still runs on the fp32-MFMA
+// kernel of qk_hgemm_f32mfma.inc; its reduction axis is the non-contiguous one and needs LDS
+// transpose reads.)
+//
+// Hamilton structure in REGISTERS: per 16-deep MFMA step a wave loads the 4 gathered-component
+// A fragments (r,i,j,k of the same rows/channels) and the 4 compact-part B fragments once, builds
+// the three negated parts with 12 v_xor (sign bit of both packed halves), and issues the 16 MFMAs
+// of the 4x4 block table:  acc[b] += A[a] * (+-B[a ^ b]).  Every fragment feeds 4 MFMAs; the
+// 4x-expanded weight (conv.py:327-331) exists nowhere -- HBM and LDS hold the compact kernel only.
+//
+// Workgroup = 8 waves (two per SIMD, so one wave's ds_read latency hides under the other's
+// MFMAs), WM x WN waves of 32 rows x (4 components x 32 channels).  K step = one tap x 32 gathered
+// channels x 4 components:
+//   A tile  BM rows x 256 B, row-major, 16-byte slots XOR-swizzled with (row & 15): staging writes
+//           (8 consecutive lanes = 8 slots of a row) and fragment reads (16 lanes = 16 rows, one
+//           slot) are both bank-conflict free;
+//   B tile  [k-slot 4][part 4][BF channels] x 16 B, exactly as the prep kernel lays the compact
+//           kernel out in the workspace, so staging is a linear copy and consecutive lanes read
+//           consecutive 16-byte slots.
+// Register prefetch of the next K step (issue-only, clamped addresses; zero fill and the relu mask
+// are applied at LDS-store time) as in the fp32 kernel.
 #include "qk_common.h"
 
 namespace qk {
+namespace {
 
-int try_hgemm_16(int, const void *, const void *, const float *, const float *, void *, const GemmGeom &,
-                 bool, void *, size_t, hipStream_t)
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ floatx16 mfma16(bf16, const uint4 &a, const uint4 &b, const floatx16 &c)
 {
-    return 0;
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ floatx16 mfma16(f16, const uint4 &a, const uint4 &b, const floatx16 &c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+__device__ __forceinline__ uint4 neg8(const uint4 &v)
+{
+    return make_uint4(v.x ^ 0x80008000u, v.y ^ 0x80008000u, v.z ^ 0x80008000u, v.w ^ 0x80008000u);
+}
+
+// zero the 16-bit lanes whose mask value is <= 0 (sign bit set, or +-0)
+__device__ __forceinline__ unsigned mask2(unsigned v, unsigned m)
+{
+    const unsigned lo = ((m & 0x8000u) || !(m & 0x7fffu)) ? 0u : 0xffffu;
+    const unsigned hi = ((m & 0x80000000u) || !(m & 0x7fff0000u)) ? 0u : 0xffff0000u;
+    return v & (lo | hi);
+}
+__device__ __forceinline__ uint4 mask8(const uint4 &v, const uint4 &m)
+{
+    return make_uint4(mask2(v.x, m.x), mask2(v.y, m.y), mask2(v.z, m.z), mask2(v.w, m.w));
+}
+
+struct RowPos16 { int n, o0, o1, o2; };
+
+__device__ __forceinline__ bool axis16(int o, int t, int pa, int pb, int pc, int pd, int isp, int &i)
+{
+    const int num = o * pa + t * pb + pc;
+    i = num;
+    bool ok = num >= 0;
+    if (pd != 1) {
+        i = num / pd;
+        ok = ok && (i * pd == num);
+    }
+    return ok && i < isp;
+}
+
+// ---------------------------------------------------------------------------------------
+// compact fp32 kernel -> 16-bit, laid out per (tap, 32-channel K chunk) as [slot][part][j][8]
+//   forward  (transposed == 0): K index = input channel c, j = filter f
+//   bwd-data (transposed == 1): K index = filter f,        j = input channel c
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_prep_w16(const float *__restrict__ w, T *__restrict__ wq, int taps, int Cq, int F, int transposed)
+{
+    const int Q = transposed ? F : Cq;
+    const int J = transposed ? Cq : F;
+    const long long total = (long long)taps * Q * 4 * J;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        long long r = idx;
+        const int e = r % 8; r /= 8;
+        const int j = r % J; r /= J;
+        const int p = r % 4; r /= 4;
+        const int slot = r % 4; r /= 4;
+        const int kc = r % (Q / 32);
+        const int t = r / (Q / 32);
+        const int k = kc * 32 + slot * 8 + e;
+        const int c = transposed ? j : k;
+        const int f = transposed ? k : j;
+        wq[idx] = from_f32<T>(w[((long long)(t * Cq + c) * 4 + p) * F + f]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+template <typename T, int WM, int WN, bool CONJ, bool MASK>
+__global__ void __launch_bounds__(512)
+k_hgemm16(const T *__restrict__ in, const T *__restrict__ mask, const uint4 *__restrict__ wq,
+          const float *__restrict__ bias, T *__restrict__ out, const GemmGeom g)
+{
+    static_assert(WM * WN == 8, "8 waves per workgroup");
+    constexpr int BM = WM * 32;
+    constexpr int BF = WN * 32;
+    constexpr int RPT = BM / 128;                   // rows of the A tile staged per thread
+    constexpr int BU = (16 * BF) / 512;             // 16-byte units of the B tile per thread
+    static_assert(BM % 128 == 0 && (16 * BF) % 512 == 0, "tile/threads");
+    constexpr unsigned TBL = CONJ ? kSignConj : kSignConv;
+    __shared__ __attribute__((aligned(16))) uint4 lds[BM * 16 + 16 * BF];
+    uint4 *As = lds;                                // [row][slot ^ (row & 15)]
+    uint4 *Bs = lds + BM * 16;                      // [slot][part][j]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int m0 = blockIdx.x * BM;
+    const int j0 = blockIdx.y * BF;
+    const int nkc = g.Q / 32;
+    const int iters = g.taps * nkc;
+
+    // ---- staging: thread -> (row, gathered component) ; 4 x 16 B = the component's 32 channels --
+    const int s_row = tid >> 2, s_cmp = tid & 3;
+    RowPos16 rp[RPT];
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+        int m = m0 + s_row + r * 128;
+        if (m >= g.M) { rp[r].n = -1; rp[r].o0 = rp[r].o1 = rp[r].o2 = 0; continue; }
+        rp[r].o2 = m % g.osp[2]; m /= g.osp[2];
+        rp[r].o1 = m % g.osp[1]; m /= g.osp[1];
+        rp[r].o0 = m % g.osp[0];
+        rp[r].n = m / g.osp[0];
+    }
+    uint4 ar[RPT][4], mr[MASK ? RPT : 1][4], br[BU];
+    unsigned a_ok = 0;
+
+    auto load_tile = [&](int it) {
+        const int t = it / nkc;
+        const int kc = it - t * nkc;
+        const int t2 = t % g.ks[2];
+        const int tt = t / g.ks[2];
+        const int t1 = tt % g.ks[1];
+        const int t0 = tt / g.ks[1];
+        a_ok = 0;
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            int i0, i1, i2;
+            const bool ok = rp[r].n >= 0 &
+                            axis16(rp[r].o0, t0, g.pa[0], g.pb[0], g.pc[0], g.pd[0], g.isp[0], i0) &
+                            axis16(rp[r].o1, t1, g.pa[1], g.pb[1], g.pc[1], g.pd[1], g.isp[1], i1) &
+                            axis16(rp[r].o2, t2, g.pa[2], g.pb[2], g.pc[2], g.pd[2], g.isp[2], i2);
+            const int off = ok ? rp[r].n * (int)g.in_sn + i0 * (int)g.in_ss[0] + i1 * (int)g.in_ss[1] +
+                                     i2 * (int)g.in_ss[2] + s_cmp * g.Q + kc * 32 : 0;
+            const uint4 *src = reinterpret_cast<const uint4 *>(in + off);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) ar[r][s] = src[s];
+            if constexpr (MASK) {
+                const uint4 *msrc = reinterpret_cast<const uint4 *>(mask + off);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) mr[r][s] = msrc[s];
+            }
+            a_ok |= (ok ? 1u : 0u) << r;
+        }
+        // B tile: 16 (slot, part) segments of BF 16-byte units each, J units apart in the workspace
+        const uint4 *wsrc = wq + (long long)(t * nkc + kc) * 16 * g.J;
+#pragma unroll
+        for (int i = 0; i < BU; ++i) {
+            const int u = tid + i * 512;
+            const int seg = u / BF, jj = u % BF;
+            br[i] = wsrc[seg * g.J + j0 + jj];
+        }
+    };
+
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            const int row = s_row + r * 128;
+            const bool ok = (a_ok >> r) & 1u;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                uint4 v = ok ? ar[r][s] : make_uint4(0u, 0u, 0u, 0u);
+                if constexpr (MASK) v = mask8(v, mr[r][s]);
+                As[row * 16 + ((s_cmp * 4 + s) ^ (row & 15))] = v;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BU; ++i) Bs[tid + i * 512] = br[i];
+    };
+
+    floatx16 acc[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+
+    const int frow = wm * 32 + lr;                  // A-tile row this lane reads
+    const uint4 *a_rd = As + frow * 16;
+    const int fsw = frow & 15;
+    const uint4 *b_rd = Bs + wn * 32 + lr;
+
+    load_tile(0);
+    store_tile();
+    __syncthreads();
+
+    for (int it = 0; it < iters; ++it) {
+        if (it + 1 < iters) load_tile(it + 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            uint4 A[4], B[4], Bn[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) A[a] = a_rd[(a * 4 + ks * 2 + lh) ^ fsw];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) B[p] = b_rd[((ks * 2 + lh) * 4 + p) * BF];
+#pragma unroll
+            for (int p = 1; p < 4; ++p) Bn[p] = neg8(B[p]);
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    constexpr unsigned tbl = TBL;
+                    const bool ng = (tbl >> (a * 4 + b)) & 1u;
+                    acc[b] = mfma16(T(), A[a], ng ? Bn[a ^ b] : B[a ^ b], acc[b]);
+                }
+        }
+        __syncthreads();
+        if (it + 1 < iters) {
+            store_tile();
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: bias + activation, 16-bit stores (32 consecutive channels per row) ------
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int ch = b * g.J + j0 + wn * 32 + lr;
+        const float bia = g.has_bias ? bias[ch] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * 32 + mfma32_row(r, lane);
+            if (m >= g.M) continue;
+            float v = acc[b][r] + bia;
+            if (g.relu) v = v > 0.f ? v : 0.f;
+            out[(long long)m * (int)g.out_ss + ch] = from_f32<T>(v);
+        }
+    }
+}
+
+template <typename T, int WM, int WN>
+int run16(const T *in, const T *mask, const uint4 *wq, const float *bias, T *out, const GemmGeom &g,
+          hipStream_t stream)
+{
+    constexpr int BM = WM * 32, BF = WN * 32;
+    dim3 grid((g.M + BM - 1) / BM, g.J / BF, 1);
+    const bool conj = g.sign_tbl == kSignConj;
+    const bool m = g.has_mask != 0;
+#define QK_GO(C, K) hipLaunchKernelGGL((k_hgemm16<T, WM, WN, C, K>), grid, dim3(512), 0, stream, in, mask, wq, bias, out, g)
+    if (conj) { if (m) QK_GO(true, true); else QK_GO(true, false); }
+    else      { if (m) QK_GO(false, true); else QK_GO(false, false); }
+#undef QK_GO
+    return hipGetLastError() == hipSuccess ? 1 : QK_ERR_LAUNCH;
+}
+
+template <typename T>
+int go16(const void *in, const void *mask, const float *w, const float *bias, void *out, const GemmGeom &g,
+         bool transposed, void *ws, hipStream_t stream)
+{
+    T *wq = static_cast<T *>(ws);
+    const int Cq = transposed ? g.J : g.Q, F = transposed ? g.Q : g.J;
+    const long long total = (long long)g.taps * Cq * 4 * F;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL((k_prep_w16<T>), dim3(blocks), dim3(256), 0, stream, w, wq, g.taps, Cq, F, transposed ? 1 : 0);
+    if (hipGetLastError() != hipSuccess) return QK_ERR_LAUNCH;
+    const uint4 *wq4 = reinterpret_cast<const uint4 *>(wq);
+    if (g.J % 64 == 0)
+        return run16<T, 4, 2>((const T *)in, (const T *)mask, wq4, bias, (T *)out, g, stream);
+    return run16<T, 8, 1>((const T *)in, (const T *)mask, wq4, bias, (T *)out, g, stream);
+}
+
+}  // namespace
+
+// Returns 1 when the 16-bit MFMA path took the call, 0 when the shape is outside its fast path
+// (the caller then runs the general fp32-MFMA kernel), < 0 on error.
+int try_hgemm_16(int dtype, const void *in, const void *mask, const float *w_f32, const float *bias,
+                 void *out, const GemmGeom &g, bool w_is_transposed, void *ws, size_t ws_bytes,
+                 hipStream_t stream)
+{
+    if (dtype != QK_BF16 && dtype != QK_F16) return 0;
+    if (g.in_sc != 1 || g.out_sc != 1) return 0;                       // channels_last buffers only
+    const long long S = (long long)g.osp[0] * g.osp[1] * g.osp[2];
+    if (g.out_sn != S * g.out_ss) return 0;
+    if (g.Q % 32 != 0 || g.J % 32 != 0) return 0;
+    const size_t need = (size_t)g.taps * g.Q * 4 * g.J * 2;
+    if (!ws || ws_bytes < need) return 0;
+    if ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(ws) | reinterpret_cast<uintptr_t>(mask)) & 15) return 0;
+    if (getenv("QK_NO_MFMA16")) return 0;                              // diagnostic switch
+    if (dtype == QK_BF16) return go16<bf16>(in, mask, w_f32, bias, out, g, w_is_transposed, ws, stream);
+    return go16<f16>(in, mask, w_f32, bias, out, g, w_is_transposed, ws, stream);
 }
 
 }  // namespace qk
