@@ -19,8 +19,9 @@
 //   B tile  [k-slot 4][part 4][BF channels] x 16 B, exactly as the prep kernel lays the compact
 //           kernel out in the workspace, so staging is a linear copy and consecutive lanes read
 //           consecutive 16-byte slots.
-// Register prefetch of the next K step (issue-only, clamped addresses; zero fill and the relu mask
-// are applied at LDS-store time) as in the fp32 kernel.
+// Two LDS buffers + a register stage give a 3-deep pipeline with ONE barrier per K step: while
+// buffer k feeds the MFMAs, tile k+1 moves registers -> LDS and tile k+2 is in flight from L2/HBM
+// (issue-only loads with clamped addresses; zero fill and the relu mask are applied at LDS-store time).
 #include "qk_common.h"
 
 namespace qk {
@@ -98,7 +99,7 @@ k_prep_w16(const float *__restrict__ w, T *__restrict__ wq, int taps, int Cq, in
 
 // ---------------------------------------------------------------------------------------
 template <typename T, int WM, int WN, bool CONJ, bool MASK>
-__global__ void __launch_bounds__(512)
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))   // 256-register budget
 k_hgemm16(const T *__restrict__ in, const T *__restrict__ mask, const uint4 *__restrict__ wq,
           const float *__restrict__ bias, T *__restrict__ out, const GemmGeom g)
 {
@@ -109,16 +110,23 @@ k_hgemm16(const T *__restrict__ in, const T *__restrict__ mask, const uint4 *__r
     constexpr int BU = (16 * BF) / 512;             // 16-byte units of the B tile per thread
     static_assert(BM % 128 == 0 && (16 * BF) % 512 == 0, "tile/threads");
     constexpr unsigned TBL = CONJ ? kSignConj : kSignConv;
-    __shared__ __attribute__((aligned(16))) uint4 lds[BM * 16 + 16 * BF];
-    uint4 *As = lds;                                // [row][slot ^ (row & 15)]
-    uint4 *Bs = lds + BM * 16;                      // [slot][part][j]
+    constexpr int TILE_U = BM * 16 + 16 * BF;       // 16-byte units of one (A, B) tile pair
+    __shared__ __attribute__((aligned(16))) uint4 lds[2 * TILE_U];   // double buffered
+    // A: [row][slot ^ (row & 15)] at lds + buf*TILE_U ; B: [slot][part][j] right behind it
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int lr = lane & 31, lh = lane >> 5;
-    const int m0 = blockIdx.x * BM;
+    // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch rule, used for speed
+    // only); give every XCD a CONTIGUOUS range of row tiles so the halo rows neighbouring tiles
+    // share (taps reach +-1 image row) are served by that XCD's own L2.
+    const int n_mt = (g.M + BM - 1) / BM;
+    const int per_xcd = (n_mt + 7) / 8;
+    const int mtile = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+    if (mtile >= n_mt) return;
+    const int m0 = mtile * BM;
     const int j0 = blockIdx.y * BF;
     const int nkc = g.Q / 32;
     const int iters = g.taps * nkc;
@@ -175,7 +183,9 @@ k_hgemm16(const T *__restrict__ in, const T *__restrict__ mask, const uint4 *__r
         }
     };
 
-    auto store_tile = [&]() {
+    auto store_tile = [&](int buf) {
+        uint4 *As = lds + buf * TILE_U;
+        uint4 *Bs = As + BM * 16;
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
             const int row = s_row + r * 128;
@@ -198,16 +208,24 @@ k_hgemm16(const T *__restrict__ in, const T *__restrict__ mask, const uint4 *__r
         for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
 
     const int frow = wm * 32 + lr;                  // A-tile row this lane reads
-    const uint4 *a_rd = As + frow * 16;
     const int fsw = frow & 15;
-    const uint4 *b_rd = Bs + wn * 32 + lr;
+    const int a_rd0 = frow * 16;
+    const int b_rd0 = BM * 16 + wn * 32 + lr;
 
+    // Pipeline (one barrier per K step): registers hold tile it+1 (loaded during step it-1);
+    //   step it:  write them to LDS buffer (it+1)&1  ->  issue the global loads of tile it+2  ->
+    //             MFMAs on buffer it&1  ->  barrier.
+    // Buffer (it+1)&1 was last read in step it-1, which every wave left through that step's barrier.
     load_tile(0);
-    store_tile();
+    store_tile(0);
+    if (iters > 1) load_tile(1);
     __syncthreads();
 
     for (int it = 0; it < iters; ++it) {
-        if (it + 1 < iters) load_tile(it + 1);
+        if (it + 1 < iters) store_tile((it + 1) & 1);
+        if (it + 2 < iters) load_tile(it + 2);
+        const uint4 *a_rd = lds + (it & 1) * TILE_U + a_rd0;
+        const uint4 *b_rd = lds + (it & 1) * TILE_U + b_rd0;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             uint4 A[4], B[4], Bn[4];
@@ -227,10 +245,6 @@ k_hgemm16(const T *__restrict__ in, const T *__restrict__ mask, const uint4 *__r
                 }
         }
         __syncthreads();
-        if (it + 1 < iters) {
-            store_tile();
-            __syncthreads();
-        }
     }
 
     // ---- epilogue: bias + activation, 16-bit stores (32 consecutive channels per row) ------
@@ -254,7 +268,8 @@ int run16(const T *in, const T *mask, const uint4 *wq, const float *bias, T *out
           hipStream_t stream)
 {
     constexpr int BM = WM * 32, BF = WN * 32;
-    dim3 grid((g.M + BM - 1) / BM, g.J / BF, 1);
+    const int n_mt = (g.M + BM - 1) / BM;
+    dim3 grid((n_mt + 7) / 8 * 8, g.J / BF, 1);       // padded to the 8 XCDs (see the tile remap)
     const bool conj = g.sign_tbl == kSignConj;
     const bool m = g.has_mask != 0;
 #define QK_GO(C, K) hipLaunchKernelGGL((k_hgemm16<T, WM, WN, C, K>), grid, dim3(512), 0, stream, in, mask, wq, bias, out, g)
