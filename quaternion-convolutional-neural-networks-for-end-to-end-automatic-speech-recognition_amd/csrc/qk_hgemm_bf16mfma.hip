@@ -56,20 +56,6 @@ __device__ __forceinline__ uint4 mask8(const uint4 &v, const uint4 &m)
     return make_uint4(mask2(v.x, m.x), mask2(v.y, m.y), mask2(v.z, m.z), mask2(v.w, m.w));
 }
 
-struct RowPos16 { int n, o0, o1, o2; };
-
-__device__ __forceinline__ bool axis16(int o, int t, int pa, int pb, int pc, int pd, int isp, int &i)
-{
-    const int num = o * pa + t * pb + pc;
-    i = num;
-    bool ok = num >= 0;
-    if (pd != 1) {
-        i = num / pd;
-        ok = ok && (i * pd == num);
-    }
-    return ok && i < isp;
-}
-
 // ---------------------------------------------------------------------------------------
 // compact fp32 kernel -> 16-bit, laid out per (tap, 32-channel K chunk) as [slot][part][j][8]
 //   forward  (transposed == 0): K index = input channel c, j = filter f
@@ -95,20 +81,20 @@ k_prep_w16(const float *__restrict__ w, T *__restrict__ wq, int taps, int Cq, in
         const int f = transposed ? k : j;
         wq[idx] = from_f32<T>(w[((long long)(t * Cq + c) * 4 + p) * F + f]);
     }
+    if (blockIdx.x == 0 && threadIdx.x < 128) wq[total + threadIdx.x] = from_f32<T>(0.f);   // zero line for padding rows
 }
 
 // ---------------------------------------------------------------------------------------
 template <typename T, int WM, int WN, bool CONJ, bool MASK>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))   // 256-register budget
 k_hgemm16(const T *__restrict__ in, const T *__restrict__ mask, const uint4 *__restrict__ wq,
-          const float *__restrict__ bias, T *__restrict__ out, const GemmGeom g)
+          const T *__restrict__ zero_line, const float *__restrict__ bias, T *__restrict__ out, const GemmGeom g)
 {
     static_assert(WM * WN == 8, "8 waves per workgroup");
     constexpr int BM = WM * 32;
     constexpr int BF = WN * 32;
-    constexpr int RPT = BM / 128;                   // rows of the A tile staged per thread
     constexpr int BU = (16 * BF) / 512;             // 16-byte units of the B tile per thread
-    static_assert(BM % 128 == 0 && (16 * BF) % 512 == 0, "tile/threads");
+    static_assert(BM % 64 == 0 && (16 * BF) % 512 == 0, "tile/threads");
     constexpr unsigned TBL = CONJ ? kSignConj : kSignConv;
     constexpr int TILE_U = BM * 16 + 16 * BF;       // 16-byte units of one (A, B) tile pair
     __shared__ __attribute__((aligned(16))) uint4 lds[2 * TILE_U];   // double buffered
@@ -131,55 +117,72 @@ k_hgemm16(const T *__restrict__ in, const T *__restrict__ mask, const uint4 *__r
     const int nkc = g.Q / 32;
     const int iters = g.taps * nkc;
 
-    // ---- staging: thread -> (row, gathered component) ; 4 x 16 B = the component's 32 channels --
-    const int s_row = tid >> 2, s_cmp = tid & 3;
-    RowPos16 rp[RPT];
+    // ---- staging ---------------------------------------------------------------------------
+    // 8 threads per row, each moving 2 of the row's 16 slots (slot = s8 and s8 + 8): the 8 lanes a
+    // ds_write_b128 is serviced in then hit 8 different 16-byte slots of one 128-byte bank window.
+    // Address generation is hoisted out of the K loop: per row one base offset (tap 0 position,
+    // possibly outside the tensor) and a bit mask of the taps that fall inside it; per K step the
+    // wave-uniform tap displacement is added.  Padding rows read a zeroed 64-byte line instead of
+    // being patched afterwards.
+    constexpr int RPT2 = BM / 64;                   // rows per thread (passes of 64 rows)
+    const int s_row = tid >> 3, s8 = tid & 7;
+    int base_off[RPT2];
+    unsigned tapmask[RPT2];
 #pragma unroll
-    for (int r = 0; r < RPT; ++r) {
-        int m = m0 + s_row + r * 128;
-        if (m >= g.M) { rp[r].n = -1; rp[r].o0 = rp[r].o1 = rp[r].o2 = 0; continue; }
-        rp[r].o2 = m % g.osp[2]; m /= g.osp[2];
-        rp[r].o1 = m % g.osp[1]; m /= g.osp[1];
-        rp[r].o0 = m % g.osp[0];
-        rp[r].n = m / g.osp[0];
+    for (int r = 0; r < RPT2; ++r) {
+        int m = m0 + s_row + r * 64;
+        base_off[r] = 0; tapmask[r] = 0;
+        if (m < g.M) {
+            const int o2 = m % g.osp[2]; m /= g.osp[2];
+            const int o1 = m % g.osp[1]; m /= g.osp[1];
+            const int o0 = m % g.osp[0];
+            const int n = m / g.osp[0];
+            const int p0 = o0 * g.pa[0] + g.pc[0], p1 = o1 * g.pa[1] + g.pc[1], p2 = o2 * g.pa[2] + g.pc[2];
+            base_off[r] = n * (int)g.in_sn + p0 * (int)g.in_ss[0] + p1 * (int)g.in_ss[1] + p2 * (int)g.in_ss[2];
+            int t = 0;
+            for (int t0 = 0; t0 < g.ks[0]; ++t0)
+                for (int t1 = 0; t1 < g.ks[1]; ++t1)
+                    for (int t2 = 0; t2 < g.ks[2]; ++t2, ++t) {
+                        const int i0 = p0 + t0 * g.pb[0], i1 = p1 + t1 * g.pb[1], i2 = p2 + t2 * g.pb[2];
+                        const bool ok = i0 >= 0 && i0 < g.isp[0] && i1 >= 0 && i1 < g.isp[1] && i2 >= 0 && i2 < g.isp[2];
+                        tapmask[r] |= (ok ? 1u : 0u) << t;
+                    }
+        }
     }
-    uint4 ar[RPT][4], mr[MASK ? RPT : 1][4], br[BU];
-    unsigned a_ok = 0;
+    // slot s8 / s8+8 -> (component, 8-channel group) -> element offset inside the row
+    const int cmp_lo = s8 >> 2, cmp_hi = cmp_lo + 2, sub = (s8 & 3) * 8;
+    uint4 ar[RPT2][2], mr[MASK ? RPT2 : 1][2], br[BU];
+    int lt0 = 0, lt1 = 0, lt2 = 0, lkc = 0, ltap = 0;      // (tap, K chunk) of the NEXT load_tile call
 
-    auto load_tile = [&](int it) {
-        const int t = it / nkc;
-        const int kc = it - t * nkc;
-        const int t2 = t % g.ks[2];
-        const int tt = t / g.ks[2];
-        const int t1 = tt % g.ks[1];
-        const int t0 = tt / g.ks[1];
-        a_ok = 0;
+    auto load_tile = [&]() {
+        const int delta = lt0 * g.pb[0] * (int)g.in_ss[0] + lt1 * g.pb[1] * (int)g.in_ss[1] +
+                          lt2 * g.pb[2] * (int)g.in_ss[2] + lkc * 32 + sub;
 #pragma unroll
-        for (int r = 0; r < RPT; ++r) {
-            int i0, i1, i2;
-            const bool ok = rp[r].n >= 0 &
-                            axis16(rp[r].o0, t0, g.pa[0], g.pb[0], g.pc[0], g.pd[0], g.isp[0], i0) &
-                            axis16(rp[r].o1, t1, g.pa[1], g.pb[1], g.pc[1], g.pd[1], g.isp[1], i1) &
-                            axis16(rp[r].o2, t2, g.pa[2], g.pb[2], g.pc[2], g.pd[2], g.isp[2], i2);
-            const int off = ok ? rp[r].n * (int)g.in_sn + i0 * (int)g.in_ss[0] + i1 * (int)g.in_ss[1] +
-                                     i2 * (int)g.in_ss[2] + s_cmp * g.Q + kc * 32 : 0;
-            const uint4 *src = reinterpret_cast<const uint4 *>(in + off);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) ar[r][s] = src[s];
+        for (int r = 0; r < RPT2; ++r) {
+            const bool ok = (tapmask[r] >> ltap) & 1u;
+            const int off = base_off[r] + delta;
+            const T *lo = ok ? in + off + cmp_lo * g.Q : zero_line;
+            const T *hi = ok ? in + off + cmp_hi * g.Q : zero_line;
+            ar[r][0] = *reinterpret_cast<const uint4 *>(lo);
+            ar[r][1] = *reinterpret_cast<const uint4 *>(hi);
             if constexpr (MASK) {
-                const uint4 *msrc = reinterpret_cast<const uint4 *>(mask + off);
-#pragma unroll
-                for (int s = 0; s < 4; ++s) mr[r][s] = msrc[s];
+                const T *mlo = ok ? mask + off + cmp_lo * g.Q : zero_line;
+                const T *mhi = ok ? mask + off + cmp_hi * g.Q : zero_line;
+                mr[r][0] = *reinterpret_cast<const uint4 *>(mlo);
+                mr[r][1] = *reinterpret_cast<const uint4 *>(mhi);
             }
-            a_ok |= (ok ? 1u : 0u) << r;
         }
         // B tile: 16 (slot, part) segments of BF 16-byte units each, J units apart in the workspace
-        const uint4 *wsrc = wq + (long long)(t * nkc + kc) * 16 * g.J;
+        const uint4 *wsrc = wq + (long long)(ltap * nkc + lkc) * 16 * g.J;
 #pragma unroll
         for (int i = 0; i < BU; ++i) {
             const int u = tid + i * 512;
             const int seg = u / BF, jj = u % BF;
             br[i] = wsrc[seg * g.J + j0 + jj];
+        }
+        if (++lkc == nkc) {
+            lkc = 0; ++ltap;
+            if (++lt2 == g.ks[2]) { lt2 = 0; if (++lt1 == g.ks[1]) { lt1 = 0; ++lt0; } }
         }
     };
 
@@ -187,15 +190,12 @@ k_hgemm16(const T *__restrict__ in, const T *__restrict__ mask, const uint4 *__r
         uint4 *As = lds + buf * TILE_U;
         uint4 *Bs = As + BM * 16;
 #pragma unroll
-        for (int r = 0; r < RPT; ++r) {
-            const int row = s_row + r * 128;
-            const bool ok = (a_ok >> r) & 1u;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                uint4 v = ok ? ar[r][s] : make_uint4(0u, 0u, 0u, 0u);
-                if constexpr (MASK) v = mask8(v, mr[r][s]);
-                As[row * 16 + ((s_cmp * 4 + s) ^ (row & 15))] = v;
-            }
+        for (int r = 0; r < RPT2; ++r) {
+            const int row = s_row + r * 64;
+            uint4 v0 = ar[r][0], v1 = ar[r][1];
+            if constexpr (MASK) { v0 = mask8(v0, mr[r][0]); v1 = mask8(v1, mr[r][1]); }
+            As[row * 16 + (s8 ^ (row & 15))] = v0;
+            As[row * 16 + ((s8 + 8) ^ (row & 15))] = v1;
         }
 #pragma unroll
         for (int i = 0; i < BU; ++i) Bs[tid + i * 512] = br[i];
@@ -216,14 +216,14 @@ k_hgemm16(const T *__restrict__ in, const T *__restrict__ mask, const uint4 *__r
     //   step it:  write them to LDS buffer (it+1)&1  ->  issue the global loads of tile it+2  ->
     //             MFMAs on buffer it&1  ->  barrier.
     // Buffer (it+1)&1 was last read in step it-1, which every wave left through that step's barrier.
-    load_tile(0);
+    load_tile();
     store_tile(0);
-    if (iters > 1) load_tile(1);
+    if (iters > 1) load_tile();
     __syncthreads();
 
     for (int it = 0; it < iters; ++it) {
         if (it + 1 < iters) store_tile((it + 1) & 1);
-        if (it + 2 < iters) load_tile(it + 2);
+        if (it + 2 < iters) load_tile();
         const uint4 *a_rd = lds + (it & 1) * TILE_U + a_rd0;
         const uint4 *b_rd = lds + (it & 1) * TILE_U + b_rd0;
 #pragma unroll
@@ -264,15 +264,15 @@ k_hgemm16(const T *__restrict__ in, const T *__restrict__ mask, const uint4 *__r
 }
 
 template <typename T, int WM, int WN>
-int run16(const T *in, const T *mask, const uint4 *wq, const float *bias, T *out, const GemmGeom &g,
-          hipStream_t stream)
+int run16(const T *in, const T *mask, const uint4 *wq, const T *zero_line, const float *bias, T *out,
+          const GemmGeom &g, hipStream_t stream)
 {
     constexpr int BM = WM * 32, BF = WN * 32;
     const int n_mt = (g.M + BM - 1) / BM;
     dim3 grid((n_mt + 7) / 8 * 8, g.J / BF, 1);       // padded to the 8 XCDs (see the tile remap)
     const bool conj = g.sign_tbl == kSignConj;
     const bool m = g.has_mask != 0;
-#define QK_GO(C, K) hipLaunchKernelGGL((k_hgemm16<T, WM, WN, C, K>), grid, dim3(512), 0, stream, in, mask, wq, bias, out, g)
+#define QK_GO(C, K) hipLaunchKernelGGL((k_hgemm16<T, WM, WN, C, K>), grid, dim3(512), 0, stream, in, mask, wq, zero_line, bias, out, g)
     if (conj) { if (m) QK_GO(true, true); else QK_GO(true, false); }
     else      { if (m) QK_GO(false, true); else QK_GO(false, false); }
 #undef QK_GO
@@ -291,9 +291,10 @@ int go16(const void *in, const void *mask, const float *w, const float *bias, vo
     hipLaunchKernelGGL((k_prep_w16<T>), dim3(blocks), dim3(256), 0, stream, w, wq, g.taps, Cq, F, transposed ? 1 : 0);
     if (hipGetLastError() != hipSuccess) return QK_ERR_LAUNCH;
     const uint4 *wq4 = reinterpret_cast<const uint4 *>(wq);
+    const T *zero_line = wq + total;                 // 256 zeroed bytes behind the re-laid-out kernel
     if (g.J % 64 == 0)
-        return run16<T, 4, 2>((const T *)in, (const T *)mask, wq4, bias, (T *)out, g, stream);
-    return run16<T, 8, 1>((const T *)in, (const T *)mask, wq4, bias, (T *)out, g, stream);
+        return run16<T, 4, 2>((const T *)in, (const T *)mask, wq4, zero_line, bias, (T *)out, g, stream);
+    return run16<T, 8, 1>((const T *)in, (const T *)mask, wq4, zero_line, bias, (T *)out, g, stream);
 }
 
 }  // namespace
@@ -309,7 +310,8 @@ int try_hgemm_16(int dtype, const void *in, const void *mask, const float *w_f32
     const long long S = (long long)g.osp[0] * g.osp[1] * g.osp[2];
     if (g.out_sn != S * g.out_ss) return 0;
     if (g.Q % 32 != 0 || g.J % 32 != 0) return 0;
-    const size_t need = (size_t)g.taps * g.Q * 4 * g.J * 2;
+    if (g.taps > 32 || g.pd[0] != 1 || g.pd[1] != 1 || g.pd[2] != 1) return 0;   // tap bit mask; unit-stride map
+    const size_t need = (size_t)g.taps * g.Q * 4 * g.J * 2 + 256;
     if (!ws || ws_bytes < need) return 0;
     if ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(ws) | reinterpret_cast<uintptr_t>(mask)) & 15) return 0;
     if (getenv("QK_NO_MFMA16")) return 0;                              // diagnostic switch
