@@ -151,7 +151,9 @@ k_hgemm16(const T *__restrict__ in, const T *__restrict__ mask, const uint4 *__r
     }
     // slot s8 / s8+8 -> (component, 8-channel group) -> element offset inside the row
     const int cmp_lo = s8 >> 2, cmp_hi = cmp_lo + 2, sub = (s8 & 3) * 8;
-    uint4 ar[RPT2][2], mr[MASK ? RPT2 : 1][2], br[BU];
+    static_assert(BU == 1 || BU == 2, "B prefetch registers are named, not an array: hipcc parks a\n"
+                  "by-reference-captured array in LDS (promote-alloca) and waits for the load right away");
+    uint4 ar[RPT2][2], mr[MASK ? RPT2 : 1][2], br0, br1;
     int lt0 = 0, lt1 = 0, lt2 = 0, lkc = 0, ltap = 0;      // (tap, K chunk) of the NEXT load_tile call
 
     auto load_tile = [&]() {
@@ -174,12 +176,8 @@ k_hgemm16(const T *__restrict__ in, const T *__restrict__ mask, const uint4 *__r
         }
         // B tile: 16 (slot, part) segments of BF 16-byte units each, J units apart in the workspace
         const uint4 *wsrc = wq + (long long)(ltap * nkc + lkc) * 16 * g.J;
-#pragma unroll
-        for (int i = 0; i < BU; ++i) {
-            const int u = tid + i * 512;
-            const int seg = u / BF, jj = u % BF;
-            br[i] = wsrc[seg * g.J + j0 + jj];
-        }
+        br0 = wsrc[(tid / BF) * g.J + j0 + tid % BF];
+        if constexpr (BU == 2) br1 = wsrc[((tid + 512) / BF) * g.J + j0 + (tid + 512) % BF];
         if (++lkc == nkc) {
             lkc = 0; ++ltap;
             if (++lt2 == g.ks[2]) { lt2 = 0; if (++lt1 == g.ks[1]) { lt1 = 0; ++lt0; } }
@@ -197,8 +195,8 @@ k_hgemm16(const T *__restrict__ in, const T *__restrict__ mask, const uint4 *__r
             As[row * 16 + (s8 ^ (row & 15))] = v0;
             As[row * 16 + ((s8 + 8) ^ (row & 15))] = v1;
         }
-#pragma unroll
-        for (int i = 0; i < BU; ++i) Bs[tid + i * 512] = br[i];
+        Bs[tid] = br0;
+        if constexpr (BU == 2) Bs[tid + 512] = br1;
     };
 
     floatx16 acc[4];
