@@ -34,6 +34,10 @@ int try_hgemm_16(int dtype, const void *in, const void *mask, const float *w_f32
                  void *out, const GemmGeom &g, bool w_is_transposed, void *ws, size_t ws_bytes,
                  hipStream_t stream);
 
+// 16-bit-input MFMA backward-weight (qk_wgrad_bf16mfma.hip); returns 1 when it took the call
+int try_wgrad_16(int dtype, const void *x, const void *dy, const void *ymask, float *dw, float *dbias,
+                 const WgradGeom &g, hipStream_t stream);
+
 int launch_hgemm(int dtype, const void *in, const void *mask, const float *wk, const float *bias,
                  void *out, const GemmGeom &g, bool vec_ok, hipStream_t stream)
 {
@@ -232,6 +236,10 @@ int conv_bwd_weight_impl(const qk_conv_desc_t *d, const void *x, const void *dy,
     if (hipMemsetAsync(dw, 0, w_floats(d) * sizeof(float), stream) != hipSuccess) { set_error("memset dw failed"); return QK_ERR_LAUNCH; }
     if (g.want_dbias && hipMemsetAsync(dbias, 0, 4 * (size_t)d->fq * sizeof(float), stream) != hipSuccess) {
         set_error("memset dbias failed"); return QK_ERR_LAUNCH;
+    }
+    if (d->dtype != QK_F32) {
+        const int r = try_wgrad_16(d->dtype, x, dy, mask ? y : nullptr, dw, dbias, g, stream);
+        if (r != 0) return r < 0 ? r : 0;
     }
     const bool vec = d->layout == QK_CH_LAST && d->cq % 4 == 0 && d->fq % 4 == 0 &&
                      vec_aligned(x, d->dtype) && vec_aligned(dy, d->dtype) && (!mask || vec_aligned(y, d->dtype));

@@ -1,0 +1,295 @@
+// Backward-weight (+ bias gradient) on the 16-bit-input matrix cores, gfx950.
+//
+//   dW[t, c, p, f] = sum_{a^b=p} sgn(a,b) * sum_m x_a[pos(m,t), c] * dy_b[m, f]
+//
+// The reduction runs over rows m, which is the NON-contiguous axis of both operands
+// (activations are [row][channel]).  v_mfma_f32_32x32x16 wants 8 consecutive reduction elements
+// per lane, so the X / dY tiles stay in LDS exactly as they lie in HBM and the fragments are
+// formed with the gfx950 LDS transpose read ds_read_b64_tr_b16: inside a 16-lane group, lane i
+// receives element (i & 3) of the 8-byte words addressed by lanes 4j + (i >> 2), j = 0..3
+// (measured, tools/tr_probe.hip).  Addressing lane L at (row m0 + L/4, channels c0 + 4*(L%4)..+3)
+// therefore hands lane i channel c0 + i for rows m0..m0+3: two reads give the 8-deep fragment.
+//
+// Block = (tap, BC input channels x BF filters, split of M); it accumulates the EXPANDED gradient
+// tile (4*BC rows x 4*BF columns) in MFMA accumulators -- wave tile 64 x TN*32 -- and folds the 16
+// (a,b) blocks onto the 4 compact parts through LDS in four race-free phases before one atomic
+// pass to HBM, as the fp32 kernel does (qk_hgemm_f32mfma.inc).  K step = 64 rows of M, two LDS
+// buffers + a register stage, one barrier per step.  Row pitches carry 64 bytes of padding so the
+// four rows a transpose read touches per 32-lane half fall on different bank quarters.
+#include "qk_common.h"
+
+namespace qk {
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef short v4s __attribute__((ext_vector_type(4)));
+typedef short v8s __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ floatx16 mfma16w(bf16, const v8s &a, const v8s &b, const floatx16 &c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ floatx16 mfma16w(f16, const v8s &a, const v8s &b, const floatx16 &c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+typedef __attribute__((address_space(3))) v4s lds_v4s;
+
+// 8-deep fragment for this lane's channel: rows [m, m+4) and [m+4, m+8) of the tile at `base`
+__device__ __forceinline__ v8s tr_frag(const char *base, int pitch)
+{
+    const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s *)(base));
+    const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s *)(base + 4 * pitch));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// component-wise select: `ok ? v : zero` on whole uint4s makes hipcc select between two ADDRESSES
+// and park both operands in scratch
+__device__ __forceinline__ uint4 keep_if(bool ok, const uint4 &v)
+{
+    return make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u);
+}
+
+__device__ __forceinline__ unsigned relu_keep2(unsigned v, unsigned m)
+{
+    const unsigned lo = ((m & 0x8000u) || !(m & 0x7fffu)) ? 0u : 0xffffu;
+    const unsigned hi = ((m & 0x80000000u) || !(m & 0x7fff0000u)) ? 0u : 0xffff0000u;
+    return v & (lo | hi);
+}
+
+template <typename T, int WR, int WC, int TN, bool MASK>
+__global__ void __launch_bounds__(WR * WC * 64) __attribute__((amdgpu_waves_per_eu(WR * WC / 4, WR * WC / 4)))
+k_wgrad16(const T *__restrict__ x, const T *__restrict__ dy, const T *__restrict__ ymask,
+          float *__restrict__ dw, float *__restrict__ dbias, const WgradGeom g)
+{
+    constexpr int NW = WR * WC, NTHR = NW * 64;
+    constexpr int BC = WR * 16;                 // quaternion input channels per block (rows = 4*BC)
+    constexpr int BF = WC * TN * 8;             // quaternion filters per block      (cols = 4*BF)
+    constexpr int KM = 64;                      // rows of M per K step
+    constexpr int XROW = 4 * BC * 2 + 64;       // bytes per tile row (64 B pad: see header)
+    constexpr int DROW = 4 * BF * 2 + 64;
+    constexpr int BUF = KM * (XROW + DROW);
+    constexpr int FOLD = BC * 4 * BF * 4;
+    static_assert(2 * BUF >= FOLD, "fold slab reuses the tile buffers");
+    __shared__ __attribute__((aligned(16))) char lds[2 * BUF];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / WC, wc = wave % WC;
+    const int nfc = g.F / BF;
+    const int cchunk = blockIdx.y / nfc;
+    const int fchunk = blockIdx.y - cchunk * nfc;
+    const int c0 = cchunk * BC, f0 = fchunk * BF;
+    const int t = blockIdx.z;
+    const int t2 = t % g.ks[2];
+    const int tt = t / g.ks[2];
+    const int t1 = tt % g.ks[1];
+    const int t0 = tt / g.ks[1];
+    const int m_begin = blockIdx.x * g.m_per_split;
+    const int m_end = min(g.M, m_begin + g.m_per_split);
+    const bool do_bias = g.want_dbias && t == 0 && cchunk == 0;
+
+    // ---- staging: NTHR/64 threads per row, 16-byte units ------------------------------------
+    constexpr int TPROW = NTHR / KM;
+    constexpr int UXR = BC / 2, UDR = BF / 2;                // 16-byte units per X / dY row
+    constexpr int UX = (UXR + TPROW - 1) / TPROW, UD = (UDR + TPROW - 1) / TPROW;
+    static_assert(UXR % TPROW == 0 && UDR % TPROW == 0, "units per thread");
+    const int s_row = tid / TPROW, s_sub = tid % TPROW;
+    uint4 xr[UX], dr[UD], mr[MASK ? UD : 1];
+    bool x_ok = false, d_ok = false;
+
+    auto load_tile = [&](int mb) {
+        const int m = mb + s_row;
+        d_ok = m < m_end;
+        x_ok = false;
+        int xo = 0;
+        if (d_ok) {
+            int s = m;
+            const int o2 = s % g.osp[2]; s /= g.osp[2];
+            const int o1 = s % g.osp[1]; s /= g.osp[1];
+            const int o0 = s % g.osp[0];
+            const int n = s / g.osp[0];
+            const int i0 = o0 * g.pa[0] + t0 * g.pb[0] + g.pc[0];
+            const int i1 = o1 * g.pa[1] + t1 * g.pb[1] + g.pc[1];
+            const int i2 = o2 * g.pa[2] + t2 * g.pb[2] + g.pc[2];
+            x_ok = i0 >= 0 && i0 < g.isp[0] && i1 >= 0 && i1 < g.isp[1] && i2 >= 0 && i2 < g.isp[2];
+            if (x_ok) xo = n * (int)g.x_sn + i0 * (int)g.x_ss[0] + i1 * (int)g.x_ss[1] + i2 * (int)g.x_ss[2];
+        }
+        const int yo = d_ok ? m * (int)g.dy_ss : 0;
+#pragma unroll
+        for (int i = 0; i < UX; ++i) {
+            const int u = s_sub + i * TPROW;
+            const int a = u / (BC / 8), c8 = u % (BC / 8);
+            xr[i] = *reinterpret_cast<const uint4 *>(x + xo + a * g.Cq + c0 + c8 * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < UD; ++i) {
+            const int u = s_sub + i * TPROW;
+            const int b = u / (BF / 8), f8 = u % (BF / 8);
+            const int e = yo + b * g.F + f0 + f8 * 8;
+            dr[i] = *reinterpret_cast<const uint4 *>(dy + e);
+            if constexpr (MASK) mr[i] = *reinterpret_cast<const uint4 *>(ymask + e);
+        }
+    };
+
+    auto store_tile = [&](int buf) {
+        char *xs = lds + buf * BUF + s_row * XROW;
+        char *ds = lds + buf * BUF + KM * XROW + s_row * DROW;
+#pragma unroll
+        for (int i = 0; i < UX; ++i)
+            *reinterpret_cast<uint4 *>(xs + (s_sub + i * TPROW) * 16) = keep_if(x_ok, xr[i]);
+#pragma unroll
+        for (int i = 0; i < UD; ++i) {
+            uint4 v = keep_if(d_ok, dr[i]);
+            if constexpr (MASK)
+                v = make_uint4(relu_keep2(v.x, mr[i].x), relu_keep2(v.y, mr[i].y), relu_keep2(v.z, mr[i].z),
+                               relu_keep2(v.w, mr[i].w));
+            *reinterpret_cast<uint4 *>(ds + (s_sub + i * TPROW) * 16) = v;
+        }
+    };
+
+    floatx16 acc[2][TN];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < TN; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[rt][ct][r] = 0.f;
+    float dbacc = 0.f;
+
+    // transpose-read addressing of this lane (see header): 16-lane group g16 covers channels
+    // 16*g16 .. +15 of the 32-channel tile, half kh the second 8 rows of the 16-deep step
+    const int Lg = lane & 15, g16 = (lane >> 4) & 1, kh = lane >> 5;
+    const int fr_row = 8 * kh + (Lg >> 2);
+    const int fr_ch = 16 * g16 + 4 * (Lg & 3);
+    const int a_off = fr_row * XROW + ((wr * 2) * 32 + fr_ch) * 2;                 // + rt*64 bytes
+    const int b_off = KM * XROW + fr_row * DROW + ((wc * TN) * 32 + fr_ch) * 2;      // + ct*64 bytes
+
+    const int iters = (m_end - m_begin + KM - 1) / KM;
+    if (iters > 0) {
+        load_tile(m_begin);
+        store_tile(0);
+        if (iters > 1) load_tile(m_begin + KM);
+        __syncthreads();
+        for (int it = 0; it < iters; ++it) {
+            if (it + 1 < iters) store_tile((it + 1) & 1);
+            if (it + 2 < iters) load_tile(m_begin + (it + 2) * KM);
+            const char *tb = lds + (it & 1) * BUF;
+            if (do_bias && tid < 4 * BF) {
+                const T *col = reinterpret_cast<const T *>(tb + KM * XROW) + tid;
+#pragma unroll 8
+                for (int mm = 0; mm < KM; ++mm) dbacc += to_f32(col[mm * (DROW / 2)]);
+            }
+#pragma unroll
+            for (int ks = 0; ks < KM / 16; ++ks) {
+                v8s A[2], B[TN];
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) A[rt] = tr_frag(tb + a_off + ks * 16 * XROW + rt * 64, XROW);
+#pragma unroll
+                for (int ct = 0; ct < TN; ++ct) B[ct] = tr_frag(tb + b_off + ks * 16 * DROW + ct * 64, DROW);
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int ct = 0; ct < TN; ++ct) acc[rt][ct] = mfma16w(T(), A[rt], B[ct], acc[rt][ct]);
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- fold the 16 expanded blocks onto the 4 compact parts, then one atomic pass ----------
+    // Phase ph deposits the rows of gathered component a = ph onto part p = ph ^ b.  Waves that hold
+    // the same a differ in their output components b (disjoint p), or in their channels cc, so the
+    // plain LDS read-modify-write is race free; phase 0 (p = b) initialises every slab entry.
+    float *slab = reinterpret_cast<float *>(lds);
+    const int lr = lane & 31;
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph) {
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            const int rowbase = (wr * 2 + rt) * 32;
+            if (rowbase / BC != ph) continue;                         // wave-uniform: BC is 32 or 64
+#pragma unroll
+            for (int ct = 0; ct < TN; ++ct) {
+                const int col = (wc * TN + ct) * 32 + lr;
+                const int b = col / BF, ff = col % BF;
+                const int p = ph ^ b;
+                const bool neg = (g.sign_tbl >> (ph * 4 + b)) & 1u;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int cc = (rowbase + mfma32_row(r, lane)) % BC;
+                    const float v = neg ? -acc[rt][ct][r] : acc[rt][ct][r];
+                    float *dst = &slab[(cc * 4 + p) * BF + ff];
+                    *dst = ph == 0 ? v : *dst + v;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < BC * 4 * BF; e += NTHR) {
+        const int ff = e % BF;
+        const int p = (e / BF) & 3;
+        const int cc = e / (4 * BF);
+        atomicAdd(dw + ((t * g.Cq + c0 + cc) * 4 + p) * g.F + f0 + ff, slab[e]);
+    }
+    if (do_bias && tid < 4 * BF) {
+        const int b = tid / BF, ff = tid % BF;
+        atomicAdd(dbias + b * g.F + f0 + ff, dbacc);
+    }
+}
+
+template <typename T, int WR, int WC, int TN>
+int run_wgrad16(const T *x, const T *dy, const T *ymask, float *dw, float *dbias, WgradGeom g,
+                hipStream_t stream)
+{
+    constexpr int BC = WR * 16, BF = WC * TN * 8, KM = 64;
+    const int ncc = g.Cq / BC, nfc = g.F / BF;
+    const long long other = (long long)ncc * nfc * g.taps;
+    const long long max_splits = ((long long)g.M + KM - 1) / KM;
+    long long target = (768 + other - 1) / other;                   // ~3 workgroups per CU
+    long long splits = target < 1 ? 1 : (target > max_splits ? max_splits : target);
+    long long mps = (g.M + splits - 1) / splits;
+    mps = (mps + KM - 1) / KM * KM;
+    splits = (g.M + mps - 1) / mps;
+    g.m_per_split = (int)mps;
+    g.ablate = 0;
+    dim3 grid((unsigned)splits, (unsigned)(ncc * nfc), (unsigned)g.taps);
+    if (g.has_mask)
+        hipLaunchKernelGGL((k_wgrad16<T, WR, WC, TN, true>), grid, dim3(WR * WC * 64), 0, stream, x, dy, ymask, dw, dbias, g);
+    else
+        hipLaunchKernelGGL((k_wgrad16<T, WR, WC, TN, false>), grid, dim3(WR * WC * 64), 0, stream, x, dy, ymask, dw, dbias, g);
+    return hipGetLastError() == hipSuccess ? 1 : QK_ERR_LAUNCH;
+}
+
+template <typename T>
+int go_wgrad16(const void *x, const void *dy, const void *ymask, float *dw, float *dbias, const WgradGeom &g,
+               hipStream_t stream)
+{
+    const T *xp = (const T *)x, *dp = (const T *)dy, *yp = (const T *)ymask;
+    if (g.Cq % 64 == 0) {
+        if (g.F % 64 == 0) return run_wgrad16<T, 4, 2, 4>(xp, dp, yp, dw, dbias, g, stream);
+        return run_wgrad16<T, 4, 2, 2>(xp, dp, yp, dw, dbias, g, stream);
+    }
+    if (g.F % 64 == 0) return run_wgrad16<T, 2, 2, 4>(xp, dp, yp, dw, dbias, g, stream);
+    return run_wgrad16<T, 2, 2, 2>(xp, dp, yp, dw, dbias, g, stream);
+}
+
+}  // namespace
+
+// Returns 1 when the 16-bit MFMA path took the call, 0 when the shape is outside its fast path,
+// < 0 on error.  dw / dbias must already be zeroed (the kernel accumulates atomically).
+int try_wgrad_16(int dtype, const void *x, const void *dy, const void *ymask, float *dw, float *dbias,
+                 const WgradGeom &g, hipStream_t stream)
+{
+    if (dtype != QK_BF16 && dtype != QK_F16) return 0;
+    if (g.x_sc != 1 || g.dy_sc != 1) return 0;                         // channels_last buffers only
+    if (g.Cq % 32 != 0 || g.F % 32 != 0) return 0;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(ymask)) & 15) return 0;
+    if (getenv("QK_NO_MFMA16")) return 0;
+    if (dtype == QK_BF16) return go_wgrad16<bf16>(x, dy, ymask, dw, dbias, g, stream);
+    return go_wgrad16<f16>(x, dy, ymask, dw, dbias, g, stream);
+}
+
+}  // namespace qk

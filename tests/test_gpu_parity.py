@@ -110,6 +110,10 @@ ORACLE_CASES = [
      dict(padding='same', activation='relu')),
     ('conv2d_body64_small', 2, (1, 14, 40, 256), (3, 5, 64, 256),
      dict(padding='same', activation='relu')),
+    ('conv2d_32to64', 2, (1, 9, 33, 128), (3, 3, 32, 256),
+     dict(padding='same', activation='relu')),
+    ('conv1d_64to32_valid', 1, (3, 70, 256), (5, 64, 128),
+     dict(padding='valid', activation=None)),
     ('conv2d_chfirst_body_small', 2, (2, 128, 14, 40), (3, 5, 32, 128),
      dict(padding='same', activation='relu', data_format='channels_first')),
     ('conv2d_first_layer', 2, (3, 4, 41, 50), (3, 5, 1, 128),
@@ -136,7 +140,8 @@ def test_fp32_matches_oracle(case):
 
 
 HALF_CASES = [c for c in ORACLE_CASES if c[0] in (
-    'cfg2_conv1d_b8_f64', 'conv1d_odd_channels', 'conv2d_body_small', 'conv2d_body64_small', 'conv2d_chfirst_body_small',
+    'cfg2_conv1d_b8_f64', 'conv1d_odd_channels', 'conv2d_body_small', 'conv2d_body64_small', 'conv2d_32to64', 'conv1d_64to32_valid',
+    'conv2d_chfirst_body_small',
     'conv2d_first_layer', 'dense_timit_head')]
 
 
