@@ -69,9 +69,16 @@ class LayerTrainStep(object):
         self.call = F.conv_call(tuple(self.x.shape), tuple(kernel.shape), dt, len(ks), 1, 'same',
                                 'channels_last', 1, cfg.get('activation', 'relu'), True)
         self.call.static_buffers = True
+        # bwd-data on the masked gradient bwd-weight leaves behind (no second pass over y)
+        self.relu = cfg.get('activation', 'relu') == 'relu'
+        self.call_lin = F.conv_call(tuple(self.x.shape), tuple(kernel.shape), dt, len(ks), 1, 'same',
+                                    'channels_last', 1, 'linear', True)
+        self.call_lin.static_buffers = True
         self.y = torch.empty(self.call.y_shape, dtype=dt, device=dev)
         self.dy = torch.randn(self.call.y_shape, device=dev, generator=gen).to(dt)
         self.dx = torch.empty_like(self.x)
+        nb = (self.dy.numel() * self.dy.element_size() + 255) // 256 * 256
+        self.dym = torch.empty(nb // self.dy.element_size(), dtype=dt, device=dev) if self.relu else None
         self.dw, self.db = self.flat.grad_view(0), self.flat.grad_view(1)
         self.t = 0
         M = B * int(np.prod(sp))
@@ -83,10 +90,13 @@ class LayerTrainStep(object):
         self.call.fwd(self.x, self.kernel.data, self.bias.data, out=self.y)
 
     def k_bwd_weight(self):
-        self.call.bwd_weight(self.x, self.dy, self.y, True, out=(self.dw, self.db))
+        self.call.bwd_weight(self.x, self.dy, self.y, True, out=(self.dw, self.db), masked_dy_out=self.dym)
 
     def k_bwd_data(self):
-        self.call.bwd_data(self.dy, self.y, self.kernel.data, out=self.dx)
+        if self.relu:
+            self.call_lin.bwd_data(self.dym, None, self.kernel.data, out=self.dx)
+        else:
+            self.call.bwd_data(self.dy, self.y, self.kernel.data, out=self.dx)
 
     def _adam(self):
         self.F.adam_step(self.flat.param, self.flat.grad, self.m, self.v, self.t, lr=5e-4,

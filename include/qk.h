@@ -18,6 +18,7 @@
  *                        (signed concat :139-143 == TRANSPOSED table => conj(W) (x) x,
  *                         K.dot :149, bias/activation :159-162)
  *   qk_dense_bwd_data / qk_dense_bwd_weight       TF autodiff of dense.py:126-164
+ *   qk_conv_bwd / qk_dense_bwd                    the same gradients in one fused call
  *   qk_adam_step         the Keras Adam update the reference trains with
  *                        (working_example.py:106, keras.optimizers.Adam defaults) applied to a
  *                        flat fp32 parameter buffer -- used by the data-parallel step.
@@ -65,7 +66,7 @@ typedef enum {
 typedef enum { QK_F32 = 0, QK_BF16 = 1, QK_F16 = 2 } qk_dtype_t;
 typedef enum { QK_CH_LAST = 0, QK_CH_FIRST = 1 } qk_layout_t;
 typedef enum { QK_ACT_LINEAR = 0, QK_ACT_RELU = 1 } qk_act_t;
-typedef enum { QK_OP_FWD = 0, QK_OP_BWD_DATA = 1, QK_OP_BWD_WEIGHT = 2 } qk_op_t;
+typedef enum { QK_OP_FWD = 0, QK_OP_BWD_DATA = 1, QK_OP_BWD_WEIGHT = 2, QK_OP_BWD = 3 } qk_op_t;
 
 /* One quaternion convolution call (QuaternionConv.__init__/build state, conv.py:93-286). */
 typedef struct {
@@ -118,10 +119,20 @@ int qk_conv_fwd(const qk_conv_desc_t *desc, const void *x, const float *w, const
 int qk_conv_bwd_data(const qk_conv_desc_t *desc, const void *dy, const void *y, const float *w,
                      void *dx, void *workspace, size_t workspace_bytes, void *stream);
 
-/* dw [*kernel, cq, 4*fq] and dbias [4*fq] (NULL when !has_bias) are OVERWRITTEN. */
+/* dw [*kernel, cq, 4*fq] and dbias [4*fq] (NULL when !has_bias) are OVERWRITTEN.
+ * Optional: with activation == RELU and a 16-byte-aligned workspace of at least |dy| bytes (rounded
+ * up to 256), the masked gradient dy * (y > 0) is left at the start of the workspace in dy's layout;
+ * qk_conv_bwd_data may then be called on it with activation = LINEAR (no y reads).  This is how a
+ * data-parallel step starts its gradient all-reduce before bwd-data. */
 int qk_conv_bwd_weight(const qk_conv_desc_t *desc, const void *x, const void *dy, const void *y,
                        float *dw, float *dbias, void *workspace, size_t workspace_bytes,
                        void *stream);
+
+/* Fused backward: all three gradients in one call (what TF autodiff of conv.py:288-345 yields).
+ * bwd-weight runs first and, for RELU, leaves the masked dy in the workspace so that bwd-data reads
+ * one tensor instead of two.  dx must not be NULL.  Workspace: qk_*_workspace_bytes(desc, QK_OP_BWD). */
+int qk_conv_bwd(const qk_conv_desc_t *desc, const void *x, const void *dy, const void *y, const float *w,
+                void *dx, float *dw, float *dbias, void *workspace, size_t workspace_bytes, void *stream);
 
 /* Dense ---------------------------------------------------------------------------------
  * x [rows, 4*in_q], w [in_q, 4*q_units] float32, bias [4*q_units], y [rows, 4*q_units]
@@ -133,6 +144,9 @@ int qk_dense_bwd_data(const qk_dense_desc_t *desc, const void *dy, const void *y
 int qk_dense_bwd_weight(const qk_dense_desc_t *desc, const void *x, const void *dy, const void *y,
                         float *dw, float *dbias, void *workspace, size_t workspace_bytes,
                         void *stream);
+
+int qk_dense_bwd(const qk_dense_desc_t *desc, const void *x, const void *dy, const void *y, const float *w,
+                 void *dx, float *dw, float *dbias, void *workspace, size_t workspace_bytes, void *stream);
 
 /* Optimiser step on a flat fp32 buffer (Keras Adam: working_example.py:106).
  *   m = b1*m + (1-b1)*g ; v = b2*v + (1-b2)*g^2

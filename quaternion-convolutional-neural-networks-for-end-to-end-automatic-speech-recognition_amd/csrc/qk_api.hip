@@ -125,13 +125,22 @@ int taps_of(const qk_conv_desc_t *d) { return d->kernel[0] * d->kernel[1] * d->k
 
 size_t w_floats(const qk_conv_desc_t *d) { return (size_t)taps_of(d) * d->cq * 4 * d->fq; }
 
+size_t dy_bytes(const qk_conv_desc_t *d)
+{
+    const size_t e = (size_t)d->batch * d->out_spatial[0] * d->out_spatial[1] * d->out_spatial[2] * 4 * d->fq;
+    return (e * elem_bytes(d->dtype) + 255) / 256 * 256;
+}
+
 size_t ws_bytes_impl(const qk_conv_desc_t *d, int op)
 {
     // bwd-data: per-tap transposed fp32 copy of the compact kernel
     // 16-bit fast path (fwd / bwd-data): 16-bit re-laid-out copy of the compact kernel
+    // fused backward additionally: the relu-masked copy of dy that bwd-weight writes for bwd-data
     size_t n = 0;
-    if (op == QK_OP_BWD_DATA) n = w_floats(d) * sizeof(float);
-    if (d->dtype != QK_F32 && (op == QK_OP_FWD || op == QK_OP_BWD_DATA)) n += w_floats(d) * 2 + 256;
+    const bool bwd_data = op == QK_OP_BWD_DATA || op == QK_OP_BWD;
+    if (bwd_data) n = w_floats(d) * sizeof(float);
+    if (d->dtype != QK_F32 && (op == QK_OP_FWD || bwd_data)) n += w_floats(d) * 2 + 256;
+    if (op == QK_OP_BWD && d->activation == QK_ACT_RELU) n = (n + 255) / 256 * 256 + dy_bytes(d);
     return n;
 }
 
@@ -210,7 +219,7 @@ int conv_bwd_data_impl(const qk_conv_desc_t *d, const void *dy, const void *y, c
 }
 
 int conv_bwd_weight_impl(const qk_conv_desc_t *d, const void *x, const void *dy, const void *y, float *dw,
-                         float *dbias, void *, size_t, hipStream_t stream)
+                         float *dbias, void *dy_masked_out, hipStream_t stream)
 {
     if (!x || !dy || !dw) { set_error("x/dy/dw must not be NULL"); return QK_ERR_INVALID_ARG; }
     const bool mask = d->activation == QK_ACT_RELU;
@@ -233,6 +242,7 @@ int conv_bwd_weight_impl(const qk_conv_desc_t *d, const void *x, const void *dy,
     g.sign_tbl = d->conj ? kSignConj : kSignConv;
     g.has_mask = mask ? 1 : 0;
     g.want_dbias = (d->has_bias && dbias) ? 1 : 0;
+    g.dym = mask ? dy_masked_out : nullptr;
     if (hipMemsetAsync(dw, 0, w_floats(d) * sizeof(float), stream) != hipSuccess) { set_error("memset dw failed"); return QK_ERR_LAUNCH; }
     if (g.want_dbias && hipMemsetAsync(dbias, 0, 4 * (size_t)d->fq * sizeof(float), stream) != hipSuccess) {
         set_error("memset dbias failed"); return QK_ERR_LAUNCH;
@@ -244,6 +254,26 @@ int conv_bwd_weight_impl(const qk_conv_desc_t *d, const void *x, const void *dy,
     const bool vec = d->layout == QK_CH_LAST && d->cq % 4 == 0 && d->fq % 4 == 0 &&
                      vec_aligned(x, d->dtype) && vec_aligned(dy, d->dtype) && (!mask || vec_aligned(y, d->dtype));
     return launch_wgrad(d->dtype, x, dy, mask ? y : nullptr, dw, dbias, g, vec, stream);
+}
+
+// Fused backward: bwd-weight first (it reads dy and y once and, for RELU, also writes the masked dy
+// into the workspace), then bwd-data on the masked copy with no mask loads of its own.
+int conv_bwd_impl(const qk_conv_desc_t *d, const void *x, const void *dy, const void *y, const float *w,
+                  void *dx, float *dw, float *dbias, void *ws, size_t wsb, hipStream_t stream)
+{
+    if (!dx) { set_error("dx must not be NULL (use qk_*_bwd_weight when d(input) is not needed)"); return QK_ERR_INVALID_ARG; }
+    const size_t need = ws_bytes_impl(d, QK_OP_BWD);
+    if (need && (!ws || wsb < need)) { set_error("bwd needs %zu workspace bytes, got %zu", need, wsb); return QK_ERR_WORKSPACE; }
+    const bool relu = d->activation == QK_ACT_RELU;
+    const size_t bd = ws_bytes_impl(d, QK_OP_BWD_DATA);
+    void *dym = relu ? static_cast<char *>(ws) + (bd + 255) / 256 * 256 : nullptr;
+    if (relu && (bd + 255) / 256 * 256 + dy_bytes(d) > wsb + 255) { set_error("workspace too small for the masked dy"); return QK_ERR_WORKSPACE; }
+    int rc = conv_bwd_weight_impl(d, x, dy, y, dw, dbias, dym, stream);
+    if (rc) return rc;
+    if (!relu) return conv_bwd_data_impl(d, dy, y, w, dx, ws, bd, stream);
+    qk_conv_desc_t lin = *d;
+    lin.activation = QK_ACT_LINEAR;
+    return conv_bwd_data_impl(&lin, dym, nullptr, w, dx, ws, bd, stream);
 }
 
 qk_conv_desc_t dense_as_conv(const qk_dense_desc_t *d)
@@ -309,7 +339,24 @@ int qk_conv_bwd_weight(const qk_conv_desc_t *desc, const void *x, const void *dy
                        float *dbias, void *workspace, size_t workspace_bytes, void *stream)
 {
     if (int rc = validate(desc, false)) return rc;
-    return check_launch(conv_bwd_weight_impl(desc, x, dy, y, dw, dbias, workspace, workspace_bytes, (hipStream_t)stream), "qk_conv_bwd_weight");
+    void *dym = (workspace && workspace_bytes >= dy_bytes(desc) && aligned(workspace, 16)) ? workspace : nullptr;
+    return check_launch(conv_bwd_weight_impl(desc, x, dy, y, dw, dbias, dym, (hipStream_t)stream), "qk_conv_bwd_weight");
+}
+
+int qk_conv_bwd(const qk_conv_desc_t *desc, const void *x, const void *dy, const void *y, const float *w,
+                void *dx, float *dw, float *dbias, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (int rc = validate(desc, false)) return rc;
+    return check_launch(conv_bwd_impl(desc, x, dy, y, w, dx, dw, dbias, workspace, workspace_bytes, (hipStream_t)stream), "qk_conv_bwd");
+}
+
+int qk_dense_bwd(const qk_dense_desc_t *desc, const void *x, const void *dy, const void *y, const float *w,
+                 void *dx, float *dw, float *dbias, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!desc) { set_error("descriptor is NULL"); return QK_ERR_INVALID_ARG; }
+    const qk_conv_desc_t c = dense_as_conv(desc);
+    if (int rc = validate(&c, true)) return rc;
+    return check_launch(conv_bwd_impl(&c, x, dy, y, w, dx, dw, dbias, workspace, workspace_bytes, (hipStream_t)stream), "qk_dense_bwd");
 }
 
 int qk_dense_fwd(const qk_dense_desc_t *desc, const void *x, const float *w, const float *bias, void *y,
@@ -336,7 +383,8 @@ int qk_dense_bwd_weight(const qk_dense_desc_t *desc, const void *x, const void *
     if (!desc) { set_error("descriptor is NULL"); return QK_ERR_INVALID_ARG; }
     const qk_conv_desc_t c = dense_as_conv(desc);
     if (int rc = validate(&c, true)) return rc;
-    return check_launch(conv_bwd_weight_impl(&c, x, dy, y, dw, dbias, workspace, workspace_bytes, (hipStream_t)stream), "qk_dense_bwd_weight");
+    void *dym = (workspace && workspace_bytes >= dy_bytes(&c) && aligned(workspace, 16)) ? workspace : nullptr;
+    return check_launch(conv_bwd_weight_impl(&c, x, dy, y, dw, dbias, dym, (hipStream_t)stream), "qk_dense_bwd_weight");
 }
 
 int qk_adam_step(float *param, const float *grad, float *m, float *v, size_t n, float lr, float beta1,

@@ -68,6 +68,8 @@ struct WgradGeom {
     int want_dbias;
     int m_per_split;    // rows of M each blockIdx.x reduces (multiple of the kernel's K step)
     int ablate;         // profiling only (env QK_ABLATE): 1 = skip fold + atomics, 2 = skip HBM atomics
+    void *dym;          // optional output: dy with the relu mask applied (same layout/dtype as dy), or NULL;
+                        // written by the blocks of tap 0 / channel chunk 0, which see every (row, filter) once
 };
 
 // ---------------------------------------------------------------------------------------

@@ -100,6 +100,9 @@ k_wgrad16(const T *__restrict__ x, const T *__restrict__ dy, const T *__restrict
     const int s_row = tid / TPROW, s_sub = tid % TPROW;
     uint4 xr[UX], dr[UD], mr[MASK ? UD : 1];
     bool x_ok = false, d_ok = false;
+    int d_e0 = 0;                                            // dY element offset of this thread's row
+    const bool write_dym = MASK && g.dym != nullptr && t == 0 && cchunk == 0;
+    T *dym = static_cast<T *>(g.dym);
 
     auto load_tile = [&](int mb) {
         const int m = mb + s_row;
@@ -119,6 +122,7 @@ k_wgrad16(const T *__restrict__ x, const T *__restrict__ dy, const T *__restrict
             if (x_ok) xo = n * (int)g.x_sn + i0 * (int)g.x_ss[0] + i1 * (int)g.x_ss[1] + i2 * (int)g.x_ss[2];
         }
         const int yo = d_ok ? m * (int)g.dy_ss : 0;
+        d_e0 = yo;
 #pragma unroll
         for (int i = 0; i < UX; ++i) {
             const int u = s_sub + i * TPROW;
@@ -148,6 +152,12 @@ k_wgrad16(const T *__restrict__ x, const T *__restrict__ dy, const T *__restrict
                 v = make_uint4(relu_keep2(v.x, mr[i].x), relu_keep2(v.y, mr[i].y), relu_keep2(v.z, mr[i].z),
                                relu_keep2(v.w, mr[i].w));
             *reinterpret_cast<uint4 *>(ds + (s_sub + i * TPROW) * 16) = v;
+            if constexpr (MASK) {
+                if (write_dym && d_ok) {
+                    const int u = s_sub + i * TPROW;
+                    *reinterpret_cast<uint4 *>(dym + d_e0 + (u / (BF / 8)) * g.F + f0 + (u % (BF / 8)) * 8) = v;
+                }
+            }
         }
     };
 

@@ -73,18 +73,38 @@ class _Call(object):
         L.check(rc, self.names[1])
         return dx
 
-    def bwd_weight(self, x, dy, y, has_bias, out=None):
+    def bwd_weight(self, x, dy, y, has_bias, out=None, masked_dy_out=None):
+        """dw, db.  `masked_dy_out` (a tensor like dy) receives dy*(y>0) for RELU layers."""
         if out is not None:
             dw, db = out
         else:
             dw = torch.empty(self.w_shape, dtype=torch.float32, device=x.device)
             db = torch.empty((self.w_shape[-1],), dtype=torch.float32, device=x.device) if has_bias else None
         ws, n = self._ws(L.QK_OP_BWD_WEIGHT, x)
+        if masked_dy_out is not None:
+            ws, n = masked_dy_out, masked_dy_out.numel() * masked_dy_out.element_size()
         with torch.cuda.device(x.device):
             rc = getattr(L.lib(), self.names[2])(ctypes.byref(self.desc), _ptr(x), _ptr(dy), _ptr(y),
                                                  _ptr(dw), _ptr(db), _ptr(ws), n, _stream(x))
         L.check(rc, self.names[2])
         return dw, db
+
+
+    def bwd(self, x, dy, y, w, has_bias, out=None):
+        """Fused backward (qk_*_bwd): returns (dx, dw, db)."""
+        if out is not None:
+            dx, dw, db = out
+        else:
+            dx = torch.empty(self.x_shape, dtype=dy.dtype, device=dy.device)
+            dw = torch.empty(self.w_shape, dtype=torch.float32, device=x.device)
+            db = torch.empty((self.w_shape[-1],), dtype=torch.float32, device=x.device) if has_bias else None
+        ws, n = self._ws(L.QK_OP_BWD, x)
+        name = self.names[1].replace('_bwd_data', '_bwd')
+        with torch.cuda.device(x.device):
+            rc = getattr(L.lib(), name)(ctypes.byref(self.desc), _ptr(x), _ptr(dy), _ptr(y), _ptr(w), _ptr(dx),
+                                        _ptr(dw), _ptr(db), _ptr(ws), n, _stream(x))
+        L.check(rc, name)
+        return dx, dw, db
 
 
 class _HamiltonFn(torch.autograd.Function):
@@ -102,9 +122,12 @@ class _HamiltonFn(torch.autograd.Function):
         call = ctx.call
         dy = dy.contiguous()
         dx = dw = db = None
-        if ctx.needs_input_grad[0]:
+        want_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
+        if ctx.needs_input_grad[0] and want_w:
+            dx, dw, db = call.bwd(x, dy, y, w, ctx.has_bias)        # fused: one pass over (dy, y)
+        elif ctx.needs_input_grad[0]:
             dx = call.bwd_data(dy, y, w)
-        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+        elif want_w:
             dw, db = call.bwd_weight(x, dy, y, ctx.has_bias)
         return dx, dw, db, None
 
