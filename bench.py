@@ -134,11 +134,12 @@ class LayerTrainStep(object):
             self.step = self._step_graph1
         else:
             self.g_a, self.g_b, self.g_c = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g_a):
+            mode = dict(capture_error_mode='thread_local')      # the RCCL watchdog thread polls events
+            with torch.cuda.graph(self.g_a, **mode):
                 self.k_fwd(); self.k_bwd_weight()
-            with torch.cuda.graph(self.g_b):
+            with torch.cuda.graph(self.g_b, **mode):
                 self.k_bwd_data()
-            with torch.cuda.graph(self.g_c):
+            with torch.cuda.graph(self.g_c, **mode):
                 self._adam()
             self.step = self._step_graphN
 
@@ -237,6 +238,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
+    ap.add_argument('--graph-multi', action='store_true',
+                    help='also use hipGraph segments around the RCCL all-reduce when N > 1 (default: eager for N > 1)')
     ap.add_argument('--activation', default='relu', choices=['relu', 'linear'], help='diagnostic: linear drops the relu mask')
     args = ap.parse_args()
 
@@ -259,7 +262,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    use_graph = not args.no_graph
+    use_graph = not args.no_graph and (world == 1 or args.graph_multi)
     if use_graph:
         try:
             job.step()
