@@ -41,7 +41,73 @@ WORKLOADS = {
                                         kernel=(3, 5), dtype='bf16'),
     'cfg3_body_qconv2d_b256_fp32': dict(kind='conv', rank=2, batch=256, spatial=(14, 200), cq=64, filters=64,
                                         kernel=(3, 5), dtype='fp32'),
+    # BASELINE.json configs[2]: the full TIMIT QCNN (models/interspeech_model.py:45-185), n=10, sf=32
+    'cfg3_qcnn_timit_b256_bf16': dict(kind='model', batch=256, frames=200, sf=32, layers=10, dtype='bf16'),
+    'cfg3_qcnn_timit_b64_fp32': dict(kind='model', batch=64, frames=200, sf=32, layers=10, dtype='fp32'),
 }
+
+
+def qcnn_flops(sf, n, batch, frames):
+    """Algorithmic fwd FLOPs (2MNK) of the quaternion layers of getTimitModel2D."""
+    def conv(m, cq, f, taps=15):
+        return 2.0 * m * 4 * f * taps * 4 * cq
+    m0, m1 = batch * 41 * frames, batch * 14 * frames
+    total = conv(m0, 1, sf)
+    widths = [sf] * (n // 2) + [2 * sf] * (n // 2)
+    cin = sf
+    for w in widths:
+        total += conv(m1, cin, w)
+        cin = w
+    mt = batch * frames
+    total += 2.0 * mt * 256 * (14 * 4 * cin)          # TimeDistributed(QuaternionDense(256)) on C*F features
+    total += 2 * 2.0 * mt * 256 * 256
+    return total
+
+
+class ModelTrainStep(object):
+    """Full TIMIT QCNN: forward + backward (autograd through the C-ABI kernels) + all-reduce + Adam."""
+
+    def __init__(self, cfg, dev, rank, world):
+        import qcnn_amd
+        from qcnn_amd import dp, functional as F
+        from qcnn_amd.models import TimitQCNN
+        self.F, self.dp, self.world, self.cfg = F, dp, world, cfg
+        dt = TORCH_DT[cfg['dtype']]
+        gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+        B, T = cfg['batch'], cfg['frames']
+        # channels_first quaternion features, physically channels-last (DESIGN.md section 2)
+        self.x = torch.randn(B, 41, T, 4, device=dev, generator=gen).to(dt).permute(0, 3, 1, 2)
+        np.random.seed(0)
+        torch.manual_seed(0)
+        self.model = TimitQCNN(num_layers=cfg['layers'], start_filter=cfg['sf'], act='relu', aact='none', dropout=0.0)
+        with torch.no_grad():
+            self.model(self.x[:2])
+        self.model.to(dev)
+        params = [p for p in self.model.parameters() if p.requires_grad]
+        self.flat = dp.FlatParams(params)
+        dp.broadcast_params(self.flat)
+        self.m = torch.zeros_like(self.flat.param)
+        self.v = torch.zeros_like(self.flat.param)
+        self.target = torch.randn(B, T, 62, device=dev, generator=gen)
+        self.t = 0
+        self.flops_per_kernel = qcnn_flops(cfg['sf'], cfg['layers'], B, T)      # forward; step = 3x
+        self.gemm = dict(layers='conv 1->%d, %dx conv, 3x TD-dense' % (cfg['sf'], cfg['layers']))
+        self.y = self.x
+
+    def step(self):
+        self.t += 1
+        pred = self.model(self.x)
+        loss = (pred.float() * self.target).sum()
+        self.flat.zero_grad()
+        loss.backward()
+        work = self.dp.allreduce_sum_(self.flat.grad, async_op=True)
+        if work is not None:
+            work.wait()
+        self.F.adam_step(self.flat.param, self.flat.grad, self.m, self.v, self.t, lr=5e-4,
+                         grad_scale=1.0 / self.world)
+
+    def capture(self):
+        raise RuntimeError('model workloads run eagerly (launch overhead is negligible at this size)')
 
 
 class LayerTrainStep(object):
@@ -255,14 +321,15 @@ def main():
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
     cfg = dict(WORKLOADS[args.workload], activation=args.activation)
-    job = LayerTrainStep(cfg, dev, rank, world)
+    is_model = cfg.get('kind') == 'model'
+    job = ModelTrainStep(cfg, dev, rank, world) if is_model else LayerTrainStep(cfg, dev, rank, world)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    use_graph = not args.no_graph and (world == 1 or args.graph_multi)
+    use_graph = not args.no_graph and (world == 1 or args.graph_multi) and not is_model
     if use_graph:
         try:
             job.step()
@@ -286,18 +353,25 @@ def main():
     samples_per_s = world * cfg['batch'] * args.steps / elapsed
 
     out = {
-        'metric': 'quaternion-conv samples/sec (fwd+bwd+Adam of one QuaternionConv layer)',
+        'metric': 'quaternion-conv samples/sec (fwd+bwd+Adam of %s)' % ('the full TIMIT QCNN' if is_model else 'one QuaternionConv layer'),
         'value': samples_per_s, 'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': cfg['dtype'], 'data': 'synthetic',
         'config': {'workload': args.workload, 'per_gpu_batch': cfg['batch'],
                    'global_batch': cfg['batch'] * world, 'input': list(job.x.shape),
-                   'filters': cfg['filters'], 'kernel_size': list(cfg['kernel']), 'padding': 'same',
+                   'filters': cfg.get('filters', cfg.get('sf')), 'kernel_size': list(cfg.get('kernel', (3, 5))), 'padding': 'same',
                    'activation': cfg['activation'], 'gemm_view': job.gemm, 'parallelism': 'dp%d' % world,
                    'optimizer': 'adam(5e-4)', 'launch': 'hipgraph' if use_graph else 'eager'},
     }
 
-    if rank == 0 and not args.no_kernel_timing:
+    if rank == 0 and is_model:
+        peak = PEAK_TFLOPS[cfg['dtype']]
+        tf = 3 * job.flops_per_kernel / (ms_per_step * 1e-3) / 1e12
+        out['roofline'] = {'bound': 'mfma', 'kernel': 'whole step: quaternion layers, 2MNK fwd + 4MNK bwd', 'achieved': tf,
+                           'peak': peak, 'unit': 'TFLOP/s', 'frac': tf / peak, 'traffic': None,
+                           'flops_per_launch': 3 * job.flops_per_kernel, 'avg_launch_ms': ms_per_step}
+        out['step_tflops'] = tf
+    if rank == 0 and not args.no_kernel_timing and not is_model:
         stream = torch.cuda.current_stream(dev)
         kernels = {}
         for name, fn in (('fwd', job.k_fwd), ('bwd_weight', job.k_bwd_weight), ('bwd_data', job.k_bwd_data)):
@@ -314,7 +388,7 @@ def main():
         out['step_tflops'] = step_flops / (ms_per_step * 1e-3) / 1e12
     if world > 1:
         dist.barrier()
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not is_model:
         out['cpu_baseline'] = cpu_baseline(cfg, args.cpu_seconds)
     if rank == 0:
         print(json.dumps(out))

@@ -8,6 +8,8 @@ The layers run only through libqk_hip.so (include/qk.h); there is no CPU fallbac
 """
 from . import _lib, functional, keras_like          # noqa: F401
 from . import complexnn                             # noqa: F401
+from . import layers, data, dp                      # noqa: F401
+from . import models                                # noqa: F401
 from .complexnn import *                            # noqa: F401,F403
 
 __version__ = '0.1.0'

@@ -1,0 +1,183 @@
+"""Stock (real-valued) Keras layers the reference's model builders put AROUND the quaternion
+layers (models/example_model.py, models/interspeech_model.py): pooling, Flatten, Dense, Dropout,
+PReLU, TimeDistributed, Permute.  They are callers of the hot path, not part of it, and are plain
+torch ops with the Keras/TensorFlow semantics the models rely on:
+
+  * 'same' pooling pads like TensorFlow (extra cell on the high side); average pooling does NOT
+    count the padding in its divisor;
+  * MaxPooling2D/AveragePooling without `data_format` pool axes 1..rank of the tensor as given
+    (the stock channels_last default the TIMIT model inherits, interspeech_model.py:103 -- for its
+    (B, 4F, 41, T) tensor this pools the 41-bin frequency axis 41 -> 14).
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from ._shape import normalize_tuple, tf_pads
+from .keras_like import Layer, activations, initializers, regularizers
+
+
+class Flatten(Layer):
+    def call(self, inputs):
+        return inputs.reshape(inputs.shape[0], -1)
+
+    def compute_output_shape(self, input_shape):
+        return (input_shape[0], int(np.prod(input_shape[1:])))
+
+
+class Dropout(Layer):
+    def __init__(self, rate, **kwargs):
+        super(Dropout, self).__init__(**kwargs)
+        self.rate = rate
+
+    def call(self, inputs):
+        return F.dropout(inputs, self.rate, self.training)
+
+
+class Dense(Layer):
+    """keras.layers.Dense on the last axis (kernel (in, units), glorot_uniform by default)."""
+
+    def __init__(self, units, activation=None, use_bias=True, kernel_initializer='glorot_uniform',
+                 bias_initializer='zeros', kernel_regularizer=None, bias_regularizer=None, **kwargs):
+        super(Dense, self).__init__(**kwargs)
+        self.units, self.use_bias = units, use_bias
+        self.activation = activations.get(activation)
+        self.kernel_initializer = initializers.get(kernel_initializer)
+        self.bias_initializer = initializers.get(bias_initializer)
+        self.kernel_regularizer = regularizers.get(kernel_regularizer)
+        self.bias_regularizer = regularizers.get(bias_regularizer)
+
+    def build(self, input_shape):
+        self.add_weight('kernel', (input_shape[-1], self.units), initializer=self.kernel_initializer,
+                        regularizer=self.kernel_regularizer)
+        if self.use_bias:
+            self.add_weight('bias', (self.units,), initializer=self.bias_initializer,
+                            regularizer=self.bias_regularizer)
+        else:
+            self.bias = None
+        self.built = True
+
+    def call(self, inputs):
+        out = inputs @ self.kernel.to(inputs.dtype)
+        if self.bias is not None:
+            out = out + self.bias.to(inputs.dtype)
+        return self.activation(out)
+
+    def compute_output_shape(self, input_shape):
+        return tuple(input_shape[:-1]) + (self.units,)
+
+
+def _pool_nd(x, pool, strides, padding, axes, mode):
+    """Pool `axes` of x with TensorFlow padding semantics."""
+    rank = len(axes)
+    perm = [0] + [i for i in range(1, x.dim()) if i not in axes] + list(axes)
+    xp = x.permute(perm)
+    lead = xp.shape[:x.dim() - rank]
+    xp = xp.reshape((-1, 1) + tuple(xp.shape[-rank:]))
+    pads = []
+    for ax in reversed(range(rank)):
+        lo, hi = tf_pads(xp.shape[2 + ax], pool[ax], strides[ax], 1, padding)
+        pads += [lo, hi]
+    fn = {1: (F.max_pool1d, F.avg_pool1d), 2: (F.max_pool2d, F.avg_pool2d), 3: (F.max_pool3d, F.avg_pool3d)}[rank]
+    if mode == 'max':
+        if any(pads):
+            xp = F.pad(xp, pads, value=float('-inf'))
+        y = fn[0](xp, pool, strides)
+    else:
+        k = float(np.prod(pool))
+        if any(pads):
+            ones = F.pad(torch.ones_like(xp), pads)
+            y = fn[1](F.pad(xp, pads), pool, strides) / fn[1](ones, pool, strides)   # divisor excludes padding
+        else:
+            y = fn[1](xp, pool, strides)
+        del k
+    y = y.reshape(tuple(lead) + tuple(y.shape[-rank:]))
+    inv = [0] * x.dim()
+    for i, p in enumerate(perm):
+        inv[p] = i
+    return y.permute(inv)
+
+
+class _Pooling(Layer):
+    rank, mode = 1, 'max'
+
+    def __init__(self, pool_size=2, strides=None, padding='valid', data_format=None, **kwargs):
+        super(_Pooling, self).__init__(**kwargs)
+        self.pool_size = normalize_tuple(pool_size, self.rank, 'pool_size')
+        self.strides = normalize_tuple(self.pool_size if strides is None else strides, self.rank, 'strides')
+        self.padding = padding
+        self.data_format = 'channels_last' if data_format is None else data_format
+
+    def call(self, inputs):
+        first = 2 if self.data_format == 'channels_first' else 1
+        axes = tuple(range(first, first + self.rank))
+        return _pool_nd(inputs, self.pool_size, self.strides, self.padding, axes, self.mode)
+
+
+class AveragePooling1D(_Pooling):
+    rank, mode = 1, 'avg'
+
+
+class MaxPooling1D(_Pooling):
+    rank, mode = 1, 'max'
+
+
+class MaxPooling2D(_Pooling):
+    rank, mode = 2, 'max'
+
+
+class AveragePooling2D(_Pooling):
+    rank, mode = 2, 'avg'
+
+
+class PReLU(Layer):
+    """keras.layers.PReLU: alpha has the input's shape without the batch axis, broadcast (size 1)
+    on `shared_axes`; axes of unknown length are shared too (the TIMIT model's time axis)."""
+
+    def __init__(self, alpha_initializer='zeros', shared_axes=None, **kwargs):
+        super(PReLU, self).__init__(**kwargs)
+        self.shared_axes = [a for a in (shared_axes or []) if a != 0]
+        self.alpha_initializer = initializers.get(alpha_initializer)
+
+    def build(self, input_shape):
+        shape = [1 if (i + 1) in self.shared_axes or d is None else d for i, d in enumerate(input_shape[1:])]
+        self.add_weight('alpha', tuple(shape), initializer=self.alpha_initializer)
+        self.built = True
+
+    def call(self, inputs):
+        a = self.alpha.to(inputs.dtype)
+        return torch.relu(inputs) - a * torch.relu(-inputs)
+
+
+class Permute(Layer):
+    def __init__(self, dims, **kwargs):
+        super(Permute, self).__init__(**kwargs)
+        self.dims = tuple(dims)
+
+    def call(self, inputs):
+        return inputs.permute((0,) + self.dims)
+
+
+class TimeDistributed(Layer):
+    """Applies `layer` to every step of (B, T, ...): folds T into the batch, as Keras does."""
+
+    def __init__(self, layer, **kwargs):
+        super(TimeDistributed, self).__init__(**kwargs)
+        self.layer = layer
+
+    def call(self, inputs):
+        b, t = inputs.shape[0], inputs.shape[1]
+        y = self.layer(inputs.reshape((b * t,) + tuple(inputs.shape[2:])))
+        return y.reshape((b, t) + tuple(y.shape[1:]))
+
+
+def ctc_batch_cost(y_pred, labels, input_length, label_length, blank=None):
+    """K.ctc_batch_cost (interspeech_model.py:37-39): y_pred (B, T, C) softmax outputs, blank = last
+    class; returns the per-sample negative log-likelihood (B, 1)."""
+    blank = y_pred.shape[-1] - 1 if blank is None else blank
+    logp = torch.log(y_pred.float().clamp_min(1e-7)).transpose(0, 1)
+    loss = F.ctc_loss(logp, labels.long(), input_length.reshape(-1).long(), label_length.reshape(-1).long(),
+                      blank=blank, reduction='none', zero_infinity=False)
+    return loss.reshape(-1, 1)

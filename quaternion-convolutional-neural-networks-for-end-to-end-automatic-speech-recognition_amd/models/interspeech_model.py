@@ -1,0 +1,73 @@
+"""TIMIT quaternion CNN + CTC -- counterpart of models/interspeech_model.py:getTimitModel2D (:45-185).
+
+Input (B, 4, 41, T) channels_first quaternion features; QuaternionConv2D(sf,(3,5),'same') ->
+MaxPooling2D((1,3),'same') (frequency 41 -> 14, see layers.py) -> n/2 convs of sf filters ->
+n/2 convs of 2*sf filters (PReLU + Dropout after each) -> Permute/reshape to (B, T, C*F) ->
+3 x TimeDistributed(QuaternionDense(256)) -> TimeDistributed(Dense(62, softmax)) -> CTC.
+`d` is the reference's attribute bag (num_layers, start_filter, act, aact, dropout, l2, model,
+quat_init); only the quaternion branch (`d.model == 'quaternion'`) is built.
+"""
+import torch
+
+from ..complexnn import QuaternionConv2D, QuaternionDense
+from ..keras_like import regularizers
+from ..layers import Dense, Dropout, MaxPooling2D, PReLU, TimeDistributed, ctc_batch_cost
+
+
+class TimitQCNN(torch.nn.Module):
+    def __init__(self, num_layers=10, start_filter=32, act='relu', aact='none', dropout=0.0, l2=0.0,
+                 quat_init='quaternion', internal_layout='channels_last'):
+        super(TimitQCNN, self).__init__()
+        n, sf = num_layers, start_filter
+        if aact != 'none':
+            act = 'linear'                                   # interspeech_model.py:55-56
+        reg = regularizers.l2(l2) if l2 else None
+        conv_args = dict(activation=act, data_format='channels_first', padding='same', bias_initializer='zeros',
+                         kernel_regularizer=reg, kernel_initializer=quat_init, use_bias=True,
+                         internal_layout=internal_layout)
+        dense_args = dict(activation=act, kernel_regularizer=reg, kernel_initializer='random_uniform',
+                          bias_initializer='zeros', use_bias=True)
+        self.aact, self.rate = aact, dropout
+        self.conv = QuaternionConv2D(sf, (3, 5), name='conv', **conv_args)
+        self.pool = MaxPooling2D(pool_size=(1, 3), padding='same')
+        widths = [sf] * (n // 2) + [2 * sf] * (n // 2)
+        self.convs = torch.nn.ModuleList([QuaternionConv2D(w, (3, 5), name='conv%d' % i, **conv_args)
+                                          for i, w in enumerate(widths)])
+        self.dense = torch.nn.ModuleList([TimeDistributed(QuaternionDense(256, **dense_args)) for _ in range(3)])
+        n_act = 1 + len(widths) + 3
+        self.prelu = torch.nn.ModuleList([PReLU(shared_axes=[1, 0]) for _ in range(n_act)]) if aact == 'prelu' else None
+        self.drop = Dropout(dropout)
+        self.pred = TimeDistributed(Dense(62, activation='softmax', kernel_regularizer=reg, use_bias=True,
+                                          bias_initializer='zeros', kernel_initializer='random_uniform'))
+
+    def _act(self, x, i):
+        return self.prelu[i](x) if self.prelu is not None else x
+
+    def forward(self, x):
+        o = self._act(self.conv(x), 0)
+        o = self.pool(o)
+        k = 1
+        for c in self.convs:
+            o = self.drop(self._act(c(o), k))
+            k += 1
+        o = o.permute(0, 3, 1, 2)                            # Permute((3,1,2)): (B, T, C, F)
+        o = o.reshape(o.shape[0], o.shape[1], o.shape[2] * o.shape[3])
+        for i, dl in enumerate(self.dense):
+            o = self._act(dl(o), k)
+            k += 1
+            if i < 2:
+                o = self.drop(o)
+        return self.pred(o)
+
+    def ctc_loss(self, x, labels, input_length, label_length):
+        return ctc_batch_cost(self(x), labels, input_length, label_length)
+
+
+def getTimitModel2D(d):
+    """(model, val_function) like the reference: `model(x)` gives the (B, T, 62) posteriors,
+    `model.ctc_loss(...)` the CTC cost of interspeech_model.py:178; val_function(x) == model(x)."""
+    if getattr(d, 'model', 'quaternion') != 'quaternion':
+        raise NotImplementedError('only the quaternion branch of getTimitModel2D is provided')
+    m = TimitQCNN(d.num_layers, d.start_filter, d.act, d.aact, d.dropout, getattr(d, 'l2', 0.0),
+                  getattr(d, 'quat_init', 'quaternion'))
+    return m, (lambda x: m(x))

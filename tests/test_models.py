@@ -1,0 +1,124 @@
+"""Callers of the hot path: stock-layer semantics on CPU, and the example
+networks on the GPU against an oracle-composed forward."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import qcnn_amd
+from qcnn_amd.layers import AveragePooling1D, Dense, Flatten, MaxPooling2D, PReLU, TimeDistributed, ctc_batch_cost
+
+
+def test_average_pooling_same_excludes_padding_from_divisor():
+    x = torch.arange(2 * 7 * 3.).reshape(2, 7, 3)
+    y = AveragePooling1D(2, padding='same')(x)
+    assert tuple(y.shape) == (2, 4, 3)
+    assert torch.allclose(y[0, :, 0], torch.tensor([1.5, 7.5, 13.5, 18.0]))
+    y4 = AveragePooling1D(4, padding='same')(torch.ones(1, 125, 2))       # QCNN: 125 -> 32 steps
+    assert tuple(y4.shape) == (1, 32, 2) and torch.allclose(y4, torch.ones_like(y4))
+
+
+def test_maxpool_default_format_pools_the_frequency_axis():
+    x = torch.randn(2, 8, 41, 5)
+    y = MaxPooling2D(pool_size=(1, 3), padding='same')(x)
+    assert tuple(y.shape) == (2, 8, 14, 5)
+    assert torch.equal(y[:, :, 0, :], x[:, :, 0:3, :].amax(2))
+    assert torch.equal(y[:, :, 13, :], x[:, :, 39:41, :].amax(2))           # last window: 2 real cells
+
+
+def test_dense_prelu_timedistributed_ctc_on_cpu():
+    np.random.seed(0)
+    d = TimeDistributed(Dense(5, activation='softmax'))
+    y = d(torch.randn(2, 7, 3))
+    assert tuple(y.shape) == (2, 7, 5) and torch.allclose(y.sum(-1), torch.ones(2, 7), atol=1e-6)
+    p = PReLU(shared_axes=[1, 0])
+    z = p(torch.tensor([[[-2.0, 3.0]]]))
+    assert tuple(p.alpha.shape) == (1, 2) and torch.equal(z, torch.tensor([[[0.0, 3.0]]]))
+    cost = ctc_batch_cost(y, torch.tensor([[1, 2], [3, 0]]), torch.tensor([[7], [7]]), torch.tensor([[2], [1]]))
+    assert tuple(cost.shape) == (2, 1) and torch.isfinite(cost).all() and (cost > 0).all()
+    assert tuple(Flatten()(torch.zeros(3, 4, 5)).shape) == (3, 20)
+
+
+def test_decoda_reader_matches_survey_facts(tmp_path):
+    line = ' '.join('0,%g,%g,%g' % (0.01 * i, 0.02, 0.03) for i in range(250)) + '\t' + \
+           ' '.join('%d,%d,%d,%d' % ((1,) * 4 if k == 3 else (0,) * 4) for k in range(8)) + '\n'
+    f = tmp_path / 'x.data'
+    f.write_text(line * 2)
+    x, y = qcnn_amd.data.dataPrepDecodaQuaternion(str(f), isquat=True)
+    assert x.shape == (2, 250, 4) and y.shape == (2, 8) and x.dtype == np.float64
+    assert x[0, 5, 1] == pytest.approx(0.05) and x[0, :, 0].max() == 0 and y[1].tolist() == [0, 0, 0, 1, 0, 0, 0, 0]
+    x3, _ = qcnn_amd.data.dataPrepDecodaQuaternion(str(f), isquat=False)
+    assert x3.shape == (2, 250, 3) and x3[0, 5, 0] == pytest.approx(0.05)
+
+
+def _np_avgpool_same(x, k):
+    t = x.shape[1]
+    out = -(-t // k)
+    total = max((out - 1) * k + k - t, 0)
+    lo = total // 2
+    y = np.zeros((x.shape[0], out, x.shape[2]))
+    for o in range(out):
+        a, b = max(o * k - lo, 0), min(o * k - lo + k, t)
+        y[:, o] = x[:, a:b].mean(1)
+    return y
+
+
+@pytest.mark.gpu
+def test_example_networks_match_oracle_composition():
+    from oracle import oracle
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    dev = torch.device('cuda:0')
+    rng = np.random.RandomState(0)
+    x = rng.rand(6, 250, 4).astype(np.float32) * 0.8
+    np.random.seed(1)
+    qcnn = qcnn_amd.models.CNN(types.SimpleNamespace(model='QCNN'))
+    xt = torch.tensor(x, device=dev)
+    p = qcnn(xt)
+    L = qcnn.layers
+    g = lambda t: t.detach().cpu().numpy().astype(np.float64)
+    h = oracle.forward(x, g(L[0].kernel), g(L[0].bias), 1, padding='same', activation='relu')
+    h = _np_avgpool_same(h, 2)
+    h = oracle.forward(h, g(L[2].kernel), g(L[2].bias), 1, padding='same', activation='relu')
+    h = _np_avgpool_same(h, 4).reshape(6, -1)
+    h = oracle.forward(h, g(L[5].r), g(L[5].bias), 0, activation='relu')
+    z = h @ g(L[6].kernel) + g(L[6].bias)
+    want = np.exp(z - z.max(1, keepdims=True))
+    want /= want.sum(1, keepdims=True)
+    assert tuple(p.shape) == (6, 8)
+    assert np.abs(g(p) - want).max() <= 1e-4
+    np.random.seed(2)
+    qdnn = qcnn_amd.models.DNN(types.SimpleNamespace(model='QDNN'))
+    q = qdnn(xt)
+    h = x.reshape(6, -1)
+    for lyr in (qdnn.h0, qdnn.h1, qdnn.h2):
+        h = oracle.forward(h, g(lyr.r), g(lyr.bias), 0, activation='relu')
+    z = h @ g(qdnn.out.kernel) + g(qdnn.out.bias)
+    want = np.exp(z - z.max(1, keepdims=True))
+    want /= want.sum(1, keepdims=True)
+    assert np.abs(g(q) - want).max() <= 1e-4
+    q.sum().backward()                                    # gradients reach every quaternion kernel
+    assert all(l.r.grad is not None and torch.isfinite(l.r.grad).all() for l in (qdnn.h0, qdnn.h1, qdnn.h2))
+
+
+@pytest.mark.gpu
+def test_timit_qcnn_shapes_and_backward():
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    dev = torch.device('cuda:0')
+    np.random.seed(0)
+    d = types.SimpleNamespace(num_layers=4, start_filter=8, act='relu', aact='prelu', dropout=0.0, l2=1e-4,
+                              model='quaternion', quat_init='quaternion')
+    model, val = qcnn_amd.models.getTimitModel2D(d)
+    x = torch.randn(2, 4, 41, 20, device=dev)
+    pred = model(x)
+    assert tuple(pred.shape) == (2, 20, 62) and torch.allclose(pred.sum(-1), torch.ones(2, 20, device=dev), atol=1e-4)
+    assert tuple(model.conv.kernel.shape) == (3, 5, 1, 32) and tuple(model.convs[2].kernel.shape) == (3, 5, 8, 64)
+    assert tuple(model.dense[0].layer.r.shape) == (14 * 4 * 16 // 4, 256)
+    labels = torch.randint(0, 61, (2, 5), device=dev)
+    cost = model.ctc_loss(x, labels, torch.full((2, 1), 20, device=dev), torch.full((2, 1), 5, device=dev))
+    reg = sum(sum(m.regularization_losses()) for m in model.modules() if hasattr(m, 'regularization_losses'))
+    (cost.mean() + reg).backward()
+    assert torch.isfinite(model.conv.kernel.grad).all() and torch.isfinite(model.dense[2].layer.r.grad).all()
+    assert torch.equal(val(x), model(x))
