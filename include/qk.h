@@ -19,6 +19,8 @@
  *                         K.dot :149, bias/activation :159-162)
  *   qk_dense_bwd_data / qk_dense_bwd_weight       TF autodiff of dense.py:126-164
  *   qk_conv_bwd / qk_dense_bwd                    the same gradients in one fused call
+ *   qk_conv_fold_taps    (no reference counterpart) im2col-style fold that turns a few-channel conv into
+ *                        a 1x1 quaternion conv, so the first layer also runs on the MFMA kernels
  *   qk_adam_step         the Keras Adam update the reference trains with
  *                        (working_example.py:106, keras.optimizers.Adam defaults) applied to a
  *                        flat fp32 parameter buffer -- used by the data-parallel step.
@@ -133,6 +135,13 @@ int qk_conv_bwd_weight(const qk_conv_desc_t *desc, const void *x, const void *dy
  * one tensor instead of two.  dx must not be NULL.  Workspace: qk_*_workspace_bytes(desc, QK_OP_BWD). */
 int qk_conv_bwd(const qk_conv_desc_t *desc, const void *x, const void *dy, const void *y, const float *w,
                 void *dx, float *dw, float *dbias, void *workspace, size_t workspace_bytes, void *stream);
+
+/* Tap folding for layers with very few input channels (the first TIMIT layer has cq = 1: K = 4*taps).
+ *   xcol[m, a*cq2 + t*cq + c] = x[pos(m, t), a*cq + c]      (0 in the padding and for t*cq + c >= taps*cq)
+ * xcol is channels_last (N, *out_spatial, 4*cq2), cq2 a multiple of 8 with cq2 >= taps*cq.  The layer
+ * then IS a 1x1 quaternion convolution on xcol with the kernel reshaped to (taps*cq -> cq2, 4*fq): the
+ * Hamilton structure acts per channel, so it survives the fold.  HBM-bound gather. */
+int qk_conv_fold_taps(const qk_conv_desc_t *desc, const void *x, void *xcol, int32_t cq2, void *stream);
 
 /* Dense ---------------------------------------------------------------------------------
  * x [rows, 4*in_q], w [in_q, 4*q_units] float32, bias [4*q_units], y [rows, 4*q_units]

@@ -387,6 +387,30 @@ int qk_dense_bwd_weight(const qk_dense_desc_t *desc, const void *x, const void *
     return check_launch(conv_bwd_weight_impl(&c, x, dy, y, dw, dbias, dym, (hipStream_t)stream), "qk_dense_bwd_weight");
 }
 
+int qk_conv_fold_taps(const qk_conv_desc_t *desc, const void *x, void *xcol, int32_t cq2, void *stream)
+{
+    if (int rc = validate(desc, false)) return rc;
+    if (!x || !xcol) { set_error("x/xcol must not be NULL"); return QK_ERR_INVALID_ARG; }
+    if (cq2 % 8 != 0 || cq2 < taps_of(desc) * desc->cq) {
+        set_error("cq2 = %d must be a multiple of 8 and >= taps*cq = %d", cq2, taps_of(desc) * desc->cq);
+        return QK_ERR_INVALID_ARG;
+    }
+    GemmGeom g;
+    memset(&g, 0, sizeof(g));
+    const Strides xs = act_strides(desc->in_spatial, 4 * desc->cq, desc->layout);
+    g.batch = desc->batch;
+    g.M = desc->batch * desc->out_spatial[0] * desc->out_spatial[1] * desc->out_spatial[2];
+    g.Q = desc->cq; g.taps = taps_of(desc);
+    for (int i = 0; i < 3; ++i) {
+        g.osp[i] = desc->out_spatial[i]; g.isp[i] = desc->in_spatial[i]; g.ks[i] = desc->kernel[i];
+        g.pa[i] = desc->stride[i]; g.pb[i] = desc->dilation[i]; g.pc[i] = -desc->pad_lo[i]; g.pd[i] = 1;
+        g.in_ss[i] = xs.ss[i];
+    }
+    g.in_sn = xs.sn; g.in_sc = xs.sc;
+    if ((long long)g.M * 4 * cq2 > INT_MAX) { set_error("folded tensor has >= 2^31 elements"); return QK_ERR_UNSUPPORTED; }
+    return check_launch(launch_fold_taps(desc->dtype, x, xcol, g, cq2, (hipStream_t)stream), "qk_conv_fold_taps");
+}
+
 int qk_adam_step(float *param, const float *grad, float *m, float *v, size_t n, float lr, float beta1,
                  float beta2, float eps, int32_t step, float grad_scale, void *stream)
 {

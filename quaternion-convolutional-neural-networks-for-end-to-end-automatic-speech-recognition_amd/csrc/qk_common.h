@@ -133,6 +133,7 @@ int launch_wgrad(int dtype, const void *x, const void *dy, const void *ymask, fl
                  float *dbias, WgradGeom g, bool vec_ok, hipStream_t stream);
 // aux: dst[t][f][p][c] = src[t][c][p][f]
 int launch_transpose_w(const float *src, float *dst, int taps, int Cq, int F, hipStream_t stream);
+int launch_fold_taps(int dtype, const void *x, void *xcol, const GemmGeom &g, int cq2, hipStream_t stream);
 int launch_adam(float *p, const float *g, float *m, float *v, size_t n, float lr, float b1,
                 float b2, float eps, int step, float gscale, hipStream_t stream);
 

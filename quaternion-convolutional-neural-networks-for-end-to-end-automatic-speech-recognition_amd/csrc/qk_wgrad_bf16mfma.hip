@@ -60,7 +60,7 @@ __device__ __forceinline__ unsigned relu_keep2(unsigned v, unsigned m)
 }
 
 template <typename T, int WR, int WC, int TN, bool MASK>
-__global__ void __launch_bounds__(WR * WC * 64) __attribute__((amdgpu_waves_per_eu(WR * WC / 4, WR * WC / 4)))
+__global__ void __launch_bounds__(WR * WC * 64) __attribute__((amdgpu_waves_per_eu(WR * WC / 4, 2)))
 k_wgrad16(const T *__restrict__ x, const T *__restrict__ dy, const T *__restrict__ ymask,
           float *__restrict__ dw, float *__restrict__ dbias, const WgradGeom g)
 {

@@ -10,6 +10,7 @@ current HIP stream and chains the backward calls.  There is NO CPU or eager fall
 a CPU tensor or a missing libqk_hip.so raises.
 """
 import ctypes
+import math
 
 import torch
 
@@ -209,7 +210,8 @@ def dense_call(x_shape, w_shape, dtype, activation=None, use_bias=True):
 
 
 def quaternion_conv(x, kernel, bias=None, strides=1, padding='valid', data_format='channels_last',
-                    dilation_rate=1, activation=None, conj=False, internal_layout='channels_last'):
+                    dilation_rate=1, activation=None, conj=False, internal_layout='channels_last',
+                    fold_small_cq=True):
     """y = act(W (x) x + b): Hamilton-product convolution of rank kernel.dim()-2.
 
     x       (N, *spatial, 4Cq) or (N, 4Cq, *spatial) -- component-planar channels (r|i|j|k)
@@ -218,11 +220,17 @@ def quaternion_conv(x, kernel, bias=None, strides=1, padding='valid', data_forma
     kept PHYSICALLY channels-last (a strided view with the logical channels_first shape is
     returned, torch.channels_last style): MFMA operands want the reduction axis contiguous.
     internal_layout='native' runs the channels_first buffers as they are.
+    fold_small_cq: layers with 1-2 quaternion input channels whose input needs no gradient (the first
+    layer of a network) are run as a 1x1 convolution on a tap-folded copy of x (qk_conv_fold_taps).
     """
     _require_device(x, 'quaternion_conv')
     rank = kernel.dim() - 2
     _check_weights(kernel, bias, kernel.shape[-1])
     ch_first = data_format == 'channels_first'
+    taps, cq = int(math.prod(kernel.shape[:rank])), kernel.shape[-2]
+    if fold_small_cq and cq <= 2 and taps > 1 and taps * cq <= 64 and not x.requires_grad and not conj:
+        return _folded_conv(x, kernel, bias, rank, strides, padding, data_format, dilation_rate, activation,
+                            internal_layout)
     if ch_first and internal_layout == 'channels_last':
         xp = x.movedim(1, -1).contiguous()
         layout = 'channels_last'
@@ -235,6 +243,25 @@ def quaternion_conv(x, kernel, bias=None, strides=1, padding='valid', data_forma
     if ch_first and internal_layout == 'channels_last':
         y = y.movedim(-1, 1)
     return y
+
+
+def _folded_conv(x, kernel, bias, rank, strides, padding, data_format, dilation_rate, activation, internal_layout):
+    ch_first = data_format == 'channels_first'
+    xp = x.contiguous()
+    taps, cq = int(math.prod(kernel.shape[:rank])), kernel.shape[-2]
+    cq2 = 32 if x.dtype != torch.float32 else (taps * cq + 7) // 8 * 8     # 16-bit MFMA path wants cq2 % 32 == 0
+    call = conv_call(tuple(xp.shape), tuple(kernel.shape), xp.dtype, rank, strides, padding, data_format,
+                     dilation_rate, None, False, False)
+    d = call.desc
+    out_sp = tuple(d.out_spatial[i] for i in range(rank))
+    xcol = torch.empty((xp.shape[0],) + out_sp + (4 * cq2,), dtype=xp.dtype, device=xp.device)
+    with torch.cuda.device(xp.device):
+        rc = L.lib().qk_conv_fold_taps(ctypes.byref(d), _ptr(xp), _ptr(xcol), cq2, _stream(xp))
+    L.check(rc, 'qk_conv_fold_taps')
+    w2 = torch.nn.functional.pad(kernel.reshape(taps * cq, kernel.shape[-1]), (0, 0, 0, cq2 - taps * cq))
+    w2 = w2.reshape((1,) * rank + (cq2, kernel.shape[-1]))
+    y = quaternion_conv(xcol, w2, bias, 1, 'valid', 'channels_last', 1, activation, False, 'channels_last', False)
+    return y.movedim(-1, 1) if ch_first else y
 
 
 def quaternion_dense(x, kernel, bias=None, activation=None):

@@ -159,6 +159,37 @@ def test_half_matches_oracle_on_rounded_inputs(case, dtype):
         assert err <= tol, '%s: rel err %.3g > %.1g' % (k, err, tol)
 
 
+@pytest.mark.parametrize('dtype,tol', [(torch.float32, 1e-4), (torch.bfloat16, 1e-2)], ids=['fp32', 'bf16'])
+@pytest.mark.parametrize('fmt', ['channels_first', 'channels_last'])
+def test_first_layer_tap_folding_matches_oracle(dtype, tol, fmt):
+    """Cq = 1 layers whose input needs no gradient run as a 1x1 conv on the tap-folded input
+    (qk_conv_fold_taps); results must equal the oracle's plain convolution."""
+    import qcnn_amd
+    from oracle import oracle
+    F = qcnn_amd.functional
+    dev = _dev()
+    rng = np.random.RandomState(5)
+    xs = (3, 4, 41, 23) if fmt == 'channels_first' else (3, 41, 23, 4)
+    x = torch.tensor(rng.randn(*xs).astype(np.float32)).to(dtype).float().numpy()
+    w = torch.tensor((rng.randn(3, 5, 1, 64) / 8).astype(np.float32)).to(dtype).float().numpy()
+    b = (0.1 * rng.randn(64)).astype(np.float32)
+    kw = dict(padding='same', activation='relu', data_format=fmt)
+    y = oracle.forward(x, w, b, 2, **kw)
+    dy = torch.tensor(rng.randn(*y.shape).astype(np.float32)).to(dtype).float().numpy()
+    _, dw, db = oracle.backward(x, w, b, dy, 2, y=y, **kw)
+    xt = torch.tensor(x, device=dev).to(dtype)                      # no requires_grad -> folded path
+    wt = torch.tensor(w, device=dev, requires_grad=True)
+    bt = torch.tensor(b, device=dev, requires_grad=True)
+    yt = F.quaternion_conv(xt, wt, bt, **kw)
+    yt.backward(torch.tensor(dy, device=dev).to(dtype))
+    assert tuple(yt.shape) == y.shape
+    assert _rel_err(yt.detach().float().cpu().numpy(), y) <= tol
+    assert _rel_err(wt.grad.cpu().numpy(), dw) <= max(tol / 5, 1e-4)
+    assert _rel_err(bt.grad.cpu().numpy(), db) <= max(tol / 5, 1e-4)
+    y_plain = F.quaternion_conv(xt, wt, bt, fold_small_cq=False, **kw)   # the unfolded kernels agree
+    assert _rel_err(y_plain.detach().float().cpu().numpy(), yt.detach().float().cpu().numpy()) <= tol
+
+
 def test_cpu_tensor_raises_no_fallback():
     import qcnn_amd
     x = torch.randn(2, 10, 8)
