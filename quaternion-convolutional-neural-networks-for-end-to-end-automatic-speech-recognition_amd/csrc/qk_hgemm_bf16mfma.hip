@@ -44,12 +44,15 @@ __device__ __forceinline__ uint4 neg8(const uint4 &v)
     return make_uint4(v.x ^ 0x80008000u, v.y ^ 0x80008000u, v.z ^ 0x80008000u, v.w ^ 0x80008000u);
 }
 
-// zero the 16-bit lanes whose mask value is <= 0 (sign bit set, or +-0)
+// zero the 16-bit halves whose mask half is <= 0 (as a signed integer == as a bf16/fp16 value):
+// v_pk_max_i16, v_pk_min_u16, v_pk_mul_lo_u16, v_and
+typedef short s2v __attribute__((ext_vector_type(2)));
+typedef unsigned short u2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned mask2(unsigned v, unsigned m)
 {
-    const unsigned lo = ((m & 0x8000u) || !(m & 0x7fffu)) ? 0u : 0xffffu;
-    const unsigned hi = ((m & 0x80000000u) || !(m & 0x7fff0000u)) ? 0u : 0xffff0000u;
-    return v & (lo | hi);
+    const s2v pos = __builtin_elementwise_max(__builtin_bit_cast(s2v, m), (s2v)(0));
+    const u2v one = __builtin_elementwise_min(__builtin_bit_cast(u2v, pos), (u2v)(1));
+    return v & __builtin_bit_cast(unsigned, (u2v)(one * (u2v)(0xffff)));
 }
 __device__ __forceinline__ uint4 mask8(const uint4 &v, const uint4 &m)
 {

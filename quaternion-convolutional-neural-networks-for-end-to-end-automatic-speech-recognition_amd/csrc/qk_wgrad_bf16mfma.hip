@@ -52,11 +52,15 @@ __device__ __forceinline__ uint4 keep_if(bool ok, const uint4 &v)
     return make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u);
 }
 
+// keep the 16-bit halves of v whose mask half is > 0 as a signed integer (== as a bf16/fp16 value,
+// NaNs aside): 4 packed VALU ops -- v_pk_max_i16, v_pk_min_u16, v_pk_mul_lo_u16, v_and
+typedef short s2v __attribute__((ext_vector_type(2)));
+typedef unsigned short u2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned relu_keep2(unsigned v, unsigned m)
 {
-    const unsigned lo = ((m & 0x8000u) || !(m & 0x7fffu)) ? 0u : 0xffffu;
-    const unsigned hi = ((m & 0x80000000u) || !(m & 0x7fff0000u)) ? 0u : 0xffff0000u;
-    return v & (lo | hi);
+    const s2v pos = __builtin_elementwise_max(__builtin_bit_cast(s2v, m), (s2v)(0));
+    const u2v one = __builtin_elementwise_min(__builtin_bit_cast(u2v, pos), (u2v)(1));
+    return v & __builtin_bit_cast(unsigned, (u2v)(one * (u2v)(0xffff)));
 }
 
 template <typename T, int WR, int WC, int TN, bool MASK>
@@ -100,6 +104,15 @@ k_wgrad16(const T *__restrict__ x, const T *__restrict__ dy, const T *__restrict
     const int s_row = tid / TPROW, s_sub = tid % TPROW;
     uint4 xr[UX], dr[UD], mr[MASK ? UD : 1];
     bool x_ok = false, d_ok = false;
+    // position of this thread's row, advanced by KM rows per load_tile call (no divisions in the loop)
+    int r_n, r_o0, r_o1, r_o2;
+    {
+        int s = m_begin + s_row;
+        r_o2 = s % g.osp[2]; s /= g.osp[2];
+        r_o1 = s % g.osp[1]; s /= g.osp[1];
+        r_o0 = s % g.osp[0];
+        r_n = s / g.osp[0];
+    }
     int d_e0 = 0;                                            // dY element offset of this thread's row
     const bool write_dym = MASK && g.dym != nullptr && t == 0 && cchunk == 0;
     T *dym = static_cast<T *>(g.dym);
@@ -110,16 +123,26 @@ k_wgrad16(const T *__restrict__ x, const T *__restrict__ dy, const T *__restrict
         x_ok = false;
         int xo = 0;
         if (d_ok) {
-            int s = m;
-            const int o2 = s % g.osp[2]; s /= g.osp[2];
-            const int o1 = s % g.osp[1]; s /= g.osp[1];
-            const int o0 = s % g.osp[0];
-            const int n = s / g.osp[0];
-            const int i0 = o0 * g.pa[0] + t0 * g.pb[0] + g.pc[0];
-            const int i1 = o1 * g.pa[1] + t1 * g.pb[1] + g.pc[1];
-            const int i2 = o2 * g.pa[2] + t2 * g.pb[2] + g.pc[2];
+            const int i0 = r_o0 * g.pa[0] + t0 * g.pb[0] + g.pc[0];
+            const int i1 = r_o1 * g.pa[1] + t1 * g.pb[1] + g.pc[1];
+            const int i2 = r_o2 * g.pa[2] + t2 * g.pb[2] + g.pc[2];
             x_ok = i0 >= 0 && i0 < g.isp[0] && i1 >= 0 && i1 < g.isp[1] && i2 >= 0 && i2 < g.isp[2];
-            if (x_ok) xo = n * (int)g.x_sn + i0 * (int)g.x_ss[0] + i1 * (int)g.x_ss[1] + i2 * (int)g.x_ss[2];
+            if (x_ok) xo = r_n * (int)g.x_sn + i0 * (int)g.x_ss[0] + i1 * (int)g.x_ss[1] + i2 * (int)g.x_ss[2];
+        }
+        // next call: KM rows further.  Carry-propagate when the innermost extent is long (images);
+        // re-decode with divisions when it is short (dense layers, 1-D convolutions: osp[2] == 1)
+        if (g.osp[2] >= KM) {
+            r_o2 += KM;
+            if (r_o2 >= g.osp[2]) {
+                r_o2 -= g.osp[2];
+                if (++r_o1 == g.osp[1]) { r_o1 = 0; if (++r_o0 == g.osp[0]) { r_o0 = 0; ++r_n; } }
+            }
+        } else {
+            int s = m + KM;
+            r_o2 = s % g.osp[2]; s /= g.osp[2];
+            r_o1 = s % g.osp[1]; s /= g.osp[1];
+            r_o0 = s % g.osp[0];
+            r_n = s / g.osp[0];
         }
         const int yo = d_ok ? m * (int)g.dy_ss : 0;
         d_e0 = yo;
@@ -282,7 +305,8 @@ int go_wgrad16(const void *x, const void *dy, const void *ymask, float *dw, floa
         if (g.F % 64 == 0) return run_wgrad16<T, 4, 2, 4>(xp, dp, yp, dw, dbias, g, stream);
         return run_wgrad16<T, 4, 2, 2>(xp, dp, yp, dw, dbias, g, stream);
     }
-    if (g.F % 64 == 0) return run_wgrad16<T, 2, 2, 4>(xp, dp, yp, dw, dbias, g, stream);
+    // 32-channel chunks: 8 waves of 64 x 64 (two per SIMD) rather than 4 waves of 64 x 128
+    if (g.F % 64 == 0) return run_wgrad16<T, 2, 4, 2>(xp, dp, yp, dw, dbias, g, stream);
     return run_wgrad16<T, 2, 2, 2>(xp, dp, yp, dw, dbias, g, stream);
 }
 
