@@ -306,6 +306,8 @@ def main():
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
     ap.add_argument('--graph-multi', action='store_true',
                     help='also use hipGraph segments around the RCCL all-reduce when N > 1 (default: eager for N > 1)')
+    ap.add_argument('--no-hamilton-gemm', action='store_true',
+                    help='skip the extra kernel timing of the batch-256 bf16 Hamilton GEMM (config-3 body conv)')
     ap.add_argument('--activation', default='relu', choices=['relu', 'linear'], help='diagnostic: linear drops the relu mask')
     args = ap.parse_args()
 
@@ -386,6 +388,27 @@ def main():
         out['kernels'] = kernels
         step_flops = 3 * job.flops_per_kernel
         out['step_tflops'] = step_flops / (ms_per_step * 1e-3) / 1e12
+    # The "% of MFMA peak on the Hamilton GEMM at batch 256" half of BASELINE.json's metric: the
+    # config-3 stage-2 body conv (M=716800, N=256, K=3840, bf16), kernels timed with HIP events.
+    if rank == 0 and world == 1 and not is_model and not args.no_hamilton_gemm and not args.no_kernel_timing \
+            and args.workload == 'cfg2_qconv1d_timit_b64_fp32':
+        try:
+            hcfg = dict(WORKLOADS['cfg3_body_qconv2d_b256_bf16'], activation='relu')
+            hjob = LayerTrainStep(hcfg, dev, 0, 1)
+            hjob.k_fwd(); hjob.k_bwd_weight(); hjob.k_bwd_data()
+            torch.cuda.synchronize()
+            stream = torch.cuda.current_stream(dev)
+            hk = {}
+            for name, fn in (('fwd', hjob.k_fwd), ('bwd_weight', hjob.k_bwd_weight), ('bwd_data', hjob.k_bwd_data)):
+                ms = event_time_ms(fn, stream, reps=5, rounds=3)
+                tf = hjob.flops_per_kernel / (ms * 1e-3) / 1e12
+                hk[name] = {'ms': ms, 'tflops': tf, 'frac_of_peak': tf / PEAK_TFLOPS['bf16'],
+                            'hbm_bytes': pmc_traffic('cfg3_body_qconv2d_b256_bf16', name)}
+            out['hamilton_gemm'] = {'workload': 'cfg3_body_qconv2d_b256_bf16', 'gemm_view': hjob.gemm, 'dtype': 'bf16',
+                                    'peak_tflops': PEAK_TFLOPS['bf16'], 'kernels': hk}
+            del hjob
+        except Exception as e:
+            out['hamilton_gemm'] = {'error': str(e)}
     if world > 1:
         dist.barrier()
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not is_model:

@@ -5,9 +5,10 @@
 // transpose reads.)
 //
 // Hamilton structure in REGISTERS: per 16-deep MFMA step a wave loads the 4 gathered-component
-// A fragments (r,i,j,k of the same rows/channels) and the 4 compact-part B fragments once, builds
-// the three negated parts with 12 v_xor (sign bit of both packed halves), and issues the 16 MFMAs
-// of the 4x4 block table:  acc[b] += A[a] * (+-B[a ^ b]).  Every fragment feeds 4 MFMAs; the
+// A fragments (r,i,j,k of the same rows/channels) and the 4 compact-part B fragments once and
+// issues the 16 MFMAs of the 4x4 block table: acc[b] += A[a] * B[a ^ b] for the ten positive
+// entries, accn[b] += ... for the six negative ones (y = acc - accn in the epilogue: no sign
+// manipulation in the loop at all).  Every fragment feeds 4 MFMAs; the
 // 4x-expanded weight (conv.py:327-331) exists nowhere -- HBM and LDS hold the compact kernel only.
 //
 // Workgroup = 8 waves (two per SIMD, so one wave's ds_read latency hides under the other's
@@ -37,11 +38,6 @@ __device__ __forceinline__ floatx16 mfma16(bf16, const uint4 &a, const uint4 &b,
 __device__ __forceinline__ floatx16 mfma16(f16, const uint4 &a, const uint4 &b, const floatx16 &c)
 {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-}
-
-__device__ __forceinline__ uint4 neg8(const uint4 &v)
-{
-    return make_uint4(v.x ^ 0x80008000u, v.y ^ 0x80008000u, v.z ^ 0x80008000u, v.w ^ 0x80008000u);
 }
 
 // zero the 16-bit halves whose mask half is <= 0 (as a signed integer == as a bf16/fp16 value):
@@ -202,11 +198,11 @@ k_hgemm16(const T *__restrict__ in, const T *__restrict__ mask, const uint4 *__r
         if constexpr (BU == 2) Bs[tid + 512] = br1;
     };
 
-    floatx16 acc[4];
+    floatx16 acc[4], accn[4];
 #pragma unroll
     for (int b = 0; b < 4; ++b)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+        for (int r = 0; r < 16; ++r) { acc[b][r] = 0.f; accn[b][r] = 0.f; }
 
     const int frow = wm * 32 + lr;                  // A-tile row this lane reads
     const int fsw = frow & 15;
@@ -229,20 +225,20 @@ k_hgemm16(const T *__restrict__ in, const T *__restrict__ mask, const uint4 *__r
         const uint4 *b_rd = lds + (it & 1) * TILE_U + b_rd0;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            uint4 A[4], B[4], Bn[4];
+            uint4 A[4], B[4];
 #pragma unroll
             for (int a = 0; a < 4; ++a) A[a] = a_rd[(a * 4 + ks * 2 + lh) ^ fsw];
 #pragma unroll
             for (int p = 0; p < 4; ++p) B[p] = b_rd[((ks * 2 + lh) * 4 + p) * BF];
-#pragma unroll
-            for (int p = 1; p < 4; ++p) Bn[p] = neg8(B[p]);
+            // products that enter with a minus sign go to a second accumulator set: no sign-flip VALU in
+            // the loop (12 v_xor per step otherwise; +4 % measured), acc -= accn once in the epilogue
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
                     constexpr unsigned tbl = TBL;
-                    const bool ng = (tbl >> (a * 4 + b)) & 1u;
-                    acc[b] = mfma16(T(), A[a], ng ? Bn[a ^ b] : B[a ^ b], acc[b]);
+                    if ((tbl >> (a * 4 + b)) & 1u) accn[b] = mfma16(T(), A[a], B[a ^ b], accn[b]);
+                    else acc[b] = mfma16(T(), A[a], B[a ^ b], acc[b]);
                 }
         }
         __syncthreads();
@@ -257,7 +253,7 @@ k_hgemm16(const T *__restrict__ in, const T *__restrict__ mask, const uint4 *__r
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + wm * 32 + mfma32_row(r, lane);
             if (m >= g.M) continue;
-            float v = acc[b][r] + bia;
+            float v = acc[b][r] - accn[b][r] + bia;
             if (g.relu) v = v > 0.f ? v : 0.f;
             out[(long long)m * (int)g.out_ss + ch] = from_f32<T>(v);
         }
