@@ -84,14 +84,15 @@ k_prep_w16(const float *__restrict__ w, T *__restrict__ wq, int taps, int Cq, in
 }
 
 // ---------------------------------------------------------------------------------------
-template <typename T, int WM, int WN, bool CONJ, bool MASK>
+template <typename T, int MT, int WM, int WN, bool CONJ, bool MASK>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))   // 256-register budget
 k_hgemm16(const T *__restrict__ in, const T *__restrict__ mask, const uint4 *__restrict__ wq,
           const T *__restrict__ zero_line, const float *__restrict__ bias, T *__restrict__ out, const GemmGeom g)
 {
     static_assert(WM * WN == 8, "8 waves per workgroup");
-    constexpr int BM = WM * 32;
+    constexpr int BM = WM * MT * 32;               // MT row tiles of 32 per wave
     constexpr int BF = WN * 32;
+    constexpr bool SPLIT = MT == 1;                 // second accumulator set for the negative entries
     constexpr int BU = (16 * BF) / 512;             // 16-byte units of the B tile per thread
     static_assert(BM % 64 == 0 && (16 * BF) % 512 == 0, "tile/threads");
     constexpr unsigned TBL = CONJ ? kSignConj : kSignConv;
@@ -198,13 +199,15 @@ k_hgemm16(const T *__restrict__ in, const T *__restrict__ mask, const uint4 *__r
         if constexpr (BU == 2) Bs[tid + 512] = br1;
     };
 
-    floatx16 acc[4], accn[4];
+    floatx16 acc[MT][4], accn[SPLIT ? 4 : 1];
 #pragma unroll
-    for (int b = 0; b < 4; ++b)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { acc[b][r] = 0.f; accn[b][r] = 0.f; }
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[mt][b][r] = 0.f; if (SPLIT) accn[b][r] = 0.f; }
 
-    const int frow = wm * 32 + lr;                  // A-tile row this lane reads
+    const int frow = wm * MT * 32 + lr;             // A-tile row this lane reads (+ 32*mt)
     const int fsw = frow & 15;
     const int a_rd0 = frow * 16;
     const int b_rd0 = BM * 16 + wn * 32 + lr;
@@ -225,21 +228,41 @@ k_hgemm16(const T *__restrict__ in, const T *__restrict__ mask, const uint4 *__r
         const uint4 *b_rd = lds + (it & 1) * TILE_U + b_rd0;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            uint4 A[4], B[4];
+            uint4 A[MT][4], B[4];
 #pragma unroll
-            for (int a = 0; a < 4; ++a) A[a] = a_rd[(a * 4 + ks * 2 + lh) ^ fsw];
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int a = 0; a < 4; ++a) A[mt][a] = a_rd[mt * 32 * 16 + ((a * 4 + ks * 2 + lh) ^ fsw)];
 #pragma unroll
             for (int p = 0; p < 4; ++p) B[p] = b_rd[((ks * 2 + lh) * 4 + p) * BF];
-            // products that enter with a minus sign go to a second accumulator set: no sign-flip VALU in
-            // the loop (12 v_xor per step otherwise; +4 % measured), acc -= accn once in the epilogue
+            if constexpr (SPLIT) {
+                // products that enter with a minus sign go to a second accumulator set: no sign-flip
+                // VALU in the loop (12 v_xor per step otherwise; +4 % measured), acc -= accn at the end
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
+                for (int a = 0; a < 4; ++a)
 #pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    constexpr unsigned tbl = TBL;
-                    if ((tbl >> (a * 4 + b)) & 1u) accn[b] = mfma16(T(), A[a], B[a ^ b], accn[b]);
-                    else acc[b] = mfma16(T(), A[a], B[a ^ b], acc[b]);
-                }
+                    for (int b = 0; b < 4; ++b) {
+                        constexpr unsigned tbl = TBL;
+                        if ((tbl >> (a * 4 + b)) & 1u) accn[b] = mfma16(T(), A[0][a], B[a ^ b], accn[b]);
+                        else acc[0][b] = mfma16(T(), A[0][a], B[a ^ b], acc[0][b]);
+                    }
+            } else {
+                // taller wave tile: the three negated parts (12 v_xor) are shared by MT row tiles
+                uint4 Bn[4];
+#pragma unroll
+                for (int p = 1; p < 4; ++p)
+                    Bn[p] = make_uint4(B[p].x ^ 0x80008000u, B[p].y ^ 0x80008000u, B[p].z ^ 0x80008000u, B[p].w ^ 0x80008000u);
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        constexpr unsigned tbl = TBL;
+                        const bool ng = (tbl >> (a * 4 + b)) & 1u;
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+                            acc[mt][b] = mfma16(T(), A[mt][a], ng ? Bn[a ^ b] : B[a ^ b], acc[mt][b]);
+                    }
+            }
         }
         __syncthreads();
     }
@@ -250,26 +273,30 @@ k_hgemm16(const T *__restrict__ in, const T *__restrict__ mask, const uint4 *__r
         const int ch = b * g.J + j0 + wn * 32 + lr;
         const float bia = g.has_bias ? bias[ch] : 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = m0 + wm * 32 + mfma32_row(r, lane);
-            if (m >= g.M) continue;
-            float v = acc[b][r] - accn[b][r] + bia;
-            if (g.relu) v = v > 0.f ? v : 0.f;
-            out[(long long)m * (int)g.out_ss + ch] = from_f32<T>(v);
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + (wm * MT + mt) * 32 + mfma32_row(r, lane);
+                if (m >= g.M) continue;
+                float v = acc[mt][b][r] + bia;
+                if constexpr (SPLIT) v -= accn[b][r];
+                if (g.relu) v = v > 0.f ? v : 0.f;
+                out[(long long)m * (int)g.out_ss + ch] = from_f32<T>(v);
+            }
         }
     }
 }
 
-template <typename T, int WM, int WN>
+template <typename T, int MT, int WM, int WN>
 int run16(const T *in, const T *mask, const uint4 *wq, const T *zero_line, const float *bias, T *out,
           const GemmGeom &g, hipStream_t stream)
 {
-    constexpr int BM = WM * 32, BF = WN * 32;
+    constexpr int BM = WM * MT * 32, BF = WN * 32;
     const int n_mt = (g.M + BM - 1) / BM;
     dim3 grid((n_mt + 7) / 8 * 8, g.J / BF, 1);       // padded to the 8 XCDs (see the tile remap)
     const bool conj = g.sign_tbl == kSignConj;
     const bool m = g.has_mask != 0;
-#define QK_GO(C, K) hipLaunchKernelGGL((k_hgemm16<T, WM, WN, C, K>), grid, dim3(512), 0, stream, in, mask, wq, zero_line, bias, out, g)
+#define QK_GO(C, K) hipLaunchKernelGGL((k_hgemm16<T, MT, WM, WN, C, K>), grid, dim3(512), 0, stream, in, mask, wq, zero_line, bias, out, g)
     if (conj) { if (m) QK_GO(true, true); else QK_GO(true, false); }
     else      { if (m) QK_GO(false, true); else QK_GO(false, false); }
 #undef QK_GO
@@ -289,9 +316,12 @@ int go16(const void *in, const void *mask, const float *w, const float *bias, vo
     if (hipGetLastError() != hipSuccess) return QK_ERR_LAUNCH;
     const uint4 *wq4 = reinterpret_cast<const uint4 *>(wq);
     const T *zero_line = wq + total;                 // 256 zeroed bytes behind the re-laid-out kernel
-    if (g.J % 64 == 0)
-        return run16<T, 4, 2>((const T *)in, (const T *)mask, wq4, zero_line, bias, (T *)out, g, stream);
-    return run16<T, 8, 1>((const T *)in, (const T *)mask, wq4, zero_line, bias, (T *)out, g, stream);
+    const bool tall = getenv("QK_TALL16") != nullptr;     // tuning aid: 256-row tiles (MT = 2)
+    if (g.J % 64 == 0) {
+        if (tall && !g.has_mask) return run16<T, 2, 4, 2>((const T *)in, (const T *)mask, wq4, zero_line, bias, (T *)out, g, stream);
+        return run16<T, 1, 4, 2>((const T *)in, (const T *)mask, wq4, zero_line, bias, (T *)out, g, stream);
+    }
+    return run16<T, 1, 8, 1>((const T *)in, (const T *)mask, wq4, zero_line, bias, (T *)out, g, stream);
 }
 
 }  // namespace
