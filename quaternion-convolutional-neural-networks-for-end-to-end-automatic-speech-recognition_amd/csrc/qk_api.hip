@@ -243,9 +243,16 @@ int conv_bwd_weight_impl(const qk_conv_desc_t *d, const void *x, const void *dy,
     g.has_mask = mask ? 1 : 0;
     g.want_dbias = (d->has_bias && dbias) ? 1 : 0;
     g.dym = mask ? dy_masked_out : nullptr;
-    if (hipMemsetAsync(dw, 0, w_floats(d) * sizeof(float), stream) != hipSuccess) { set_error("memset dw failed"); return QK_ERR_LAUNCH; }
-    if (g.want_dbias && hipMemsetAsync(dbias, 0, 4 * (size_t)d->fq * sizeof(float), stream) != hipSuccess) {
-        set_error("memset dbias failed"); return QK_ERR_LAUNCH;
+    // dw / dbias are accumulated atomically: zero them first (one fill when they are adjacent, as in
+    // a flat gradient buffer)
+    const size_t dwb = w_floats(d) * sizeof(float), dbb = 4 * (size_t)d->fq * sizeof(float);
+    const char *dw_end = reinterpret_cast<const char *>(dw) + dwb;
+    const char *db_c = reinterpret_cast<const char *>(dbias);
+    if (g.want_dbias && db_c >= dw_end && db_c - dw_end <= 256) {
+        if (hipMemsetAsync(dw, 0, (size_t)(db_c - reinterpret_cast<const char *>(dw)) + dbb, stream) != hipSuccess) { set_error("memset dw failed"); return QK_ERR_LAUNCH; }
+    } else {
+        if (hipMemsetAsync(dw, 0, dwb, stream) != hipSuccess) { set_error("memset dw failed"); return QK_ERR_LAUNCH; }
+        if (g.want_dbias && hipMemsetAsync(dbias, 0, dbb, stream) != hipSuccess) { set_error("memset dbias failed"); return QK_ERR_LAUNCH; }
     }
     if (d->dtype != QK_F32) {
         const int r = try_wgrad_16(d->dtype, x, dy, mask ? y : nullptr, dw, dbias, g, stream);

@@ -67,7 +67,8 @@ struct WgradGeom {
     unsigned sign_tbl;
     int has_mask;
     int want_dbias;
-    int m_per_split;    // rows of M each blockIdx.x reduces (multiple of the kernel's K step)
+    int m_per_split;    // rows of M each split reduces (multiple of the kernel's K step)
+    int n_splits;
     int ablate;         // profiling only (env QK_ABLATE): 1 = skip fold + atomics, 2 = skip HBM atomics
     void *dym;          // optional output: dy with the relu mask applied (same layout/dtype as dy), or NULL;
                         // written by the blocks of tap 0 / channel chunk 0, which see every (row, filter) once

@@ -83,16 +83,27 @@ k_wgrad16(const T *__restrict__ x, const T *__restrict__ dy, const T *__restrict
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave / WC, wc = wave % WC;
+    // XCD-aware order (workgroup b runs on XCD b % 8, speed only): the (tap, channel-chunk) blocks of
+    // one split of M sit next to each other on one XCD, so the dY / X rows they all read are served
+    // by that XCD's L2 (without this the 30 blocks of a split re-fetch them from HBM: 7x over-fetch).
     const int nfc = g.F / BF;
-    const int cchunk = blockIdx.y / nfc;
-    const int fchunk = blockIdx.y - cchunk * nfc;
+    const int n_inner = g.taps * (g.Cq / BC) * nfc;
+    const int n_tiles = n_inner * g.n_splits;
+    const int per_xcd = (n_tiles + 7) / 8;
+    const int tile = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+    if (tile >= n_tiles) return;
+    const int split = tile / n_inner;
+    const int inner = tile - split * n_inner;
+    const int t = inner % g.taps;
+    const int chunk = inner / g.taps;
+    const int cchunk = chunk / nfc;
+    const int fchunk = chunk - cchunk * nfc;
     const int c0 = cchunk * BC, f0 = fchunk * BF;
-    const int t = blockIdx.z;
     const int t2 = t % g.ks[2];
     const int tt = t / g.ks[2];
     const int t1 = tt % g.ks[1];
     const int t0 = tt / g.ks[1];
-    const int m_begin = blockIdx.x * g.m_per_split;
+    const int m_begin = split * g.m_per_split;
     const int m_end = min(g.M, m_begin + g.m_per_split);
     const bool do_bias = g.want_dbias && t == 0 && cchunk == 0;
 
@@ -287,8 +298,10 @@ int run_wgrad16(const T *x, const T *dy, const T *ymask, float *dw, float *dbias
     mps = (mps + KM - 1) / KM * KM;
     splits = (g.M + mps - 1) / mps;
     g.m_per_split = (int)mps;
+    g.n_splits = (int)splits;
     g.ablate = 0;
-    dim3 grid((unsigned)splits, (unsigned)(ncc * nfc), (unsigned)g.taps);
+    const long long n_tiles = splits * other;
+    dim3 grid((unsigned)((n_tiles + 7) / 8 * 8), 1, 1);      // padded to the 8 XCDs (see the tile remap)
     if (g.has_mask)
         hipLaunchKernelGGL((k_wgrad16<T, WR, WC, TN, true>), grid, dim3(WR * WC * 64), 0, stream, x, dy, ymask, dw, dbias, g);
     else
