@@ -194,6 +194,8 @@ class LayerTrainStep(object):
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         if self.world == 1:
+            # (forking bwd-weight / bwd-data onto two streams inside the graph was measured SLOWER:
+            #  0.205 vs 0.153 ms per step -- the kernels already fill the CUs, they only contend.)
             self.g_all = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g_all):
                 self.k_fwd(); self.k_bwd_weight(); self.k_bwd_data(); self._adam()
@@ -303,9 +305,12 @@ def main():
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
-    ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
+    ap.add_argument('--graph', action='store_true',
+                    help='replay the step as a hipGraph (measured 3 %% SLOWER than eager back-to-back launches here: '
+                         '0.159 vs 0.154 ms -- the GPU is never starved and a replay has a fixed cost)')
+    ap.add_argument('--no-graph', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--graph-multi', action='store_true',
-                    help='also use hipGraph segments around the RCCL all-reduce when N > 1 (default: eager for N > 1)')
+                    help='with --graph and N > 1: hipGraph segments around the RCCL all-reduce')
     ap.add_argument('--no-hamilton-gemm', action='store_true',
                     help='skip the extra kernel timing of the batch-256 bf16 Hamilton GEMM (config-3 body conv)')
     ap.add_argument('--activation', default='relu', choices=['relu', 'linear'], help='diagnostic: linear drops the relu mask')
@@ -331,7 +336,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    use_graph = not args.no_graph and (world == 1 or args.graph_multi) and not is_model
+    use_graph = args.graph and not args.no_graph and (world == 1 or args.graph_multi) and not is_model
     if use_graph:
         try:
             job.step()
