@@ -133,12 +133,11 @@ size_t dy_bytes(const qk_conv_desc_t *d)
 
 size_t ws_bytes_impl(const qk_conv_desc_t *d, int op)
 {
-    // bwd-data: per-tap transposed fp32 copy of the compact kernel
-    // 16-bit fast path (fwd / bwd-data): 16-bit re-laid-out copy of the compact kernel
+    // 16-bit fast path (fwd / bwd-data): 16-bit re-laid-out copy of the compact kernel (+ zero line);
+    // the fp32-MFMA kernels read the compact kernel in place and need nothing
     // fused backward additionally: the relu-masked copy of dy that bwd-weight writes for bwd-data
     size_t n = 0;
     const bool bwd_data = op == QK_OP_BWD_DATA || op == QK_OP_BWD;
-    if (bwd_data) n = w_floats(d) * sizeof(float);
     if (d->dtype != QK_F32 && (op == QK_OP_FWD || bwd_data)) n += w_floats(d) * 2 + 256;
     if (op == QK_OP_BWD && d->activation == QK_ACT_RELU) n = (n + 255) / 256 * 256 + dy_bytes(d);
     return n;
@@ -182,12 +181,12 @@ int conv_bwd_data_impl(const qk_conv_desc_t *d, const void *dy, const void *y, c
     if (!dy || !w || !dx) { set_error("dy/w/dx must not be NULL"); return QK_ERR_INVALID_ARG; }
     const bool mask = d->activation == QK_ACT_RELU;
     if (mask && !y) { set_error("activation is RELU: the forward output y is required"); return QK_ERR_INVALID_ARG; }
-    const size_t need = w_floats(d) * sizeof(float);
-    if (!ws || wsb < ws_bytes_impl(d, QK_OP_BWD_DATA)) {
-        set_error("bwd_data needs %zu workspace bytes, got %zu", ws_bytes_impl(d, QK_OP_BWD_DATA), wsb);
+    const size_t need = ws_bytes_impl(d, QK_OP_BWD_DATA);
+    if (need && (!ws || wsb < need)) {
+        set_error("bwd_data needs %zu workspace bytes, got %zu", need, wsb);
         return QK_ERR_WORKSPACE;
     }
-    if (!aligned(ws, 16)) { set_error("workspace must be 16-byte aligned"); return QK_ERR_WORKSPACE; }
+    if (need && !aligned(ws, 16)) { set_error("workspace must be 16-byte aligned"); return QK_ERR_WORKSPACE; }
     GemmGeom g;
     memset(&g, 0, sizeof(g));
     const Strides dys = act_strides(d->out_spatial, 4 * d->fq, d->layout);
@@ -205,17 +204,14 @@ int conv_bwd_data_impl(const qk_conv_desc_t *d, const void *dy, const void *y, c
     g.sign_tbl = d->conj ? kSignConv : kSignConj;   // transposed table
     g.relu = 0; g.has_bias = 0; g.has_mask = mask ? 1 : 0;
     if (d->dtype != QK_F32) {
-        void *ws16 = static_cast<char *>(ws) + need;
-        const int r = try_hgemm_16(d->dtype, dy, mask ? y : nullptr, w, nullptr, dx, g, true, ws16,
-                                   wsb - need, stream);
+        const int r = try_hgemm_16(d->dtype, dy, mask ? y : nullptr, w, nullptr, dx, g, true, ws, wsb, stream);
         if (r != 0) return r < 0 ? r : 0;
     }
-    float *wt = static_cast<float *>(ws);
-    int rc = launch_transpose_w(w, wt, g.taps, d->cq, d->fq, stream);
-    if (rc) { set_error("transpose_w launch failed"); return rc; }
-    const bool vec = d->layout == QK_CH_LAST && d->cq % 4 == 0 && d->fq % 4 == 0 &&
+    // the fp32-MFMA kernel stages the compact kernel in place with the channel/filter roles swapped
+    g.w_swapped = 1;
+    const bool vec = d->layout == QK_CH_LAST && d->cq % 4 == 0 && d->fq % 4 == 0 && aligned(w, 16) &&
                      vec_aligned(dy, d->dtype) && (!mask || vec_aligned(y, d->dtype));
-    return launch_hgemm(d->dtype, dy, mask ? y : nullptr, wt, nullptr, dx, g, vec, stream);
+    return launch_hgemm(d->dtype, dy, mask ? y : nullptr, w, nullptr, dx, g, vec, stream);
 }
 
 int conv_bwd_weight_impl(const qk_conv_desc_t *d, const void *x, const void *dy, const void *y, float *dw,

@@ -1,28 +1,8 @@
-// Small HBM-bound helpers: compact-kernel transposition for backward-data and the fused Adam step.
+// Small HBM-bound helpers: the fused Adam step and the tap-folding gather.
 #include "qk_common.h"
 
 namespace qk {
 namespace {
-
-// dst[t][f][p][c] = src[t][c][p][f]  -- backward-data reads the compact kernel with the roles of
-// input channel and filter swapped (the transposed convolution of conv.py:334).
-__global__ void __launch_bounds__(256)
-k_transpose_w(const float *__restrict__ src, float *__restrict__ dst, int taps, int Cq, int F)
-{
-    __shared__ float tile[32][33];
-    const int t = blockIdx.z >> 2, p = blockIdx.z & 3;
-    const int c0 = blockIdx.y * 32, f0 = blockIdx.x * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
-    for (int r = ty; r < 32; r += 8) {
-        const int c = c0 + r, f = f0 + tx;
-        tile[r][tx] = (c < Cq && f < F) ? src[((size_t)(t * Cq + c) * 4 + p) * F + f] : 0.f;
-    }
-    __syncthreads();
-    for (int r = ty; r < 32; r += 8) {
-        const int f = f0 + r, c = c0 + tx;
-        if (c < Cq && f < F) dst[((size_t)(t * F + f) * 4 + p) * Cq + c] = tile[tx][r];
-    }
-}
 
 // Keras-2 Adam (keras/optimizers.py Adam.get_updates), the optimiser of working_example.py:106.
 __global__ void __launch_bounds__(256)
@@ -97,13 +77,6 @@ int launch_fold_taps(int dtype, const void *x, void *xcol, const GemmGeom &g, in
     case QK_F16: hipLaunchKernelGGL(k_fold_taps<f16>, dim3((unsigned)blocks), dim3(256), 0, stream, (const f16 *)x, (f16 *)xcol, g, cq2); break;
     default: return QK_ERR_INVALID_ARG;
     }
-    return hipGetLastError() == hipSuccess ? 0 : QK_ERR_LAUNCH;
-}
-
-int launch_transpose_w(const float *src, float *dst, int taps, int Cq, int F, hipStream_t stream)
-{
-    dim3 grid((F + 31) / 32, (Cq + 31) / 32, taps * 4);
-    hipLaunchKernelGGL(k_transpose_w, grid, dim3(256), 0, stream, src, dst, taps, Cq, F);
     return hipGetLastError() == hipSuccess ? 0 : QK_ERR_LAUNCH;
 }
 

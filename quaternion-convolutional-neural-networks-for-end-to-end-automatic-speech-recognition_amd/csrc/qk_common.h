@@ -27,8 +27,8 @@ constexpr unsigned kSignConj = 0x284Eu;   // transpose: (0,1) (0,2) (0,3) (1,2) 
 //                                                      * Wk[((t*Q + q)*4 + (a^b))*J + j] )
 //
 //   forward : In = x,  Q = Cq, J = F,  Wk = the compact kernel as stored (conv.py:165)
-//   bwd-data: In = dy, Q = F,  J = Cq, Wk = per-tap transposed copy [t][f][p][c], sign table
-//             transposed, and the position map inverted (pd = stride).
+//   bwd-data: In = dy, Q = F,  J = Cq, Wk = the same compact kernel read with q/j swapped
+//             (w_swapped), sign table transposed, and the position map inverted (pd = stride).
 //
 // pos(m, t): m -> (n, o0, o1, o2); per axis num = o*pa + t*pb + pc; the tap contributes iff
 // num >= 0, num % pd == 0 and num/pd < isp (zero padding otherwise).
@@ -50,6 +50,7 @@ struct GemmGeom {
     int has_bias;
     int has_mask;       // gathered value is zeroed where mask[same index] <= 0 (relu backward)
     int ablate;         // profiling only (env QK_ABLATE): 4 = skip the MFMA loop, 8 = skip the epilogue
+    int w_swapped;      // Wk is the compact kernel itself, read with q/j swapped (backward-data): no transposed copy
 };
 
 // Backward-weight geometry:  dW[t, c, p, f] = sum_{a^b=p} sgn(a,b) sum_m x_a[pos(m,t), c] * dy_b[m, f]
@@ -132,8 +133,6 @@ int launch_hgemm(int dtype, const void *in, const void *mask, const float *wk, c
 // fp32-MFMA Hamilton backward-weight (+ fused bias gradient); dw/dbias must be zeroed before
 int launch_wgrad(int dtype, const void *x, const void *dy, const void *ymask, float *dw,
                  float *dbias, WgradGeom g, bool vec_ok, hipStream_t stream);
-// aux: dst[t][f][p][c] = src[t][c][p][f]
-int launch_transpose_w(const float *src, float *dst, int taps, int Cq, int F, hipStream_t stream);
 int launch_fold_taps(int dtype, const void *x, void *xcol, const GemmGeom &g, int cq2, hipStream_t stream);
 int launch_adam(float *p, const float *g, float *m, float *v, size_t n, float lr, float b1,
                 float b2, float eps, int step, float gscale, hipStream_t stream);

@@ -1,8 +1,6 @@
 // Hamilton implicit GEMM on the 16-bit-input matrix cores (v_mfma_f32_32x32x16_{bf16,f16}), gfx950.
 // Forward and backward-data of the quaternion convolution / dense layers for bfloat16 / float16
-// activations, fp32 accumulation.  (Backward-weight for 16-bit data still runs on the fp32-MFMA
-// kernel of qk_hgemm_f32mfma.inc; its reduction axis is the non-contiguous one and needs LDS
-// transpose reads.)
+// activations, fp32 accumulation.  (Backward-weight for 16-bit data: qk_wgrad_bf16mfma.hip.)
 //
 // Hamilton structure in REGISTERS: per 16-deep MFMA step a wave loads the 4 gathered-component
 // A fragments (r,i,j,k of the same rows/channels) and the 4 compact-part B fragments once and

@@ -55,7 +55,10 @@ def test_invalid_descriptor_is_rejected_without_gpu():
     assert b'rank' in lib.qk_last_error()
     call = functional.conv_call((2, 10, 8), (3, 2, 8), torch.float32, 1, padding='same')
     assert lib.qk_conv_workspace_bytes(ctypes.byref(call.desc), _lib.QK_OP_FWD) == 0
-    assert lib.qk_conv_workspace_bytes(ctypes.byref(call.desc), _lib.QK_OP_BWD_DATA) == 3 * 2 * 8 * 4
+    assert lib.qk_conv_workspace_bytes(ctypes.byref(call.desc), _lib.QK_OP_BWD_DATA) == 0      # fp32: in-place kernel reads
+    call16 = functional.conv_call((2, 10, 8), (3, 2, 8), torch.bfloat16, 1, padding='same', activation='relu')
+    assert lib.qk_conv_workspace_bytes(ctypes.byref(call16.desc), _lib.QK_OP_BWD_DATA) == 3 * 2 * 8 * 2 + 256
+    assert lib.qk_conv_workspace_bytes(ctypes.byref(call16.desc), _lib.QK_OP_BWD) == 512 + 512   # + masked dy (2*10*8*2 B -> 512)
     assert lib.qk_conv_fwd(ctypes.byref(call.desc), None, None, None, None, None, 0, None) == -1
     assert b'NULL' in lib.qk_last_error()
 
