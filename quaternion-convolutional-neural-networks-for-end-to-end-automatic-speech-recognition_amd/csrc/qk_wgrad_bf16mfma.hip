@@ -52,14 +52,12 @@ __device__ __forceinline__ uint4 keep_if(bool ok, const uint4 &v)
     return make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u);
 }
 
-// keep the 16-bit halves of v whose mask half is > 0 as a signed integer (== as a bf16/fp16 value,
-// NaNs aside): 4 packed VALU ops -- v_pk_max_i16, v_pk_min_u16, v_pk_mul_lo_u16, v_and
-typedef short s2v __attribute__((ext_vector_type(2)));
+// keep the 16-bit halves of v whose mask half is non-zero.  The mask is this layer's RELU output
+// (include/qk.h), i.e. >= +0, so "non-zero" == "> 0": v_pk_min_u16, v_pk_mul_lo_u16, v_and.
 typedef unsigned short u2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned relu_keep2(unsigned v, unsigned m)
 {
-    const s2v pos = __builtin_elementwise_max(__builtin_bit_cast(s2v, m), (s2v)(0));
-    const u2v one = __builtin_elementwise_min(__builtin_bit_cast(u2v, pos), (u2v)(1));
+    const u2v one = __builtin_elementwise_min(__builtin_bit_cast(u2v, m), (u2v)(1));
     return v & __builtin_bit_cast(unsigned, (u2v)(one * (u2v)(0xffff)));
 }
 
