@@ -252,3 +252,77 @@ def test_full_size_properties_cfg3_body(dtype, tol):
     scale = float(y.double().norm() * dy.double().norm())
     assert abs(lhs - rhs_x) / scale <= tol, ('adjoint x', lhs, rhs_x, scale)
     assert abs(lhs - rhs_w) / scale <= tol, ('adjoint w', lhs, rhs_w, scale)
+
+
+def test_masked_dy_side_output_and_fused_backward_agree():
+    """bwd_weight can leave dy*(y>0) for bwd_data (the DP step's ordering); the fused qk_conv_bwd and the
+    two-call sequence must give the same gradients as the separate masked calls."""
+    import qcnn_amd
+    F = qcnn_amd.functional
+    dev = _dev()
+    g = torch.Generator(device=dev).manual_seed(3)
+    for dtype in (torch.float32, torch.bfloat16):
+        x = torch.randn(3, 40, 128, device=dev, generator=g).to(dtype)
+        w = torch.randn(3, 32, 128, device=dev, generator=g) / 20
+        b = torch.randn(128, device=dev, generator=g) / 10
+        call = F.conv_call(tuple(x.shape), tuple(w.shape), dtype, 1, 1, 'same', 'channels_last', 1, 'relu', True)
+        lin = F.conv_call(tuple(x.shape), tuple(w.shape), dtype, 1, 1, 'same', 'channels_last', 1, 'linear', True)
+        y = call.fwd(x, w, b)
+        dy = torch.randn(y.shape, device=dev, generator=g).to(dtype)
+        dx_ref = call.bwd_data(dy, y, w)
+        dw_ref, db_ref = call.bwd_weight(x, dy, y, True)
+        dym = torch.empty((dy.numel() + 127) // 128 * 128, dtype=dtype, device=dev)
+        dw2, db2 = call.bwd_weight(x, dy, y, True, masked_dy_out=dym)
+        want = torch.where(y > 0, dy, torch.zeros_like(dy))
+        assert torch.equal(dym[:dy.numel()].view_as(dy), want)
+        dx2 = lin.bwd_data(dym[:dy.numel()].view_as(dy), None, w)
+        dx3, dw3, db3 = call.bwd(x, dy, y, w, True)
+        tol = 1e-5 if dtype == torch.float32 else 1e-2
+        for got, ref in ((dx2, dx_ref), (dx3, dx_ref), (dw2, dw_ref), (dw3, dw_ref), (db2, db_ref), (db3, db_ref)):
+            assert _rel_err(got.float().cpu().numpy(), ref.float().cpu().numpy()) <= tol
+
+
+def test_adam_step_matches_keras_formula():
+    import qcnn_amd
+    dev = _dev()
+    rng = np.random.RandomState(0)
+    n = 10007
+    p, g = rng.randn(n).astype(np.float32), rng.randn(n).astype(np.float32)
+    m, v = np.zeros(n, np.float32), np.zeros(n, np.float32)
+    tp, tg = torch.tensor(p, device=dev), torch.tensor(g, device=dev)
+    tm, tv = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    lr, b1, b2, eps = 5e-4, 0.9, 0.999, 1e-7
+    p64, m64, v64 = p.astype(np.float64), m.astype(np.float64), v.astype(np.float64)
+    for t in (1, 2, 3):
+        qcnn_amd.functional.adam_step(tp, tg, tm, tv, t, lr=lr, beta1=b1, beta2=b2, eps=eps, grad_scale=0.5)
+        gs = 0.5 * g.astype(np.float64)
+        m64 = b1 * m64 + (1 - b1) * gs
+        v64 = b2 * v64 + (1 - b2) * gs * gs
+        p64 = p64 - lr * np.sqrt(1 - b2 ** t) / (1 - b1 ** t) * m64 / (np.sqrt(v64) + eps)
+    assert np.abs(tp.cpu().numpy() - p64).max() <= 1e-5
+    assert np.abs(tm.cpu().numpy() - m64).max() <= 1e-6
+
+
+def test_c_abi_reports_errors_instead_of_faulting():
+    import ctypes
+    import qcnn_amd
+    from qcnn_amd import _lib
+    F = qcnn_amd.functional
+    dev = _dev()
+    x = torch.randn(2, 16, 128, device=dev).to(torch.bfloat16)
+    w = torch.randn(3, 32, 128, device=dev)
+    call = F.conv_call(tuple(x.shape), tuple(w.shape), torch.bfloat16, 1, 1, 'same', 'channels_last', 1, 'relu', False)
+    y = call.fwd(x, w, None)
+    lib = _lib.lib()
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    dx = torch.empty_like(x)
+    dw = torch.empty_like(w)
+    # fused backward without a workspace
+    rc = lib.qk_conv_bwd(ctypes.byref(call.desc), p(x), p(y), p(y), p(w), p(dx), p(dw), None, None, 0, None)
+    assert rc == -3 and b'workspace' in lib.qk_last_error()
+    # relu backward-data without the forward output
+    rc = lib.qk_conv_bwd_data(ctypes.byref(call.desc), p(y), None, p(w), p(dx), None, 0, None)
+    assert rc == -1 and b'forward output' in lib.qk_last_error()
+    # tap folding with a bad channel count
+    rc = lib.qk_conv_fold_taps(ctypes.byref(call.desc), p(x), p(dx), 20, None)
+    assert rc == -1 and b'cq2' in lib.qk_last_error()
