@@ -265,21 +265,34 @@ k_hgemm16(const T *__restrict__ in, const T *__restrict__ mask, const uint4 *__r
         __syncthreads();
     }
 
-    // ---- epilogue: bias + activation, 16-bit stores (32 consecutive channels per row) ------
+    // ---- epilogue: bias + activation, then 16-byte stores ------------------------------------
+    // An MFMA accumulator holds ONE column per lane, so storing it directly means 64 two-byte stores
+    // per lane (store-issue bound: 17 % of the kernel, measured).  Each wave instead transposes its
+    // 32x32 tiles through a private 2.5 KB LDS patch (the tile buffers are free after the last
+    // barrier; a wave's own LDS accesses execute in order) and writes 8 channels = 16 bytes per lane.
+    constexpr int EP_PITCH = 80;                                   // 64 B of data + 16 B pad per row
+    char *ep = reinterpret_cast<char *>(lds) + wave * (32 * EP_PITCH);
+    const int e_row = lane >> 2, e_chunk = lane & 3;
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-        const int ch = b * g.J + j0 + wn * 32 + lr;
-        const float bia = g.has_bias ? bias[ch] : 0.f;
+        const int ch0 = b * g.J + j0 + wn * 32;
+        const float bia = g.has_bias ? bias[ch0 + lr] : 0.f;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + (wm * MT + mt) * 32 + mfma32_row(r, lane);
-                if (m >= g.M) continue;
                 float v = acc[mt][b][r] + bia;
                 if constexpr (SPLIT) v -= accn[b][r];
                 if (g.relu) v = v > 0.f ? v : 0.f;
-                out[(long long)m * (int)g.out_ss + ch] = from_f32<T>(v);
+                *reinterpret_cast<T *>(ep + mfma32_row(r, lane) * EP_PITCH + lr * 2) = from_f32<T>(v);
+            }
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) {
+                const int row = e_row + 16 * pass;
+                const uint4 val = *reinterpret_cast<const uint4 *>(ep + row * EP_PITCH + e_chunk * 16);
+                const int m = m0 + (wm * MT + mt) * 32 + row;
+                if (m < g.M)
+                    *reinterpret_cast<uint4 *>(out + (long long)m * (int)g.out_ss + ch0 + e_chunk * 8) = val;
             }
         }
     }
@@ -287,9 +300,10 @@ k_hgemm16(const T *__restrict__ in, const T *__restrict__ mask, const uint4 *__r
 
 template <typename T, int MT, int WM, int WN>
 int run16(const T *in, const T *mask, const uint4 *wq, const T *zero_line, const float *bias, T *out,
-          const GemmGeom &g, hipStream_t stream)
+          const GemmGeom &g_in, hipStream_t stream)
 {
     constexpr int BM = WM * MT * 32, BF = WN * 32;
+    const GemmGeom &g = g_in;
     const int n_mt = (g.M + BM - 1) / BM;
     dim3 grid((n_mt + 7) / 8 * 8, g.J / BF, 1);       // padded to the 8 XCDs (see the tile remap)
     const bool conj = g.sign_tbl == kSignConj;
