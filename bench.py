@@ -137,6 +137,7 @@ class LayerTrainStep(object):
         self.call.static_buffers = True
         # bwd-data on the masked gradient bwd-weight leaves behind (no second pass over y)
         self.relu = cfg.get('activation', 'relu') == 'relu'
+        self.diag_mask_in_bwd_data = bool(os.environ.get('QK_DIAG_MASK_IN_BWD_DATA'))
         self.call_lin = F.conv_call(tuple(self.x.shape), tuple(kernel.shape), dt, len(ks), 1, 'same',
                                     'channels_last', 1, 'linear', True)
         self.call_lin.static_buffers = True
@@ -159,7 +160,7 @@ class LayerTrainStep(object):
         self.call.bwd_weight(self.x, self.dy, self.y, True, out=(self.dw, self.db), masked_dy_out=self.dym)
 
     def k_bwd_data(self):
-        if self.relu:
+        if self.relu and not self.diag_mask_in_bwd_data:
             self.call_lin.bwd_data(self.dym, None, self.kernel.data, out=self.dx)
         else:
             self.call.bwd_data(self.dy, self.y, self.kernel.data, out=self.dx)

@@ -103,7 +103,12 @@ k_wgrad16(const T *__restrict__ x, const T *__restrict__ dy, const T *__restrict
     const int t0 = tt / g.ks[1];
     const int m_begin = split * g.m_per_split;
     const int m_end = min(g.M, m_begin + g.m_per_split);
-    const bool do_bias = g.want_dbias && t == 0 && cchunk == 0;
+    // dbias and the masked-dY side output need every dY row exactly once.  The `taps` blocks of one
+    // (split, filter chunk) all stage the same dY tiles, so they take turns: tap block t owns the K
+    // steps with step % taps == t.  (One owner block would run ~30 % longer than its peers and, with
+    // one workgroup per CU, set the kernel time.)
+    const bool bias_blk = g.want_dbias && cchunk == 0;
+    int bias_turn = t;                                       // 0 => this K step is ours
 
     // ---- staging: NTHR/64 threads per row, 16-byte units ------------------------------------
     constexpr int TPROW = NTHR / KM;
@@ -123,7 +128,8 @@ k_wgrad16(const T *__restrict__ x, const T *__restrict__ dy, const T *__restrict
         r_n = s / g.osp[0];
     }
     int d_e0 = 0;                                            // dY element offset of this thread's row
-    const bool write_dym = MASK && g.dym != nullptr && t == 0 && cchunk == 0;
+    const bool dym_blk = MASK && g.dym != nullptr && cchunk == 0;
+    int dym_turn = t;                                        // same rotation for the staged tiles
     T *dym = static_cast<T *>(g.dym);
 
     auto load_tile = [&](int mb) {
@@ -172,6 +178,8 @@ k_wgrad16(const T *__restrict__ x, const T *__restrict__ dy, const T *__restrict
     };
 
     auto store_tile = [&](int buf) {
+        const bool write_dym = dym_blk && dym_turn == 0;
+        dym_turn = dym_turn == 0 ? g.taps - 1 : dym_turn - 1;
         char *xs = lds + buf * BUF + s_row * XROW;
         char *ds = lds + buf * BUF + KM * XROW + s_row * DROW;
 #pragma unroll
@@ -220,7 +228,9 @@ k_wgrad16(const T *__restrict__ x, const T *__restrict__ dy, const T *__restrict
             if (it + 1 < iters) store_tile((it + 1) & 1);
             if (it + 2 < iters) load_tile(m_begin + (it + 2) * KM);
             const char *tb = lds + (it & 1) * BUF;
-            if (do_bias && tid < 4 * BF) {
+            const bool bias_now = bias_blk && bias_turn == 0;
+            bias_turn = bias_turn == 0 ? g.taps - 1 : bias_turn - 1;
+            if (bias_now && tid < 4 * BF) {
                 const T *col = reinterpret_cast<const T *>(tb + KM * XROW) + tid;
 #pragma unroll 8
                 for (int mm = 0; mm < KM; ++mm) dbacc += to_f32(col[mm * (DROW / 2)]);
@@ -276,7 +286,7 @@ k_wgrad16(const T *__restrict__ x, const T *__restrict__ dy, const T *__restrict
         const int cc = e / (4 * BF);
         atomicAdd(dw + ((t * g.Cq + c0 + cc) * 4 + p) * g.F + f0 + ff, slab[e]);
     }
-    if (do_bias && tid < 4 * BF) {
+    if (bias_blk && tid < 4 * BF) {
         const int b = tid / BF, ff = tid % BF;
         atomicAdd(dbias + b * g.F + f0 + ff, dbacc);
     }
@@ -290,8 +300,29 @@ int run_wgrad16(const T *x, const T *dy, const T *ymask, float *dw, float *dbias
     const int ncc = g.Cq / BC, nfc = g.F / BF;
     const long long other = (long long)ncc * nfc * g.taps;
     const long long max_splits = ((long long)g.M + KM - 1) / KM;
-    long long target = (768 + other - 1) / other;                   // ~3 workgroups per CU
-    long long splits = target < 1 ? 1 : (target > max_splits ? max_splits : target);
+    // Split M so that the grid fills a whole number of residency rounds: with 144 KB of LDS there is
+    // one workgroup per CU, and e.g. 780 equal tiles on 256 CUs take four rounds, the last 5 % full.
+    static int slots = 0;
+    if (!slots) {
+        int dev = 0, n_cu = 0, per_cu = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_wgrad16<T, WR, WC, TN, true>, WR * WC * 64, 0) != hipSuccess)
+            return QK_ERR_LAUNCH;
+        slots = (n_cu > 0 ? n_cu : 256) * (per_cu > 0 ? per_cu : 1);
+    }
+    const long long kEpilogueSteps = 16;                   // fold + atomics, in K-step equivalents
+    long long splits = 1, best_cost = -1;
+    for (int r = 1; r <= 4; ++r) {
+        long long sp = (long long)r * slots / other;
+        sp = sp < 1 ? 1 : (sp > max_splits ? max_splits : sp);
+        long long mps_r = (g.M + sp - 1) / sp;
+        mps_r = (mps_r + KM - 1) / KM * KM;
+        sp = (g.M + mps_r - 1) / mps_r;
+        const long long rounds = (sp * other + slots - 1) / slots;
+        const long long cost = rounds * (mps_r / KM + kEpilogueSteps);
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; splits = sp; }
+    }
     long long mps = (g.M + splits - 1) / splits;
     mps = (mps + KM - 1) / KM * KM;
     splits = (g.M + mps - 1) / mps;

@@ -1,10 +1,12 @@
 #!/bin/bash
 export TMPDIR=/tmp
-for ab in 0 0; do
-  echo "QK_ABLATE=$ab"
-  QK_ABLATE=$ab timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-hamilton-gemm --workload cfg3_body_qconv2d_b256_bf16 2>/dev/null | tail -1 | python -c "
+run() {
+  timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-hamilton-gemm "$@" 2>/dev/null | tail -1 | python -c "
 import sys, json
 d = json.loads(sys.stdin.read())
 print('   ms/step', round(d['ms_per_step'],4), ' '.join('%s %.1f (%.0f TF)' % (k, v['ms']*1e3, v['tflops']) for k,v in d.get('kernels',{}).items()))
 "
-done
+}
+run --workload cfg3_body_qconv2d_b256_bf16
+run --workload cfg3_body_qconv2d_b256_bf16 --activation linear
+run --workload cfg3_qcnn_timit_b256_bf16
