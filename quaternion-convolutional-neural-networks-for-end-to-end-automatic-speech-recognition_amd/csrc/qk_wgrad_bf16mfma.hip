@@ -14,7 +14,8 @@
 // tile (4*BC rows x 4*BF columns) in MFMA accumulators -- wave tile 64 x TN*32 -- and folds the 16
 // (a,b) blocks onto the 4 compact parts through LDS in four race-free phases before one atomic
 // pass to HBM, as the fp32 kernel does (qk_hgemm_f32mfma.inc).  K step = 64 rows of M, two LDS
-// buffers + a register stage, one barrier per step.  Row pitches carry 64 bytes of padding so the
+// buffers + a register stage, one barrier per step; the staging stores / loads are issued between
+// the MFMAs of the step (pinned with sched_barrier), not in a phase of their own.  Row pitches carry 64 bytes of padding so the
 // four rows a transpose read touches per 32-lane half fall on different bank quarters.
 #include "qk_common.h"
 
@@ -117,8 +118,11 @@ k_wgrad16(const T *__restrict__ x, const T *__restrict__ dy, const T *__restrict
     static_assert(UXR % TPROW == 0 && UDR % TPROW == 0, "units per thread");
     const int s_row = tid / TPROW, s_sub = tid % TPROW;
     uint4 xr[UX], dr[UD], mr[MASK ? UD : 1];
-    bool x_ok = false, d_ok = false;
-    // position of this thread's row, advanced by KM rows per load_tile call (no divisions in the loop)
+    // The register stage holds tile j+1 while tile j is multiplied; (x_ok, d_ok, d_e0) describe the
+    // tile in the registers, (nx_ok, nd_ok, nxo, nyo) the tile the next loads fetch.
+    bool x_ok = false, d_ok = false, nx_ok = false, nd_ok = false;
+    int d_e0 = 0, nxo = 0, nyo = 0;
+    // position of this thread's row, advanced by KM rows per decode (no divisions in the loop)
     int r_n, r_o0, r_o1, r_o2;
     {
         int s = m_begin + s_row;
@@ -127,31 +131,33 @@ k_wgrad16(const T *__restrict__ x, const T *__restrict__ dy, const T *__restrict
         r_o0 = s % g.osp[0];
         r_n = s / g.osp[0];
     }
-    int d_e0 = 0;                                            // dY element offset of this thread's row
     const bool dym_blk = MASK && g.dym != nullptr && cchunk == 0;
     int dym_turn = t;                                        // same rotation for the staged tiles
     T *dym = static_cast<T *>(g.dym);
 
-    auto load_tile = [&](int mb) {
+    auto decode_next = [&](int mb) {
         const int m = mb + s_row;
-        d_ok = m < m_end;
-        x_ok = false;
-        int xo = 0;
-        if (d_ok) {
-            const int i0 = r_o0 * g.pa[0] + t0 * g.pb[0] + g.pc[0];
-            const int i1 = r_o1 * g.pa[1] + t1 * g.pb[1] + g.pc[1];
-            const int i2 = r_o2 * g.pa[2] + t2 * g.pb[2] + g.pc[2];
-            x_ok = i0 >= 0 && i0 < g.isp[0] && i1 >= 0 && i1 < g.isp[1] && i2 >= 0 && i2 < g.isp[2];
-            if (x_ok) xo = r_n * (int)g.x_sn + i0 * (int)g.x_ss[0] + i1 * (int)g.x_ss[1] + i2 * (int)g.x_ss[2];
-        }
+        nd_ok = m < m_end;
+        const int i0 = r_o0 * g.pa[0] + t0 * g.pb[0] + g.pc[0];
+        const int i1 = r_o1 * g.pa[1] + t1 * g.pb[1] + g.pc[1];
+        const int i2 = r_o2 * g.pa[2] + t2 * g.pb[2] + g.pc[2];
+        nx_ok = nd_ok && i0 >= 0 && i0 < g.isp[0] && i1 >= 0 && i1 < g.isp[1] && i2 >= 0 && i2 < g.isp[2];
+        const int xo = r_n * (int)g.x_sn + i0 * (int)g.x_ss[0] + i1 * (int)g.x_ss[1] + i2 * (int)g.x_ss[2];
+        nxo = nx_ok ? xo : 0;
+        nyo = nd_ok ? m * (int)g.dy_ss : 0;
         // next call: KM rows further.  Carry-propagate when the innermost extent is long (images);
         // re-decode with divisions when it is short (dense layers, 1-D convolutions: osp[2] == 1)
         if (g.osp[2] >= KM) {
             r_o2 += KM;
-            if (r_o2 >= g.osp[2]) {
-                r_o2 -= g.osp[2];
-                if (++r_o1 == g.osp[1]) { r_o1 = 0; if (++r_o0 == g.osp[0]) { r_o0 = 0; ++r_n; } }
-            }
+            const bool c2 = r_o2 >= g.osp[2];
+            r_o2 -= c2 ? g.osp[2] : 0;
+            r_o1 += c2 ? 1 : 0;
+            const bool c1 = r_o1 == g.osp[1];
+            r_o1 = c1 ? 0 : r_o1;
+            r_o0 += c1 ? 1 : 0;
+            const bool c0 = r_o0 == g.osp[0];
+            r_o0 = c0 ? 0 : r_o0;
+            r_n += c0 ? 1 : 0;
         } else {
             int s = m + KM;
             r_o2 = s % g.osp[2]; s /= g.osp[2];
@@ -159,46 +165,42 @@ k_wgrad16(const T *__restrict__ x, const T *__restrict__ dy, const T *__restrict
             r_o0 = s % g.osp[0];
             r_n = s / g.osp[0];
         }
-        const int yo = d_ok ? m * (int)g.dy_ss : 0;
-        d_e0 = yo;
-#pragma unroll
-        for (int i = 0; i < UX; ++i) {
-            const int u = s_sub + i * TPROW;
-            const int a = u / (BC / 8), c8 = u % (BC / 8);
-            xr[i] = *reinterpret_cast<const uint4 *>(x + xo + a * g.Cq + c0 + c8 * 8);
-        }
-#pragma unroll
-        for (int i = 0; i < UD; ++i) {
-            const int u = s_sub + i * TPROW;
-            const int b = u / (BF / 8), f8 = u % (BF / 8);
-            const int e = yo + b * g.F + f0 + f8 * 8;
+    };
+    auto commit_next = [&]() { x_ok = nx_ok; d_ok = nd_ok; d_e0 = nyo; };
+    // unit u of the staged pair (X units first, then dY): one 16-byte load / one 16-byte LDS store
+    auto load_unit = [&](int u) {
+        if (u < UX) {
+            const int q = s_sub + u * TPROW;
+            xr[u] = *reinterpret_cast<const uint4 *>(x + nxo + (q / (BC / 8)) * g.Cq + c0 + (q % (BC / 8)) * 8);
+        } else {
+            const int i = u - UX, q = s_sub + i * TPROW;
+            const int e = nyo + (q / (BF / 8)) * g.F + f0 + (q % (BF / 8)) * 8;
             dr[i] = *reinterpret_cast<const uint4 *>(dy + e);
             if constexpr (MASK) mr[i] = *reinterpret_cast<const uint4 *>(ymask + e);
         }
     };
-
-    auto store_tile = [&](int buf) {
-        const bool write_dym = dym_blk && dym_turn == 0;
-        dym_turn = dym_turn == 0 ? g.taps - 1 : dym_turn - 1;
-        char *xs = lds + buf * BUF + s_row * XROW;
-        char *ds = lds + buf * BUF + KM * XROW + s_row * DROW;
-#pragma unroll
-        for (int i = 0; i < UX; ++i)
-            *reinterpret_cast<uint4 *>(xs + (s_sub + i * TPROW) * 16) = keep_if(x_ok, xr[i]);
-#pragma unroll
-        for (int i = 0; i < UD; ++i) {
+    auto store_unit = [&](int u, int buf, bool write_dym) {
+        if (u < UX) {
+            char *xs = lds + buf * BUF + s_row * XROW;
+            *reinterpret_cast<uint4 *>(xs + (s_sub + u * TPROW) * 16) = keep_if(x_ok, xr[u]);
+        } else {
+            const int i = u - UX, q = s_sub + i * TPROW;
+            char *ds = lds + buf * BUF + KM * XROW + s_row * DROW;
             uint4 v = keep_if(d_ok, dr[i]);
             if constexpr (MASK)
                 v = make_uint4(relu_keep2(v.x, mr[i].x), relu_keep2(v.y, mr[i].y), relu_keep2(v.z, mr[i].z),
                                relu_keep2(v.w, mr[i].w));
-            *reinterpret_cast<uint4 *>(ds + (s_sub + i * TPROW) * 16) = v;
+            *reinterpret_cast<uint4 *>(ds + q * 16) = v;
             if constexpr (MASK) {
-                if (write_dym && d_ok) {
-                    const int u = s_sub + i * TPROW;
-                    *reinterpret_cast<uint4 *>(dym + d_e0 + (u / (BF / 8)) * g.F + f0 + (u % (BF / 8)) * 8) = v;
-                }
+                if (write_dym && d_ok)
+                    *reinterpret_cast<uint4 *>(dym + d_e0 + (q / (BF / 8)) * g.F + f0 + (q % (BF / 8)) * 8) = v;
             }
         }
+    };
+    auto dym_now = [&]() {
+        const bool w = dym_blk && dym_turn == 0;
+        dym_turn = dym_turn == 0 ? g.taps - 1 : dym_turn - 1;
+        return w;
     };
 
     floatx16 acc[2][TN];
@@ -218,16 +220,33 @@ k_wgrad16(const T *__restrict__ x, const T *__restrict__ dy, const T *__restrict
     const int a_off = fr_row * XROW + ((wr * 2) * 32 + fr_ch) * 2;                 // + rt*64 bytes
     const int b_off = KM * XROW + fr_row * DROW + ((wc * TN) * 32 + fr_ch) * 2;      // + ct*64 bytes
 
+    constexpr int NU = UX + UD;                      // staged 16-byte units per thread and K step
+    constexpr int KS = KM / 16;                      // 16-deep MFMA steps per K step
+    constexpr int NMF = 2 * TN;                      // MFMAs per 16-deep step
+    static_assert((NU + KS - 1) / KS * 2 <= NMF, "two issue slots per staged unit");
     const int iters = (m_end - m_begin + KM - 1) / KM;
     if (iters > 0) {
-        load_tile(m_begin);
-        store_tile(0);
-        if (iters > 1) load_tile(m_begin + KM);
+        decode_next(m_begin);
+#pragma unroll
+        for (int u = 0; u < NU; ++u) load_unit(u);
+        commit_next();
+        {
+            const bool w = dym_now();
+#pragma unroll
+            for (int u = 0; u < NU; ++u) store_unit(u, 0, w);
+        }
+        decode_next(m_begin + KM);
+#pragma unroll
+        for (int u = 0; u < NU; ++u) load_unit(u);
+        commit_next();
         __syncthreads();
         for (int it = 0; it < iters; ++it) {
-            if (it + 1 < iters) store_tile((it + 1) & 1);
-            if (it + 2 < iters) load_tile(m_begin + (it + 2) * KM);
+            // Tile `it` is multiplied out of buffer it & 1 while tile it + 1 moves from the register
+            // stage into the other buffer and tile it + 2 is fetched into the freed registers.  The
+            // staging instructions are pinned BETWEEN the MFMAs (one store or one load per slot), so
+            // they issue in the shadow of the matrix pipe instead of in a phase of their own.
             const char *tb = lds + (it & 1) * BUF;
+            const int nb = (it + 1) & 1;
             const bool bias_now = bias_blk && bias_turn == 0;
             bias_turn = bias_turn == 0 ? g.taps - 1 : bias_turn - 1;
             if (bias_now && tid < 4 * BF) {
@@ -235,18 +254,32 @@ k_wgrad16(const T *__restrict__ x, const T *__restrict__ dy, const T *__restrict
 #pragma unroll 8
                 for (int mm = 0; mm < KM; ++mm) dbacc += to_f32(col[mm * (DROW / 2)]);
             }
+            const bool w = dym_now();
+            decode_next(m_begin + (it + 2) * KM);
 #pragma unroll
-            for (int ks = 0; ks < KM / 16; ++ks) {
+            for (int ks = 0; ks < KS; ++ks) {
+                // (prefetching the next step's fragments during these MFMAs was measured: +2 % on the
+                // linear variant, but the RELU variant then spills; not worth a second code path)
                 v8s A[2], B[TN];
 #pragma unroll
                 for (int rt = 0; rt < 2; ++rt) A[rt] = tr_frag(tb + a_off + ks * 16 * XROW + rt * 64, XROW);
 #pragma unroll
                 for (int ct = 0; ct < TN; ++ct) B[ct] = tr_frag(tb + b_off + ks * 16 * DROW + ct * 64, DROW);
+                __builtin_amdgcn_sched_barrier(0);
+                const int u_lo = ks * NU / KS, u_hi = (ks + 1) * NU / KS;
 #pragma unroll
-                for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-                    for (int ct = 0; ct < TN; ++ct) acc[rt][ct] = mfma16w(T(), A[rt], B[ct], acc[rt][ct]);
+                for (int j = 0; j < NMF; ++j) {
+                    const int rt = j / TN, ct = j % TN;
+                    acc[rt][ct] = mfma16w(T(), A[rt], B[ct], acc[rt][ct]);
+                    const int u = u_lo + j / 2;
+                    if (u < u_hi) {
+                        if (j % 2 == 0) store_unit(u, nb, w);
+                        else load_unit(u);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
+            commit_next();
             __syncthreads();
         }
     }
