@@ -152,49 +152,74 @@ k_hgemm16(const T *__restrict__ in, const T *__restrict__ mask, const uint4 *__r
     static_assert(BU == 1 || BU == 2, "B prefetch registers are named, not an array: hipcc parks a\n"
                   "by-reference-captured array in LDS (promote-alloca) and waits for the load right away");
     uint4 ar[RPT2][2], mr[MASK ? RPT2 : 1][2], br0, br1;
-    int lt0 = 0, lt1 = 0, lt2 = 0, lkc = 0, ltap = 0;      // (tap, K chunk) of the NEXT load_tile call
+    int lt0 = 0, lt1 = 0, lt2 = 0, lkc = 0, ltap = 0;      // (tap, K chunk) of the tile the loads fetch
+    int ldelta = 0;                                         // its wave-uniform displacement
+    const uint4 *lwsrc = wq;                                // and its slice of the re-laid-out kernel
 
-    auto load_tile = [&]() {
-        const int delta = lt0 * g.pb[0] * (int)g.in_ss[0] + lt1 * g.pb[1] * (int)g.in_ss[1] +
-                          lt2 * g.pb[2] * (int)g.in_ss[2] + lkc * 32 + sub;
-#pragma unroll
-        for (int r = 0; r < RPT2; ++r) {
-            const bool ok = (tapmask[r] >> ltap) & 1u;
-            const int off = base_off[r] + delta;
-            const T *lo = ok ? in + off + cmp_lo * g.Q : zero_line;
-            const T *hi = ok ? in + off + cmp_hi * g.Q : zero_line;
-            ar[r][0] = *reinterpret_cast<const uint4 *>(lo);
-            ar[r][1] = *reinterpret_cast<const uint4 *>(hi);
-            if constexpr (MASK) {
-                const T *mlo = ok ? mask + off + cmp_lo * g.Q : zero_line;
-                const T *mhi = ok ? mask + off + cmp_hi * g.Q : zero_line;
-                mr[r][0] = *reinterpret_cast<const uint4 *>(mlo);
-                mr[r][1] = *reinterpret_cast<const uint4 *>(mhi);
-            }
-        }
-        // B tile: 16 (slot, part) segments of BF 16-byte units each, J units apart in the workspace
-        const uint4 *wsrc = wq + (long long)(ltap * nkc + lkc) * 16 * g.J;
-        br0 = wsrc[(tid / BF) * g.J + j0 + tid % BF];
-        if constexpr (BU == 2) br1 = wsrc[((tid + 512) / BF) * g.J + j0 + (tid + 512) % BF];
+    auto prep_loads = [&]() {
+        ldelta = lt0 * g.pb[0] * (int)g.in_ss[0] + lt1 * g.pb[1] * (int)g.in_ss[1] +
+                 lt2 * g.pb[2] * (int)g.in_ss[2] + lkc * 32 + sub;
+        lwsrc = wq + (long long)(ltap * nkc + lkc) * 16 * g.J;
+    };
+    auto advance_loads = [&]() {
         if (++lkc == nkc) {
             lkc = 0; ++ltap;
             if (++lt2 == g.ks[2]) { lt2 = 0; if (++lt1 == g.ks[1]) { lt1 = 0; ++lt0; } }
         }
     };
-
-    auto store_tile = [&](int buf) {
-        uint4 *As = lds + buf * TILE_U;
-        uint4 *Bs = As + BM * 16;
-#pragma unroll
-        for (int r = 0; r < RPT2; ++r) {
-            const int row = s_row + r * 64;
-            uint4 v0 = ar[r][0], v1 = ar[r][1];
-            if constexpr (MASK) { v0 = mask8(v0, mr[r][0]); v1 = mask8(v1, mr[r][1]); }
-            As[row * 16 + (s8 ^ (row & 15))] = v0;
-            As[row * 16 + ((s8 + 8) ^ (row & 15))] = v1;
+    auto load_a = [&](int r) {
+        const bool ok = (tapmask[r] >> ltap) & 1u;
+        const int off = base_off[r] + ldelta;
+        const T *lo = ok ? in + off + cmp_lo * g.Q : zero_line;
+        const T *hi = ok ? in + off + cmp_hi * g.Q : zero_line;
+        ar[r][0] = *reinterpret_cast<const uint4 *>(lo);
+        ar[r][1] = *reinterpret_cast<const uint4 *>(hi);
+        if constexpr (MASK) {
+            const T *mlo = ok ? mask + off + cmp_lo * g.Q : zero_line;
+            const T *mhi = ok ? mask + off + cmp_hi * g.Q : zero_line;
+            mr[r][0] = *reinterpret_cast<const uint4 *>(mlo);
+            mr[r][1] = *reinterpret_cast<const uint4 *>(mhi);
         }
+    };
+    // B tile: 16 (slot, part) segments of BF 16-byte units each, J units apart in the workspace
+    auto load_b = [&]() {
+        br0 = lwsrc[(tid / BF) * g.J + j0 + tid % BF];
+        if constexpr (BU == 2) br1 = lwsrc[((tid + 512) / BF) * g.J + j0 + (tid + 512) % BF];
+    };
+    auto store_a = [&](int r, int buf) {
+        uint4 *As = lds + buf * TILE_U;
+        const int row = s_row + r * 64;
+        uint4 v0 = ar[r][0], v1 = ar[r][1];
+        if constexpr (MASK) { v0 = mask8(v0, mr[r][0]); v1 = mask8(v1, mr[r][1]); }
+        As[row * 16 + (s8 ^ (row & 15))] = v0;
+        As[row * 16 + ((s8 + 8) ^ (row & 15))] = v1;
+    };
+    auto store_b = [&](int buf) {
+        uint4 *Bs = lds + buf * TILE_U + BM * 16;
         Bs[tid] = br0;
         if constexpr (BU == 2) Bs[tid + 512] = br1;
+    };
+    auto load_tile = [&]() {
+        prep_loads();
+#pragma unroll
+        for (int r = 0; r < RPT2; ++r) load_a(r);
+        load_b();
+        advance_loads();
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int r = 0; r < RPT2; ++r) store_a(r, buf);
+        store_b(buf);
+    };
+    // staging op `op` of a K step: store A rows r, refill them; ...; store B, refill it.  The loop
+    // below issues one op after every second MFMA of the step, so the global loads, the mask VALU and
+    // the LDS stores run in the shadow of the matrix pipe instead of in a phase of their own.
+    constexpr int N_OPS = 2 * RPT2 + 2;
+    auto stage_op = [&](int op, int buf) {
+        if (op < 2 * RPT2) {
+            if (op % 2 == 0) store_a(op / 2, buf); else load_a(op / 2);
+        } else if (op == 2 * RPT2) store_b(buf);
+        else load_b();
     };
 
     floatx16 acc[MT][4], accn[SPLIT ? 4 : 1];
@@ -211,19 +236,22 @@ k_hgemm16(const T *__restrict__ in, const T *__restrict__ mask, const uint4 *__r
     const int b_rd0 = BM * 16 + wn * 32 + lr;
 
     // Pipeline (one barrier per K step): registers hold tile it+1 (loaded during step it-1);
-    //   step it:  write them to LDS buffer (it+1)&1  ->  issue the global loads of tile it+2  ->
-    //             MFMAs on buffer it&1  ->  barrier.
+    //   step it:  MFMAs on buffer it&1, and between them: registers -> LDS buffer (it+1)&1, then the
+    //             freed registers <- global loads of tile it+2;  barrier.
     // Buffer (it+1)&1 was last read in step it-1, which every wave left through that step's barrier.
+    // The last two steps re-fetch (and re-store) the final tile instead of branching around the ops:
+    // nobody reads that buffer again.
     load_tile();
     store_tile(0);
     if (iters > 1) load_tile();
     __syncthreads();
 
+    int fetched = 2;                                  // tiles whose loads have been issued
     for (int it = 0; it < iters; ++it) {
-        if (it + 1 < iters) store_tile((it + 1) & 1);
-        if (it + 2 < iters) load_tile();
+        const int nb = (it + 1) & 1;
         const uint4 *a_rd = lds + (it & 1) * TILE_U + a_rd0;
         const uint4 *b_rd = lds + (it & 1) * TILE_U + b_rd0;
+        prep_loads();
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             uint4 A[MT][4], B[4];
@@ -233,35 +261,36 @@ k_hgemm16(const T *__restrict__ in, const T *__restrict__ mask, const uint4 *__r
                 for (int a = 0; a < 4; ++a) A[mt][a] = a_rd[mt * 32 * 16 + ((a * 4 + ks * 2 + lh) ^ fsw)];
 #pragma unroll
             for (int p = 0; p < 4; ++p) B[p] = b_rd[((ks * 2 + lh) * 4 + p) * BF];
-            if constexpr (SPLIT) {
-                // products that enter with a minus sign go to a second accumulator set: no sign-flip
-                // VALU in the loop (12 v_xor per step otherwise; +4 % measured), acc -= accn at the end
-#pragma unroll
-                for (int a = 0; a < 4; ++a)
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) {
-                        constexpr unsigned tbl = TBL;
-                        if ((tbl >> (a * 4 + b)) & 1u) accn[b] = mfma16(T(), A[0][a], B[a ^ b], accn[b]);
-                        else acc[0][b] = mfma16(T(), A[0][a], B[a ^ b], acc[0][b]);
-                    }
-            } else {
+            uint4 Bn[SPLIT ? 1 : 4];
+            if constexpr (!SPLIT) {
                 // taller wave tile: the three negated parts (12 v_xor) are shared by MT row tiles
-                uint4 Bn[4];
 #pragma unroll
                 for (int p = 1; p < 4; ++p)
                     Bn[p] = make_uint4(B[p].x ^ 0x80008000u, B[p].y ^ 0x80008000u, B[p].z ^ 0x80008000u, B[p].w ^ 0x80008000u);
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int a = 0; a < 4; ++a)
+            for (int a = 0; a < 4; ++a)
 #pragma unroll
-                    for (int b = 0; b < 4; ++b) {
-                        constexpr unsigned tbl = TBL;
-                        const bool ng = (tbl >> (a * 4 + b)) & 1u;
+                for (int b = 0; b < 4; ++b) {
+                    constexpr unsigned tbl = TBL;
+                    const bool ng = (tbl >> (a * 4 + b)) & 1u;
+                    if constexpr (SPLIT) {
+                        // products that enter with a minus sign go to a second accumulator set: no
+                        // sign-flip VALU in the loop, acc -= accn at the end
+                        if (ng) accn[b] = mfma16(T(), A[0][a], B[a ^ b], accn[b]);
+                        else acc[0][b] = mfma16(T(), A[0][a], B[a ^ b], acc[0][b]);
+                    } else {
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt)
                             acc[mt][b] = mfma16(T(), A[mt][a], ng ? Bn[a ^ b] : B[a ^ b], acc[mt][b]);
                     }
-            }
+                    const int f = ks * 16 + a * 4 + b;           // MFMA group index inside the K step
+                    if (f % 2 == 1 && f / 2 < N_OPS) stage_op(f / 2, nb);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
         }
+        if (fetched < iters) { advance_loads(); ++fetched; }
         __syncthreads();
     }
 
