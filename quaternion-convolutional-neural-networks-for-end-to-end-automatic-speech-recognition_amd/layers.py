@@ -72,6 +72,24 @@ class Dense(Layer):
 def _pool_nd(x, pool, strides, padding, axes, mode):
     """Pool `axes` of x with TensorFlow padding semantics."""
     rank = len(axes)
+    if x.dim() == 4 and rank <= 2:
+        # Pool a 4-D tensor where it lies: per-axis window / stride over dims 1..3 (1 = untouched); when
+        # dim 1 is untouched torch pools dims (2, 3) of the (B, C, H, W) view directly -- with its NHWC
+        # kernels when the buffer is channels-last, which is how the quaternion layers keep
+        # channels_first tensors (DESIGN.md section 2).  (The TIMIT model's MaxPooling2D((1, 3)) on a
+        # channels_first tensor is this case: Keras' default data_format makes it pool axes (C, F) with a
+        # window of 1 on C.)  TF padding must be all on the high side, which ceil_mode covers: a partial
+        # last window ignores the missing elements (max) / leaves them out of the divisor (avg).
+        win, step = [1, 1, 1], [1, 1, 1]
+        for ax, pl, st in zip(axes, pool, strides):
+            win[ax - 1], step[ax - 1] = pl, st
+        if win[0] == 1 and step[0] == 1:
+            lo_hi = [tf_pads(x.shape[d], win[d - 1], step[d - 1], 1, padding) for d in (2, 3)]
+            if all(lo == 0 for lo, _ in lo_hi):
+                ceil = any(hi > 0 for _, hi in lo_hi)
+                if mode == 'max':
+                    return F.max_pool2d(x, tuple(win[1:]), tuple(step[1:]), ceil_mode=ceil)
+                return F.avg_pool2d(x, tuple(win[1:]), tuple(step[1:]), ceil_mode=ceil, count_include_pad=False)
     perm = [0] + [i for i in range(1, x.dim()) if i not in axes] + list(axes)
     xp = x.permute(perm)
     lead = xp.shape[:x.dim() - rank]

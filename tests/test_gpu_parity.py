@@ -240,18 +240,78 @@ def test_full_size_properties_cfg3_body(dtype, tol):
     x12 = (x1.to(dtype).float() + 2 * x2.to(dtype).float())
     if dtype == torch.float32:
         y12 = F.quaternion_conv(x12, w, None, **kw)
-        lin = (y12 - (y1 + 2 * y2)).abs().max() / y12.abs().max()
+        lin = ((y12 - (y1 + 2 * y2)).abs().max() / y12.abs().max()).detach()
         assert float(lin) <= tol, 'linearity %.3g' % float(lin)
     xa = x1.to(dtype).requires_grad_(True)
     y = F.quaternion_conv(xa, w, None, **kw)
     dy = torch.randn(y.shape, device=dev, generator=g).to(dtype)
     y.backward(dy)
-    lhs = float((y.double() * dy.double()).sum())
+    lhs = float((y.detach().double() * dy.double()).sum())
     rhs_x = float((xa.grad.double() * xa.detach().double()).sum())
     rhs_w = float((w.grad.double() * w.detach().double()).sum())
-    scale = float(y.double().norm() * dy.double().norm())
+    scale = float(y.detach().double().norm() * dy.double().norm())
     assert abs(lhs - rhs_x) / scale <= tol, ('adjoint x', lhs, rhs_x, scale)
     assert abs(lhs - rhs_w) / scale <= tol, ('adjoint w', lhs, rhs_w, scale)
+
+
+FULL_SIZE_16BIT = [
+    # BASELINE config 3, stage-2 body layer at the full batch (the Hamilton GEMM of the 40 % target)
+    ('cfg3_body_b256_bf16', torch.bfloat16, (256, 14, 200, 256), (3, 5, 64, 256)),
+    # config 3 stage-1 body layer (32 -> 32 filters) and the 32 -> 64 transition, full batch
+    ('cfg3_stage1_b256_bf16', torch.bfloat16, (256, 14, 200, 128), (3, 5, 32, 128)),
+    ('cfg3_32to64_b256_bf16', torch.bfloat16, (256, 14, 200, 128), (3, 5, 32, 256)),
+    # config 5 body layer (Cq = F = 256, fp16), 32 samples per GPU
+    ('cfg5_body_b32_fp16', torch.float16, (32, 14, 200, 1024), (3, 5, 256, 1024)),
+]
+
+
+@pytest.mark.parametrize('case', FULL_SIZE_16BIT, ids=[c[0] for c in FULL_SIZE_16BIT])
+def test_full_size_16bit_mfma_kernels_agree_with_exact_fp32_kernels(case):
+    """At BASELINE's full sizes the oracle would run for hours, so the 16-bit MFMA kernels (k_hgemm16,
+    k_wgrad16) are checked against the general fp32-MFMA kernels on the SAME 16-bit inputs: those are an
+    exact fp32 fmaf chain and are themselves pinned to the oracle above at every small shape.  Both see
+    identical operands (the fp32 kernel also rounds its output to 16 bits), so the only differences are
+    the kernel rounded to 16 bits for the matrix cores and the accumulation order.  QK_NO_MFMA16 is the
+    library's diagnostic switch (read at every call)."""
+    import qcnn_amd
+    F = qcnn_amd.functional
+    _, dtype, xs, ws = case
+    dev = _dev()
+    g = torch.Generator(device=dev).manual_seed(21)
+    x = torch.randn(xs, device=dev, generator=g).to(dtype)
+    # kernel values exactly representable in 16 bits: both paths then multiply identical numbers
+    w = (torch.randn(ws, device=dev, generator=g) / (4.0 * (ws[-2] * 15) ** 0.5)).to(dtype).float()
+    b = (torch.randn(ws[-1], device=dev, generator=g) / 10).to(dtype).float()
+    call = F.conv_call(tuple(xs), tuple(ws), dtype, 2, 1, 'same', 'channels_last', 1, 'relu', True)
+
+    dy = torch.randn(call.y_shape, device=dev, generator=g).to(dtype)
+
+    def run(y_mask):
+        y = call.fwd(x, w, b)
+        # the same relu mask for both paths: an element of y that rounds to 0 on one path and to a tiny
+        # positive number on the other would otherwise switch a whole dy element on or off
+        dx, dw, db = call.bwd(x, dy, y if y_mask is None else y_mask, w, True)
+        torch.cuda.synchronize()
+        return y, dx, dw, db
+
+    fast = run(None)
+    os.environ['QK_NO_MFMA16'] = '1'
+    try:
+        exact = run(fast[0])
+    finally:
+        del os.environ['QK_NO_MFMA16']
+    assert not torch.equal(fast[2], exact[2]), 'QK_NO_MFMA16 did not switch kernels: the check is vacuous'
+    # y: identical up to the last 16-bit rounding (and relu flips of values that round across zero)
+    tol16 = 1e-2 if dtype == torch.bfloat16 else 2e-3
+    names = ('y', 'dx', 'dkernel', 'dbias')
+    for name, a, e in zip(names, fast, exact):
+        a, e = a.float(), e.float()
+        err = float((a - e).abs().max()) / float(e.abs().max())
+        tol = tol16 if name in ('y', 'dx') else 2e-3
+        assert err <= tol, '%s: rel err %.3g > %.1g' % (name, err, tol)
+        # and no systematic drift: the sums agree much more tightly than single elements
+        ssum = abs(float(a.double().sum()) - float(e.double().sum())) / float(e.double().abs().sum())
+        assert ssum <= 1e-4, '%s: checksum drift %.3g' % (name, ssum)
 
 
 def test_masked_dy_side_output_and_fused_backward_agree():

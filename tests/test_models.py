@@ -27,6 +27,22 @@ def test_maxpool_default_format_pools_the_frequency_axis():
     assert torch.equal(y[:, :, 13, :], x[:, :, 39:41, :].amax(2))           # last window: 2 real cells
 
 
+@pytest.mark.parametrize('shape,pool,strides,axes', [
+    ((2, 8, 41, 20), (1, 3), (1, 3), (1, 2)),        # the TIMIT model's frequency pooling
+    ((2, 5, 10, 11), (2, 2), (2, 2), (2, 3)),
+    ((2, 6, 9, 7), (2, 2), (2, 2), (1, 2)),          # pools the channel position too: generic path
+    ((2, 5, 9, 7), (3, 2), (2, 2), (2, 3)),          # low-side padding: generic path
+])
+@pytest.mark.parametrize('mode', ['max', 'avg'])
+def test_in_place_pooling_of_channels_last_buffers_matches_generic_path(shape, pool, strides, axes, mode):
+    from qcnn_amd.layers import _pool_nd
+    x = torch.randn(*shape, generator=torch.Generator().manual_seed(5))
+    fast = _pool_nd(x.contiguous(memory_format=torch.channels_last), pool, strides, 'same', axes, mode)
+    generic = _pool_nd(x.unsqueeze(-1), pool, strides, 'same', axes, mode).squeeze(-1)   # 5-D: no fast path
+    assert fast.shape == generic.shape
+    assert float((fast - generic).abs().max()) <= 1e-6
+
+
 def test_dense_prelu_timedistributed_ctc_on_cpu():
     np.random.seed(0)
     d = TimeDistributed(Dense(5, activation='softmax'))
