@@ -194,7 +194,8 @@ class LayerTrainStep(object):
             self.k_fwd(); self.k_bwd_weight(); self.k_bwd_data(); self._adam()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        if self.world == 1:
+        import torch.distributed as dist
+        if not dist.is_initialized():
             # (forking bwd-weight / bwd-data onto two streams inside the graph was measured SLOWER:
             #  0.205 vs 0.153 ms per step -- the kernels already fill the CUs, they only contend.)
             self.g_all = torch.cuda.CUDAGraph()
@@ -333,7 +334,7 @@ def main():
     job = ModelTrainStep(cfg, dev, rank, world) if is_model else LayerTrainStep(cfg, dev, rank, world)
 
     def barrier():
-        if world > 1:
+        if world > 1 or dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 

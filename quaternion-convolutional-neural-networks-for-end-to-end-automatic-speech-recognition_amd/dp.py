@@ -19,6 +19,11 @@ import os
 import torch
 import torch.distributed as dist
 
+# Diagnostic: with QK_DP_FORCE_COLLECTIVES=1 a single process still creates the process group and issues
+# the collectives (a one-rank RCCL communicator).  That is how the 1-GPU test box exercises the exact
+# init / all-reduce / barrier calls the 8-GPU run makes.
+_FORCE = bool(os.environ.get('QK_DP_FORCE_COLLECTIVES'))
+
 
 def init_from_env(backend=None):
     """Initialise torch.distributed from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun).
@@ -26,7 +31,7 @@ def init_from_env(backend=None):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or _FORCE) and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
@@ -86,7 +91,7 @@ def broadcast_params(flat, src=0, group=None):
 def allreduce_sum_(tensor, group=None, async_op=False):
     """Sum all-reduce of the flat gradient buffer (RCCL on GPUs).  Returns the work handle when
     async_op; no-op for world size 1."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not _FORCE):
         return None
     return dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
 

@@ -81,3 +81,31 @@ def test_shard_rows_partitions_the_batch():
         covered = [i for lo, hi in spans for i in range(lo, hi)]
         assert covered == list(range(n))
     assert dp.world_size() == 1 and dp.allreduce_sum_(torch.zeros(4)) is None
+
+
+@pytest.mark.gpu
+def test_bench_step_through_one_rank_rccl_group():
+    """The 1-GPU test box cannot form a 2-rank RCCL group (one device), so the exact calls of the
+    multi-GPU bench -- torchrun env, nccl process group with device_id, async all-reduce overlapping
+    backward-data, barrier, MAX-reduce of the elapsed time -- run here with a one-rank communicator
+    (QK_DP_FORCE_COLLECTIVES, qcnn_amd/dp.py)."""
+    import json
+    import subprocess
+    import sys
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, QK_DP_FORCE_COLLECTIVES='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.join(root, 'bench.py'),
+           '--gpus', '1', '--steps', '20', '--warmup', '3', '--no-cpu-baseline', '--no-hamilton-gemm',
+           '--no-kernel-timing']
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1]
+    rec = json.loads(line)
+    assert rec['n_gpus'] == 1 and rec['value'] > 0 and rec['config']['launch'] == 'eager'
