@@ -29,11 +29,35 @@ def _require_device(t, what):
 
 
 def _ptr(t):
-    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    return t.data_ptr() if t is not None else None      # argtypes are c_void_p: ints convert
+
+
+# Host cost matters: the config-2 layer step is ~150 us of GPU time over 7 launches, so every
+# microsecond of Python per launch shows up once a collective joins the step.
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
 
 
 def _stream(t):
-    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    if _raw_stream is not None:
+        return _raw_stream(t.device.index)
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+class _on_device(object):
+    """torch.cuda.device(d) guard that is skipped when d is already the current device (the usual case)."""
+    __slots__ = ('guard',)
+
+    def __init__(self, dev):
+        self.guard = None if torch.cuda.current_device() == dev.index else torch.cuda.device(dev)
+
+    def __enter__(self):
+        if self.guard is not None:
+            self.guard.__enter__()
+
+    def __exit__(self, *exc):
+        if self.guard is not None:
+            self.guard.__exit__(*exc)
+        return False
 
 
 class _Call(object):
@@ -44,9 +68,12 @@ class _Call(object):
         self.x_shape, self.y_shape, self.w_shape, self.relu = x_shape, y_shape, w_shape, relu
         self.static_buffers = False      # True: keep workspaces (graph capture / bench loops)
         self._ws_cache = {}
+        self._ws_bytes = {}              # the descriptor never changes after construction
 
     def _ws(self, op, like):
-        n = int(getattr(L.lib(), self.ws_fn)(ctypes.byref(self.desc), op))
+        n = self._ws_bytes.get(op)
+        if n is None:
+            n = self._ws_bytes[op] = int(getattr(L.lib(), self.ws_fn)(ctypes.byref(self.desc), op))
         if n == 0:
             return None, 0
         if self.static_buffers:
@@ -59,7 +86,7 @@ class _Call(object):
     def fwd(self, x, w, bias, out=None):
         y = out if out is not None else torch.empty(self.y_shape, dtype=x.dtype, device=x.device)
         ws, n = self._ws(L.QK_OP_FWD, x)
-        with torch.cuda.device(x.device):
+        with _on_device(x.device):
             rc = getattr(L.lib(), self.names[0])(ctypes.byref(self.desc), _ptr(x), _ptr(w), _ptr(bias),
                                                  _ptr(y), _ptr(ws), n, _stream(x))
         L.check(rc, self.names[0])
@@ -68,7 +95,7 @@ class _Call(object):
     def bwd_data(self, dy, y, w, out=None):
         dx = out if out is not None else torch.empty(self.x_shape, dtype=dy.dtype, device=dy.device)
         ws, n = self._ws(L.QK_OP_BWD_DATA, dy)
-        with torch.cuda.device(dy.device):
+        with _on_device(dy.device):
             rc = getattr(L.lib(), self.names[1])(ctypes.byref(self.desc), _ptr(dy), _ptr(y), _ptr(w),
                                                  _ptr(dx), _ptr(ws), n, _stream(dy))
         L.check(rc, self.names[1])
@@ -84,7 +111,7 @@ class _Call(object):
         ws, n = self._ws(L.QK_OP_BWD_WEIGHT, x)
         if masked_dy_out is not None:
             ws, n = masked_dy_out, masked_dy_out.numel() * masked_dy_out.element_size()
-        with torch.cuda.device(x.device):
+        with _on_device(x.device):
             rc = getattr(L.lib(), self.names[2])(ctypes.byref(self.desc), _ptr(x), _ptr(dy), _ptr(y),
                                                  _ptr(dw), _ptr(db), _ptr(ws), n, _stream(x))
         L.check(rc, self.names[2])
@@ -101,7 +128,7 @@ class _Call(object):
             db = torch.empty((self.w_shape[-1],), dtype=torch.float32, device=x.device) if has_bias else None
         ws, n = self._ws(L.QK_OP_BWD, x)
         name = self.names[1].replace('_bwd_data', '_bwd')
-        with torch.cuda.device(x.device):
+        with _on_device(x.device):
             rc = getattr(L.lib(), name)(ctypes.byref(self.desc), _ptr(x), _ptr(dy), _ptr(y), _ptr(w), _ptr(dx),
                                         _ptr(dw), _ptr(db), _ptr(ws), n, _stream(x))
         L.check(rc, name)
@@ -255,7 +282,7 @@ def _folded_conv(x, kernel, bias, rank, strides, padding, data_format, dilation_
     d = call.desc
     out_sp = tuple(d.out_spatial[i] for i in range(rank))
     xcol = torch.empty((xp.shape[0],) + out_sp + (4 * cq2,), dtype=xp.dtype, device=xp.device)
-    with torch.cuda.device(xp.device):
+    with _on_device(xp.device):
         rc = L.lib().qk_conv_fold_taps(ctypes.byref(d), _ptr(xp), _ptr(xcol), cq2, _stream(xp))
     L.check(rc, 'qk_conv_fold_taps')
     w2 = torch.nn.functional.pad(kernel.reshape(taps * cq, kernel.shape[-1]), (0, 0, 0, cq2 - taps * cq))
@@ -279,7 +306,7 @@ def adam_step(param, grad, m, v, step, lr=0.001, beta1=0.9, beta2=0.999, eps=1e-
         if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
             raise RuntimeError('adam_step needs contiguous float32 device buffers')
     n = param.numel()
-    with torch.cuda.device(param.device):
+    with _on_device(param.device):
         rc = L.lib().qk_adam_step(_ptr(param), _ptr(grad), _ptr(m), _ptr(v), n, lr, beta1, beta2, eps,
                                   int(step), grad_scale, _stream(param))
     L.check(rc, 'qk_adam_step')
