@@ -71,6 +71,7 @@ struct WgradGeom {
     int m_per_split;    // rows of M each split reduces (multiple of the kernel's K step)
     int n_splits;
     int ablate;         // profiling only (env QK_ABLATE): 1 = skip fold + atomics, 2 = skip HBM atomics
+    unsigned x_bytes, dy_bytes;   // extents of x and of dy / y / dym (buffer-resource bounds of the 16-bit kernel)
     void *dym;          // optional output: dy with the relu mask applied (same layout/dtype as dy), or NULL;
                         // written by the blocks of tap 0 / channel chunk 0, which see every (row, filter) once
 };

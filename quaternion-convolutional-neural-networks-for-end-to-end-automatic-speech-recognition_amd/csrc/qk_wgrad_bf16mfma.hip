@@ -46,15 +46,33 @@ __device__ __forceinline__ v8s tr_frag(const char *base, int pitch)
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-// component-wise select: `ok ? v : zero` on whole uint4s makes hipcc select between two ADDRESSES
-// and park both operands in scratch
-__device__ __forceinline__ uint4 keep_if(bool ok, const uint4 &v)
+// Staging goes through buffer resources: `buffer_load_dwordx4 v, voffset, s[rsrc], soffset offen`
+// takes a 32-bit per-lane byte offset plus a wave-uniform one, so a load costs no address VALU at all
+// (flat 64-bit pointers cost ~4 VALU per load here), and an offset beyond the resource's extent
+// returns zeros -- padding rows and rows past the split need no select afterwards.  The kernel was
+// VALU-bound on exactly that work: 291 VALU per wave and K step next to 32 MFMAs (PMC).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned kOutOfRange = 0xF0000000u;          // > every extent try_wgrad_16 admits
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, unsigned bytes)
 {
-    return make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void buf_store16(const uint4 &d, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+    u32x4 v; v.x = d.x; v.y = d.y; v.z = d.z; v.w = d.w;
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)voff, (int)soff, 0);
 }
 
 // keep the 16-bit halves of v whose mask half is non-zero.  The mask is this layer's RELU output
 // (include/qk.h), i.e. >= +0, so "non-zero" == "> 0": v_pk_min_u16, v_pk_mul_lo_u16, v_and.
+// (Two tempting shortcuts do not survive: `v * min(m, 1)` is turned into compare + select + permute
+// by hipcc, 5.5 VALU per dword; the same two instructions as inline asm stored a stale first dword
+// on some lanes -- the hazard recogniser does not see through the asm.)
 typedef unsigned short u2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned relu_keep2(unsigned v, unsigned m)
 {
@@ -118,10 +136,19 @@ k_wgrad16(const T *__restrict__ x, const T *__restrict__ dy, const T *__restrict
     static_assert(UXR % TPROW == 0 && UDR % TPROW == 0, "units per thread");
     const int s_row = tid / TPROW, s_sub = tid % TPROW;
     uint4 xr[UX], dr[UD], mr[MASK ? UD : 1];
-    // The register stage holds tile j+1 while tile j is multiplied; (x_ok, d_ok, d_e0) describe the
-    // tile in the registers, (nx_ok, nd_ok, nxo, nyo) the tile the next loads fetch.
-    bool x_ok = false, d_ok = false, nx_ok = false, nd_ok = false;
-    int d_e0 = 0, nxo = 0, nyo = 0;
+    // Per-lane byte offsets into the buffer resources: the register stage holds tile j+1 while tile j
+    // is multiplied; `vd_cur` is the dY offset of the tile in the registers (masked-dY store), nvx / nvd
+    // those of the tile the next loads fetch.  Rows outside the tensor or the split get kOutOfRange.
+    constexpr int UC = BC / 8, UF = BF / 8;                  // 16-byte units per component block
+    static_assert(TPROW % UC == 0 && TPROW % UF == 0, "unit -> (component, channel group) must split per thread");
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, g.x_bytes), rdy = make_rsrc(dy, g.dy_bytes);
+    const __amdgpu_buffer_rsrc_t ry = make_rsrc(MASK ? ymask : dy, g.dy_bytes);
+    const __amdgpu_buffer_rsrc_t rdym = make_rsrc(g.dym ? g.dym : dy, g.dym ? g.dy_bytes : 0u);
+    const unsigned x_thr = (unsigned)((s_sub / UC) * g.Cq + c0 + (s_sub % UC) * 8) * 2u;
+    const unsigned d_thr = (unsigned)((s_sub / UF) * g.F + f0 + (s_sub % UF) * 8) * 2u;
+    const unsigned x_ustep = (unsigned)((TPROW / UC) * g.Cq) * 2u;     // unit u: + u * x_ustep (wave-uniform)
+    const unsigned d_ustep = (unsigned)((TPROW / UF) * g.F) * 2u;
+    unsigned nvx = kOutOfRange, nvd = kOutOfRange, vd_cur = kOutOfRange;
     // position of this thread's row, advanced by KM rows per decode (no divisions in the loop)
     int r_n, r_o0, r_o1, r_o2;
     {
@@ -133,18 +160,17 @@ k_wgrad16(const T *__restrict__ x, const T *__restrict__ dy, const T *__restrict
     }
     const bool dym_blk = MASK && g.dym != nullptr && cchunk == 0;
     int dym_turn = t;                                        // same rotation for the staged tiles
-    T *dym = static_cast<T *>(g.dym);
 
     auto decode_next = [&](int mb) {
         const int m = mb + s_row;
-        nd_ok = m < m_end;
+        const bool d_in = m < m_end;
         const int i0 = r_o0 * g.pa[0] + t0 * g.pb[0] + g.pc[0];
         const int i1 = r_o1 * g.pa[1] + t1 * g.pb[1] + g.pc[1];
         const int i2 = r_o2 * g.pa[2] + t2 * g.pb[2] + g.pc[2];
-        nx_ok = nd_ok && i0 >= 0 && i0 < g.isp[0] && i1 >= 0 && i1 < g.isp[1] && i2 >= 0 && i2 < g.isp[2];
+        const bool x_in = d_in && i0 >= 0 && i0 < g.isp[0] && i1 >= 0 && i1 < g.isp[1] && i2 >= 0 && i2 < g.isp[2];
         const int xo = r_n * (int)g.x_sn + i0 * (int)g.x_ss[0] + i1 * (int)g.x_ss[1] + i2 * (int)g.x_ss[2];
-        nxo = nx_ok ? xo : 0;
-        nyo = nd_ok ? m * (int)g.dy_ss : 0;
+        nvx = x_in ? (unsigned)xo * 2u + x_thr : kOutOfRange;
+        nvd = d_in ? (unsigned)(m * (int)g.dy_ss) * 2u + d_thr : kOutOfRange;
         // next call: KM rows further.  Carry-propagate when the innermost extent is long (images);
         // re-decode with divisions when it is short (dense layers, 1-D convolutions: osp[2] == 1)
         if (g.osp[2] >= KM) {
@@ -155,9 +181,9 @@ k_wgrad16(const T *__restrict__ x, const T *__restrict__ dy, const T *__restrict
             const bool c1 = r_o1 == g.osp[1];
             r_o1 = c1 ? 0 : r_o1;
             r_o0 += c1 ? 1 : 0;
-            const bool c0 = r_o0 == g.osp[0];
-            r_o0 = c0 ? 0 : r_o0;
-            r_n += c0 ? 1 : 0;
+            const bool c0_ = r_o0 == g.osp[0];
+            r_o0 = c0_ ? 0 : r_o0;
+            r_n += c0_ ? 1 : 0;
         } else {
             int s = m + KM;
             r_o2 = s % g.osp[2]; s /= g.osp[2];
@@ -166,34 +192,38 @@ k_wgrad16(const T *__restrict__ x, const T *__restrict__ dy, const T *__restrict
             r_n = s / g.osp[0];
         }
     };
-    auto commit_next = [&]() { x_ok = nx_ok; d_ok = nd_ok; d_e0 = nyo; };
+    auto commit_next = [&]() { vd_cur = nvd; };
     // unit u of the staged pair (X units first, then dY): one 16-byte load / one 16-byte LDS store
     auto load_unit = [&](int u) {
         if (u < UX) {
-            const int q = s_sub + u * TPROW;
-            xr[u] = *reinterpret_cast<const uint4 *>(x + nxo + (q / (BC / 8)) * g.Cq + c0 + (q % (BC / 8)) * 8);
+            xr[u] = buf_load16(rx, nvx, u * x_ustep);
         } else {
-            const int i = u - UX, q = s_sub + i * TPROW;
-            const int e = nyo + (q / (BF / 8)) * g.F + f0 + (q % (BF / 8)) * 8;
-            dr[i] = *reinterpret_cast<const uint4 *>(dy + e);
-            if constexpr (MASK) mr[i] = *reinterpret_cast<const uint4 *>(ymask + e);
+            const int i = u - UX;
+            dr[i] = buf_load16(rdy, nvd, i * d_ustep);
+            if constexpr (MASK) mr[i] = buf_load16(ry, nvd, i * d_ustep);
         }
     };
     auto store_unit = [&](int u, int buf, bool write_dym) {
         if (u < UX) {
             char *xs = lds + buf * BUF + s_row * XROW;
-            *reinterpret_cast<uint4 *>(xs + (s_sub + u * TPROW) * 16) = keep_if(x_ok, xr[u]);
+            *reinterpret_cast<uint4 *>(xs + (s_sub + u * TPROW) * 16) = xr[u];
         } else {
             const int i = u - UX, q = s_sub + i * TPROW;
             char *ds = lds + buf * BUF + KM * XROW + s_row * DROW;
-            uint4 v = keep_if(d_ok, dr[i]);
+            uint4 v = dr[i];
             if constexpr (MASK)
                 v = make_uint4(relu_keep2(v.x, mr[i].x), relu_keep2(v.y, mr[i].y), relu_keep2(v.z, mr[i].z),
                                relu_keep2(v.w, mr[i].w));
             *reinterpret_cast<uint4 *>(ds + q * 16) = v;
             if constexpr (MASK) {
-                if (write_dym && d_ok)
-                    *reinterpret_cast<uint4 *>(dym + d_e0 + (q / (BF / 8)) * g.F + f0 + (q % (BF / 8)) * 8) = v;
+                if (write_dym) {
+                    buf_store16(v, rdym, vd_cur, i * d_ustep);                // rows past the split: dropped
+                    // A 16-byte buffer store reads its data registers for many cycles after issue.  hipcc
+                    // pads a following VALU write of them with 2 wait states (none when soffset is an
+                    // SGPR); on gfx950 that corrupted the first dwords on some lanes (the registers are
+                    // reused as address temporaries right away).  16 wait states, on 1/taps of the steps.
+                    asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+                }
             }
         }
     };
@@ -361,6 +391,8 @@ int run_wgrad16(const T *x, const T *dy, const T *ymask, float *dw, float *dbias
     splits = (g.M + mps - 1) / mps;
     g.m_per_split = (int)mps;
     g.n_splits = (int)splits;
+    g.x_bytes = (unsigned)((long long)g.batch * g.x_sn * 2);
+    g.dy_bytes = (unsigned)((long long)g.M * g.dy_ss * 2);
     g.ablate = 0;
     const long long n_tiles = splits * other;
     dim3 grid((unsigned)((n_tiles + 7) / 8 * 8), 1, 1);      // padded to the 8 XCDs (see the tile remap)
@@ -395,6 +427,8 @@ int try_wgrad_16(int dtype, const void *x, const void *dy, const void *ymask, fl
     if (dtype != QK_BF16 && dtype != QK_F16) return 0;
     if (g.x_sc != 1 || g.dy_sc != 1) return 0;                         // channels_last buffers only
     if (g.Cq % 32 != 0 || g.F % 32 != 0) return 0;
+    // buffer-resource addressing: 32-bit byte offsets, kOutOfRange must stay beyond every extent
+    if ((long long)g.batch * g.x_sn * 2 >= 0xF0000000ll || (long long)g.M * g.dy_ss * 2 >= 0xF0000000ll) return 0;
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(ymask)) & 15) return 0;
     if (getenv("QK_NO_MFMA16")) return 0;
     if (dtype == QK_BF16) return go_wgrad16<bf16>(x, dy, ymask, dw, dbias, g, stream);

@@ -342,6 +342,37 @@ def test_masked_dy_side_output_and_fused_backward_agree():
             assert _rel_err(got.float().cpu().numpy(), ref.float().cpu().numpy()) <= tol
 
 
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16], ids=['bf16', 'fp16'])
+@pytest.mark.parametrize('xs,ws', [((2, 14, 40, 128), (3, 5, 32, 128)), ((1, 14, 40, 256), (3, 5, 64, 256)),
+                                   ((1, 9, 33, 128), (3, 3, 32, 256)), ((3, 70, 256), (5, 64, 128))],
+                         ids=['32to32', '64to64', '32to64', 'conv1d_64to32'])
+def test_masked_dy_side_output_is_bit_exact_and_repeatable(xs, ws, dtype):
+    """dy * (y > 0) is a pure selection, so the side output of the 16-bit backward-weight kernel must
+    equal torch.where bit for bit on every run (a store-data hazard once corrupted a few lanes of it,
+    non-deterministically; gradients themselves were unaffected)."""
+    import qcnn_amd
+    F = qcnn_amd.functional
+    dev = _dev()
+    g = torch.Generator(device=dev).manual_seed(3)
+    rank = len(xs) - 2
+    x = torch.randn(xs, device=dev, generator=g).to(dtype)
+    w = torch.randn(ws, device=dev, generator=g) / 20
+    b = torch.randn(ws[-1], device=dev, generator=g) / 10
+    call = F.conv_call(tuple(xs), tuple(ws), dtype, rank, 1, 'same', 'channels_last', 1, 'relu', True)
+    y = call.fwd(x, w, b)
+    dy = torch.randn(y.shape, device=dev, generator=g).to(dtype)
+    want = torch.where(y > 0, dy, torch.zeros_like(dy))
+    dw0 = None
+    for rep in range(10):
+        dym = torch.full(((dy.numel() + 127) // 128 * 128,), 7.0, dtype=dtype, device=dev)
+        dw, db = call.bwd_weight(x, dy, y, True, masked_dy_out=dym)
+        assert torch.equal(dym[:dy.numel()].view_as(dy), want), 'run %d' % rep
+        assert bool((dym[dy.numel():] == 7.0).all()), 'wrote past the end of dy'
+        if dw0 is None:
+            dw0 = dw.clone()
+        assert _rel_err(dw.cpu().numpy(), dw0.cpu().numpy()) <= 1e-5      # atomics: order varies, values barely
+
+
 def test_adam_step_matches_keras_formula():
     import qcnn_amd
     dev = _dev()
