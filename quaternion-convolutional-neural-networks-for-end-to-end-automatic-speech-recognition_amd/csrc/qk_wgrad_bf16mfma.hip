@@ -80,13 +80,18 @@ __device__ __forceinline__ unsigned relu_keep2(unsigned v, unsigned m)
     return v & __builtin_bit_cast(unsigned, (u2v)(one * (u2v)(0xffff)));
 }
 
-template <typename T, int WR, int WC, int TN, bool MASK>
+// TG = taps per block.  With 32 input channels a (tap, all channels) block is only 128 rows tall;
+// two taps side by side ("virtual channels" [tap member][component][channel]) restore the 256-row
+// tile: the dY / Y tiles are then staged once for two taps (half the L2 traffic and half the mask
+// VALU per MFMA).  A group's missing last tap is staged as zeros.
+template <typename T, int WR, int WC, int TN, int TG, bool MASK>
 __global__ void __launch_bounds__(WR * WC * 64) __attribute__((amdgpu_waves_per_eu(WR * WC / 4, 2)))
 k_wgrad16(const T *__restrict__ x, const T *__restrict__ dy, const T *__restrict__ ymask,
           float *__restrict__ dw, float *__restrict__ dbias, const WgradGeom g)
 {
     constexpr int NW = WR * WC, NTHR = NW * 64;
-    constexpr int BC = WR * 16;                 // quaternion input channels per block (rows = 4*BC)
+    constexpr int BC = WR * 16;                 // "virtual" quaternion input channels per block (rows = 4*BC)
+    constexpr int BCQ = BC / TG;                // real input channels per block and tap
     constexpr int BF = WC * TN * 8;             // quaternion filters per block      (cols = 4*BF)
     constexpr int KM = 64;                      // rows of M per K step
     constexpr int XROW = 4 * BC * 2 + 64;       // bytes per tile row (64 B pad: see header)
@@ -94,6 +99,7 @@ k_wgrad16(const T *__restrict__ x, const T *__restrict__ dy, const T *__restrict
     constexpr int BUF = KM * (XROW + DROW);
     constexpr int FOLD = BC * 4 * BF * 4;
     static_assert(2 * BUF >= FOLD, "fold slab reuses the tile buffers");
+    static_assert(BCQ % 32 == 0, "a 32-row MFMA tile must lie inside one (tap member, component)");
     __shared__ __attribute__((aligned(16))) char lds[2 * BUF];
 
     const int tid = threadIdx.x;
@@ -104,27 +110,35 @@ k_wgrad16(const T *__restrict__ x, const T *__restrict__ dy, const T *__restrict
     // one split of M sit next to each other on one XCD, so the dY / X rows they all read are served
     // by that XCD's L2 (without this the 30 blocks of a split re-fetch them from HBM: 7x over-fetch).
     const int nfc = g.F / BF;
-    const int n_inner = g.taps * (g.Cq / BC) * nfc;
+    const int n_grp = (g.taps + TG - 1) / TG;   // tap groups
+    const int n_inner = n_grp * (g.Cq / BCQ) * nfc;
     const int n_tiles = n_inner * g.n_splits;
     const int per_xcd = (n_tiles + 7) / 8;
     const int tile = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
     if (tile >= n_tiles) return;
     const int split = tile / n_inner;
     const int inner = tile - split * n_inner;
-    const int t = inner % g.taps;
-    const int chunk = inner / g.taps;
+    const int t = inner % n_grp;                // tap group of this block
+    const int chunk = inner / n_grp;
     const int cchunk = chunk / nfc;
     const int fchunk = chunk - cchunk * nfc;
-    const int c0 = cchunk * BC, f0 = fchunk * BF;
-    const int t2 = t % g.ks[2];
-    const int tt = t / g.ks[2];
-    const int t1 = tt % g.ks[1];
-    const int t0 = tt / g.ks[1];
+    const int c0 = cchunk * BCQ, f0 = fchunk * BF;
+    int tp0[TG], tp1[TG], tp2[TG];              // kernel position of each member tap
+    bool tp_ok[TG];
+#pragma unroll
+    for (int mbr = 0; mbr < TG; ++mbr) {
+        const int tm = t * TG + mbr;
+        tp_ok[mbr] = tm < g.taps;
+        tp2[mbr] = tm % g.ks[2];
+        const int tt = tm / g.ks[2];
+        tp1[mbr] = tt % g.ks[1];
+        tp0[mbr] = tt / g.ks[1];
+    }
     const int m_begin = split * g.m_per_split;
     const int m_end = min(g.M, m_begin + g.m_per_split);
-    // dbias and the masked-dY side output need every dY row exactly once.  The `taps` blocks of one
-    // (split, filter chunk) all stage the same dY tiles, so they take turns: tap block t owns the K
-    // steps with step % taps == t.  (One owner block would run ~30 % longer than its peers and, with
+    // dbias and the masked-dY side output need every dY row exactly once.  The tap-group blocks of one
+    // (split, filter chunk) all stage the same dY tiles, so they take turns: group block t owns the K
+    // steps with step % n_grp == t.  (One owner block would run ~30 % longer than its peers and, with
     // one workgroup per CU, set the kernel time.)
     const bool bias_blk = g.want_dbias && cchunk == 0;
     int bias_turn = t;                                       // 0 => this K step is ours
@@ -139,16 +153,21 @@ k_wgrad16(const T *__restrict__ x, const T *__restrict__ dy, const T *__restrict
     // Per-lane byte offsets into the buffer resources: the register stage holds tile j+1 while tile j
     // is multiplied; `vd_cur` is the dY offset of the tile in the registers (masked-dY store), nvx / nvd
     // those of the tile the next loads fetch.  Rows outside the tensor or the split get kOutOfRange.
-    constexpr int UC = BC / 8, UF = BF / 8;                  // 16-byte units per component block
-    static_assert(TPROW % UC == 0 && TPROW % UF == 0, "unit -> (component, channel group) must split per thread");
+    constexpr int UC = BCQ / 8, UF = BF / 8;                 // 16-byte units per component block
+    constexpr int UM = 4 * UC;                               // units per tap member of an X row
+    static_assert(TPROW % UC == 0 && UM % TPROW == 0 && TPROW % UF == 0,
+                  "unit -> (member, component, channel group) must split into a per-thread and a per-unit part");
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, g.x_bytes), rdy = make_rsrc(dy, g.dy_bytes);
     const __amdgpu_buffer_rsrc_t ry = make_rsrc(MASK ? ymask : dy, g.dy_bytes);
     const __amdgpu_buffer_rsrc_t rdym = make_rsrc(g.dym ? g.dym : dy, g.dym ? g.dy_bytes : 0u);
+    // X unit q = s_sub + u*TPROW of a row: member q / UM, component (q % UM) / UC, channel group q % UC
     const unsigned x_thr = (unsigned)((s_sub / UC) * g.Cq + c0 + (s_sub % UC) * 8) * 2u;
     const unsigned d_thr = (unsigned)((s_sub / UF) * g.F + f0 + (s_sub % UF) * 8) * 2u;
-    const unsigned x_ustep = (unsigned)((TPROW / UC) * g.Cq) * 2u;     // unit u: + u * x_ustep (wave-uniform)
+    const unsigned x_cstep = (unsigned)g.Cq * 2u;            // one component further (wave-uniform)
     const unsigned d_ustep = (unsigned)((TPROW / UF) * g.F) * 2u;
-    unsigned nvx = kOutOfRange, nvd = kOutOfRange, vd_cur = kOutOfRange;
+    unsigned nvx[TG], nvd = kOutOfRange, vd_cur = kOutOfRange;
+#pragma unroll
+    for (int mbr = 0; mbr < TG; ++mbr) nvx[mbr] = kOutOfRange;
     // position of this thread's row, advanced by KM rows per decode (no divisions in the loop)
     int r_n, r_o0, r_o1, r_o2;
     {
@@ -164,12 +183,16 @@ k_wgrad16(const T *__restrict__ x, const T *__restrict__ dy, const T *__restrict
     auto decode_next = [&](int mb) {
         const int m = mb + s_row;
         const bool d_in = m < m_end;
-        const int i0 = r_o0 * g.pa[0] + t0 * g.pb[0] + g.pc[0];
-        const int i1 = r_o1 * g.pa[1] + t1 * g.pb[1] + g.pc[1];
-        const int i2 = r_o2 * g.pa[2] + t2 * g.pb[2] + g.pc[2];
-        const bool x_in = d_in && i0 >= 0 && i0 < g.isp[0] && i1 >= 0 && i1 < g.isp[1] && i2 >= 0 && i2 < g.isp[2];
-        const int xo = r_n * (int)g.x_sn + i0 * (int)g.x_ss[0] + i1 * (int)g.x_ss[1] + i2 * (int)g.x_ss[2];
-        nvx = x_in ? (unsigned)xo * 2u + x_thr : kOutOfRange;
+        const int xb = r_n * (int)g.x_sn;
+#pragma unroll
+        for (int mbr = 0; mbr < TG; ++mbr) {
+            const int i0 = r_o0 * g.pa[0] + tp0[mbr] * g.pb[0] + g.pc[0];
+            const int i1 = r_o1 * g.pa[1] + tp1[mbr] * g.pb[1] + g.pc[1];
+            const int i2 = r_o2 * g.pa[2] + tp2[mbr] * g.pb[2] + g.pc[2];
+            const bool x_in = d_in && tp_ok[mbr] && i0 >= 0 && i0 < g.isp[0] && i1 >= 0 && i1 < g.isp[1] && i2 >= 0 && i2 < g.isp[2];
+            const int xo = xb + i0 * (int)g.x_ss[0] + i1 * (int)g.x_ss[1] + i2 * (int)g.x_ss[2];
+            nvx[mbr] = x_in ? (unsigned)xo * 2u + x_thr : kOutOfRange;
+        }
         nvd = d_in ? (unsigned)(m * (int)g.dy_ss) * 2u + d_thr : kOutOfRange;
         // next call: KM rows further.  Carry-propagate when the innermost extent is long (images);
         // re-decode with divisions when it is short (dense layers, 1-D convolutions: osp[2] == 1)
@@ -196,7 +219,7 @@ k_wgrad16(const T *__restrict__ x, const T *__restrict__ dy, const T *__restrict
     // unit u of the staged pair (X units first, then dY): one 16-byte load / one 16-byte LDS store
     auto load_unit = [&](int u) {
         if (u < UX) {
-            xr[u] = buf_load16(rx, nvx, u * x_ustep);
+            xr[u] = buf_load16(rx, nvx[(u * TPROW) / UM], (((u * TPROW) % UM) / UC) * x_cstep);
         } else {
             const int i = u - UX;
             dr[i] = buf_load16(rdy, nvd, i * d_ustep);
@@ -229,7 +252,7 @@ k_wgrad16(const T *__restrict__ x, const T *__restrict__ dy, const T *__restrict
     };
     auto dym_now = [&]() {
         const bool w = dym_blk && dym_turn == 0;
-        dym_turn = dym_turn == 0 ? g.taps - 1 : dym_turn - 1;
+        dym_turn = dym_turn == 0 ? n_grp - 1 : dym_turn - 1;
         return w;
     };
 
@@ -278,7 +301,7 @@ k_wgrad16(const T *__restrict__ x, const T *__restrict__ dy, const T *__restrict
             const char *tb = lds + (it & 1) * BUF;
             const int nb = (it + 1) & 1;
             const bool bias_now = bias_blk && bias_turn == 0;
-            bias_turn = bias_turn == 0 ? g.taps - 1 : bias_turn - 1;
+            bias_turn = bias_turn == 0 ? n_grp - 1 : bias_turn - 1;
             if (bias_now && tid < 4 * BF) {
                 const T *col = reinterpret_cast<const T *>(tb + KM * XROW) + tid;
 #pragma unroll 8
@@ -324,8 +347,9 @@ k_wgrad16(const T *__restrict__ x, const T *__restrict__ dy, const T *__restrict
     for (int ph = 0; ph < 4; ++ph) {
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
-            const int rowbase = (wr * 2 + rt) * 32;
-            if (rowbase / BC != ph) continue;                         // wave-uniform: BC is 32 or 64
+            const int rowbase = (wr * 2 + rt) * 32;                    // rows: [member][component][BCQ]
+            if ((rowbase / BCQ) % 4 != ph) continue;                  // wave-uniform: BCQ is 32 or 64
+            const int mbr = rowbase / (4 * BCQ);
 #pragma unroll
             for (int ct = 0; ct < TN; ++ct) {
                 const int col = (wc * TN + ct) * 32 + lr;
@@ -334,9 +358,9 @@ k_wgrad16(const T *__restrict__ x, const T *__restrict__ dy, const T *__restrict
                 const bool neg = (g.sign_tbl >> (ph * 4 + b)) & 1u;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int cc = (rowbase + mfma32_row(r, lane)) % BC;
+                    const int cc = (rowbase + mfma32_row(r, lane)) % BCQ;
                     const float v = neg ? -acc[rt][ct][r] : acc[rt][ct][r];
-                    float *dst = &slab[(cc * 4 + p) * BF + ff];
+                    float *dst = &slab[((mbr * BCQ + cc) * 4 + p) * BF + ff];
                     *dst = ph == 0 ? v : *dst + v;
                 }
             }
@@ -346,8 +370,10 @@ k_wgrad16(const T *__restrict__ x, const T *__restrict__ dy, const T *__restrict
     for (int e = tid; e < BC * 4 * BF; e += NTHR) {
         const int ff = e % BF;
         const int p = (e / BF) & 3;
-        const int cc = e / (4 * BF);
-        atomicAdd(dw + ((t * g.Cq + c0 + cc) * 4 + p) * g.F + f0 + ff, slab[e]);
+        const int cv = e / (4 * BF);                                    // virtual channel: member * BCQ + cc
+        const int tm = t * TG + cv / BCQ;
+        if (tm < g.taps)
+            atomicAdd(dw + ((tm * g.Cq + c0 + cv % BCQ) * 4 + p) * g.F + f0 + ff, slab[e]);
     }
     if (bias_blk && tid < 4 * BF) {
         const int b = tid / BF, ff = tid % BF;
@@ -355,13 +381,13 @@ k_wgrad16(const T *__restrict__ x, const T *__restrict__ dy, const T *__restrict
     }
 }
 
-template <typename T, int WR, int WC, int TN>
+template <typename T, int WR, int WC, int TN, int TG>
 int run_wgrad16(const T *x, const T *dy, const T *ymask, float *dw, float *dbias, WgradGeom g,
                 hipStream_t stream)
 {
-    constexpr int BC = WR * 16, BF = WC * TN * 8, KM = 64;
-    const int ncc = g.Cq / BC, nfc = g.F / BF;
-    const long long other = (long long)ncc * nfc * g.taps;
+    constexpr int BCQ = WR * 16 / TG, BF = WC * TN * 8, KM = 64;
+    const int ncc = g.Cq / BCQ, nfc = g.F / BF;
+    const long long other = (long long)ncc * nfc * ((g.taps + TG - 1) / TG);
     const long long max_splits = ((long long)g.M + KM - 1) / KM;
     // Split M so that the grid fills a whole number of residency rounds: with 144 KB of LDS there is
     // one workgroup per CU, and e.g. 780 equal tiles on 256 CUs take four rounds, the last 5 % full.
@@ -370,7 +396,7 @@ int run_wgrad16(const T *x, const T *dy, const T *ymask, float *dw, float *dbias
         int dev = 0, n_cu = 0, per_cu = 0;
         if (hipGetDevice(&dev) != hipSuccess ||
             hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_wgrad16<T, WR, WC, TN, true>, WR * WC * 64, 0) != hipSuccess)
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_wgrad16<T, WR, WC, TN, TG, true>, WR * WC * 64, 0) != hipSuccess)
             return QK_ERR_LAUNCH;
         slots = (n_cu > 0 ? n_cu : 256) * (per_cu > 0 ? per_cu : 1);
     }
@@ -397,9 +423,9 @@ int run_wgrad16(const T *x, const T *dy, const T *ymask, float *dw, float *dbias
     const long long n_tiles = splits * other;
     dim3 grid((unsigned)((n_tiles + 7) / 8 * 8), 1, 1);      // padded to the 8 XCDs (see the tile remap)
     if (g.has_mask)
-        hipLaunchKernelGGL((k_wgrad16<T, WR, WC, TN, true>), grid, dim3(WR * WC * 64), 0, stream, x, dy, ymask, dw, dbias, g);
+        hipLaunchKernelGGL((k_wgrad16<T, WR, WC, TN, TG, true>), grid, dim3(WR * WC * 64), 0, stream, x, dy, ymask, dw, dbias, g);
     else
-        hipLaunchKernelGGL((k_wgrad16<T, WR, WC, TN, false>), grid, dim3(WR * WC * 64), 0, stream, x, dy, ymask, dw, dbias, g);
+        hipLaunchKernelGGL((k_wgrad16<T, WR, WC, TN, TG, false>), grid, dim3(WR * WC * 64), 0, stream, x, dy, ymask, dw, dbias, g);
     return hipGetLastError() == hipSuccess ? 1 : QK_ERR_LAUNCH;
 }
 
@@ -408,13 +434,19 @@ int go_wgrad16(const void *x, const void *dy, const void *ymask, float *dw, floa
                hipStream_t stream)
 {
     const T *xp = (const T *)x, *dp = (const T *)dy, *yp = (const T *)ymask;
+    const bool one_tap = getenv("QK_WGRAD16_ONE_TAP") != nullptr;     // tuning aid: the TG = 1 tilings only
     if (g.Cq % 64 == 0) {
-        if (g.F % 64 == 0) return run_wgrad16<T, 4, 2, 4>(xp, dp, yp, dw, dbias, g, stream);
-        return run_wgrad16<T, 4, 2, 2>(xp, dp, yp, dw, dbias, g, stream);
+        if (g.F % 64 == 0) return run_wgrad16<T, 4, 2, 4, 1>(xp, dp, yp, dw, dbias, g, stream);
+        return run_wgrad16<T, 4, 2, 2, 1>(xp, dp, yp, dw, dbias, g, stream);
     }
-    // 32-channel chunks: 8 waves of 64 x 64 (two per SIMD) rather than 4 waves of 64 x 128
-    if (g.F % 64 == 0) return run_wgrad16<T, 2, 4, 2>(xp, dp, yp, dw, dbias, g, stream);
-    return run_wgrad16<T, 2, 2, 2>(xp, dp, yp, dw, dbias, g, stream);
+    // 32-channel chunks: two taps per block make the same 256-row tiles (dY staged once for both)
+    if (g.taps > 1 && !one_tap) {
+        if (g.F % 64 == 0) return run_wgrad16<T, 4, 2, 4, 2>(xp, dp, yp, dw, dbias, g, stream);
+        return run_wgrad16<T, 4, 2, 2, 2>(xp, dp, yp, dw, dbias, g, stream);
+    }
+    // single tap (dense layers, 1x1 convolutions): 8 waves of 64 x 64 rather than 4 waves of 64 x 128
+    if (g.F % 64 == 0) return run_wgrad16<T, 2, 4, 2, 1>(xp, dp, yp, dw, dbias, g, stream);
+    return run_wgrad16<T, 2, 2, 2, 1>(xp, dp, yp, dw, dbias, g, stream);
 }
 
 }  // namespace
