@@ -255,6 +255,8 @@ def quaternion_conv(x, kernel, bias=None, strides=1, padding='valid', data_forma
     _check_weights(kernel, bias, kernel.shape[-1])
     ch_first = data_format == 'channels_first'
     taps, cq = int(math.prod(kernel.shape[:rank])), kernel.shape[-2]
+    if x.shape[0] == 0:
+        return _empty_batch(x, kernel, bias, rank, strides, padding, data_format, dilation_rate)
     if fold_small_cq and cq <= 2 and taps > 1 and taps * cq <= 64 and not x.requires_grad and not conj:
         return _folded_conv(x, kernel, bias, rank, strides, padding, data_format, dilation_rate, activation,
                             internal_layout)
@@ -270,6 +272,22 @@ def quaternion_conv(x, kernel, bias=None, strides=1, padding='valid', data_forma
     if ch_first and internal_layout == 'channels_last':
         y = y.movedim(-1, 1)
     return y
+
+
+def _empty_batch(x, kernel, bias, rank, strides, padding, data_format, dilation_rate):
+    """Zero samples: Keras returns an empty tensor of the right shape (and zero gradients); there is
+    nothing to launch."""
+    ch_first = data_format == 'channels_first'
+    ks = tuple(kernel.shape[:rank])
+    st, dl = normalize_tuple(strides, rank, 'strides'), normalize_tuple(dilation_rate, rank, 'dilation_rate')
+    sp = x.shape[2:] if ch_first else x.shape[1:-1]
+    out = tuple(conv_output_length(sp[i], ks[i], padding, st[i], dl[i]) for i in range(rank))
+    shape = (0, kernel.shape[-1]) + out if ch_first else (0,) + out + (kernel.shape[-1],)
+    y = torch.zeros(shape, dtype=x.dtype, device=x.device)
+    tie = x.sum() * 0 + (kernel.sum() * 0).to(x.dtype)          # keeps autograd connected: zero gradients
+    if bias is not None:
+        tie = tie + (bias.sum() * 0).to(x.dtype)
+    return y + tie
 
 
 def _folded_conv(x, kernel, bias, rank, strides, padding, data_format, dilation_rate, activation, internal_layout):
@@ -295,6 +313,9 @@ def quaternion_dense(x, kernel, bias=None, activation=None):
     """y = act(conj(W) (x) x + b) -- the table dense.py:139-143 builds (transpose of conv's)."""
     _require_device(x, 'quaternion_dense')
     _check_weights(kernel, bias, kernel.shape[-1])
+    if x.shape[0] == 0:
+        tie = x.sum() * 0 + (kernel.sum() * 0).to(x.dtype) + ((bias.sum() * 0).to(x.dtype) if bias is not None else 0)
+        return torch.zeros((0, kernel.shape[-1]), dtype=x.dtype, device=x.device) + tie
     xp = x.contiguous()
     call = dense_call(tuple(xp.shape), tuple(kernel.shape), xp.dtype, activation, bias is not None)
     return _HamiltonFn.apply(xp, kernel.contiguous(), bias, call)

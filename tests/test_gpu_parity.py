@@ -394,6 +394,49 @@ def test_adam_step_matches_keras_formula():
     assert np.abs(tm.cpu().numpy() - m64).max() <= 1e-6
 
 
+def test_empty_batch_gives_empty_output_and_zero_gradients():
+    import qcnn_amd
+    F = qcnn_amd.functional
+    dev = _dev()
+    for dtype in (torch.float32, torch.bfloat16):
+        x = torch.zeros(0, 9, 11, 8, device=dev, dtype=dtype, requires_grad=True)
+        w = torch.randn(3, 2, 2, 12, device=dev, requires_grad=True)
+        b = torch.zeros(12, device=dev, requires_grad=True)
+        y = F.quaternion_conv(x, w, b, padding='same', strides=(2, 1), activation='relu')
+        assert tuple(y.shape) == (0, 5, 11, 12) and y.dtype == dtype
+        y.sum().backward()
+        assert float(w.grad.abs().max()) == 0.0 and float(b.grad.abs().max()) == 0.0 and x.grad.shape == x.shape
+        yc = F.quaternion_conv(x.detach().permute(0, 3, 1, 2), w.detach(), None, padding='valid',
+                               data_format='channels_first')
+        assert tuple(yc.shape) == (0, 12, 7, 10)
+        xd = torch.zeros(0, 16, device=dev, dtype=dtype)
+        assert tuple(F.quaternion_dense(xd, torch.randn(4, 8, device=dev), None).shape) == (0, 8)
+
+
+RAGGED_CASES = [
+    # rows that do not fill a tile, a kernel wider than the input, single-position outputs, one sample
+    ('one_row', 1, (1, 1, 8), (3, 2, 8), dict(padding='same', activation='relu')),
+    ('kernel_wider_than_input', 1, (2, 3, 16), (7, 4, 8), dict(padding='same', activation=None)),
+    ('valid_to_single_position', 2, (3, 3, 5, 8), (3, 5, 2, 16), dict(padding='valid', activation='relu')),
+    ('m_not_multiple_of_tile', 1, (3, 43, 128), (3, 32, 128), dict(padding='same', activation='relu')),
+    ('causal_dilated', 1, (2, 37, 16), (4, 4, 8), dict(padding='causal', dilation_rate=3, activation='relu')),
+    ('dense_one_row', 0, (1, 128), (32, 128), dict(activation='relu')),
+]
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['fp32', 'bf16'])
+@pytest.mark.parametrize('case', RAGGED_CASES, ids=[c[0] for c in RAGGED_CASES])
+def test_ragged_and_degenerate_shapes_match_oracle(case, dtype):
+    import qcnn_amd
+    _, rank, xs, ws, kw = case
+    x, w, b, dy, want = _oracle_case(rank, xs, ws, kw, seed=5, dtype=dtype)
+    got = _run_layer(qcnn_amd.functional, x, w, b, dy, rank, kw, dtype)
+    tol16, tol32 = (1e-4, 1e-4) if dtype == torch.float32 else (1e-2, 2e-3)
+    for k, v in got.items():
+        err = _rel_err(v, want[k])
+        assert err <= (tol16 if k in ('y', 'dx') else tol32), '%s: rel err %.3g' % (k, err)
+
+
 def test_c_abi_reports_errors_instead_of_faulting():
     import ctypes
     import qcnn_amd
