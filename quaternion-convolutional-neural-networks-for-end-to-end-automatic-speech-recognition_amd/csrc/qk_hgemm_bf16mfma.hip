@@ -199,12 +199,18 @@ k_hgemm16(const T *__restrict__ in, const T *__restrict__ mask, const uint4 *__r
         Bs[tid] = br0;
         if constexpr (BU == 2) Bs[tid + 512] = br1;
     };
+    // The counters never move past the last tile: once it has been fetched, further fetches repeat
+    // it (the K loop issues its loads unconditionally; see below).
+    int next_tile = 0;                                      // tile the counters point at
+    auto advance_if_more = [&]() {
+        if (next_tile + 1 < iters) { advance_loads(); ++next_tile; }
+    };
     auto load_tile = [&]() {
         prep_loads();
 #pragma unroll
         for (int r = 0; r < RPT2; ++r) load_a(r);
         load_b();
-        advance_loads();
+        advance_if_more();
     };
     auto store_tile = [&](int buf) {
 #pragma unroll
@@ -246,7 +252,6 @@ k_hgemm16(const T *__restrict__ in, const T *__restrict__ mask, const uint4 *__r
     if (iters > 1) load_tile();
     __syncthreads();
 
-    int fetched = 2;                                  // tiles whose loads have been issued
     for (int it = 0; it < iters; ++it) {
         const int nb = (it + 1) & 1;
         const uint4 *a_rd = lds + (it & 1) * TILE_U + a_rd0;
@@ -290,7 +295,7 @@ k_hgemm16(const T *__restrict__ in, const T *__restrict__ mask, const uint4 *__r
                     __builtin_amdgcn_sched_barrier(0);
                 }
         }
-        if (fetched < iters) { advance_loads(); ++fetched; }
+        advance_if_more();
         __syncthreads();
     }
 

@@ -16,7 +16,7 @@ from ..layers import Dense, Dropout, MaxPooling2D, PReLU, TimeDistributed, ctc_b
 
 class TimitQCNN(torch.nn.Module):
     def __init__(self, num_layers=10, start_filter=32, act='relu', aact='none', dropout=0.0, l2=0.0,
-                 quat_init='quaternion', internal_layout='channels_last'):
+                 quat_init='quaternion', internal_layout='channels_last', fuse_head=True):
         super(TimitQCNN, self).__init__()
         n, sf = num_layers, start_filter
         if aact != 'none':
@@ -28,6 +28,7 @@ class TimitQCNN(torch.nn.Module):
         dense_args = dict(activation=act, kernel_regularizer=reg, kernel_initializer='random_uniform',
                           bias_initializer='zeros', use_bias=True)
         self.aact, self.rate = aact, dropout
+        self.fuse_head = fuse_head          # first TimeDistributed dense as an (F, 1) convolution (no transpose copy)
         self.conv = QuaternionConv2D(sf, (3, 5), name='conv', **conv_args)
         self.pool = MaxPooling2D(pool_size=(1, 3), padding='same')
         widths = [sf] * (n // 2) + [2 * sf] * (n // 2)
@@ -50,14 +51,41 @@ class TimitQCNN(torch.nn.Module):
         for c in self.convs:
             o = self.drop(self._act(c(o), k))
             k += 1
-        o = o.permute(0, 3, 1, 2)                            # Permute((3,1,2)): (B, T, C, F)
-        o = o.reshape(o.shape[0], o.shape[1], o.shape[2] * o.shape[3])
-        for i, dl in enumerate(self.dense):
-            o = self._act(dl(o), k)
+        first = 0
+        if self.fuse_head and o.is_cuda:
+            o = self._act(self._head_as_conv(o), k)
+            o = self.drop(o)
+            k, first = k + 1, 1
+        else:
+            o = o.permute(0, 3, 1, 2)                        # Permute((3,1,2)): (B, T, C, F)
+            o = o.reshape(o.shape[0], o.shape[1], o.shape[2] * o.shape[3])
+        for i in range(first, len(self.dense)):
+            o = self._act(self.dense[i](o), k)
             k += 1
             if i < 2:
                 o = self.drop(o)
         return self.pred(o)
+
+    def _head_as_conv(self, o):
+        """Permute((3,1,2)) + reshape + TimeDistributed(QuaternionDense) (interspeech_model.py:141-149) on
+        the conv output (B, C, F, T) WITHOUT the 367 MB transpose copy: feature c*F + f of time step t
+        is o[b, c, f, t], so the dense layer is a quaternion convolution with an (F, 1) 'valid' kernel
+        over (F, T) -- same GEMM (K = F*C), same conj(W) (x) x table -- whose kernel is the dense weight
+        r[(cq*F + f), :] re-indexed to [f, 0, cq, :].  Parameters stay the reference's (in_q, units)."""
+        from .. import functional as Fq
+        from ..keras_like import activations
+        dl = self.dense[0].layer
+        b, c, f, t = o.shape
+        if not dl.built:
+            dl._build_device = o.device
+            dl.build((None, c * f))
+        w = dl.r.view(c // 4, f, dl.r.shape[-1]).permute(1, 0, 2).unsqueeze(1)       # (F, 1, Cq, units)
+        name = activations.serialize(dl.activation)
+        fused = name if name in ('linear', 'relu') else 'linear'
+        y = Fq.quaternion_conv(o, w.contiguous(), dl.bias, 1, 'valid', 'channels_first', 1, fused, conj=True)
+        if fused != name:
+            y = dl.activation(y)
+        return y.reshape(b, dl.r.shape[-1], t).permute(0, 2, 1)                      # (B, units, 1, T) -> (B, T, units)
 
     def ctc_loss(self, x, labels, input_length, label_length):
         return ctc_batch_cost(self(x), labels, input_length, label_length)

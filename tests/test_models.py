@@ -138,3 +138,30 @@ def test_timit_qcnn_shapes_and_backward():
     (cost.mean() + reg).backward()
     assert torch.isfinite(model.conv.kernel.grad).all() and torch.isfinite(model.dense[2].layer.r.grad).all()
     assert torch.equal(val(x), model(x))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype,tol', [(torch.float32, 1e-5), (torch.bfloat16, 2e-2)], ids=['fp32', 'bf16'])
+def test_timit_head_as_convolution_equals_permute_reshape_dense(dtype, tol):
+    """TimitQCNN(fuse_head=True) computes Permute + reshape + TimeDistributed(QuaternionDense) as an (F, 1)
+    conj-convolution on the conv output; outputs and every gradient must match the literal path."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    dev = torch.device('cuda:0')
+    from qcnn_amd.models import TimitQCNN
+    x = torch.randn(2, 41, 24, 4, device=dev, generator=torch.Generator(device=dev).manual_seed(1)).to(dtype).permute(0, 3, 1, 2)
+    np.random.seed(3)
+    ref = TimitQCNN(num_layers=2, start_filter=32, act='relu', aact='none', dropout=0.0, fuse_head=False)
+    fused = TimitQCNN(num_layers=2, start_filter=32, act='relu', aact='none', dropout=0.0, fuse_head=True)
+    with torch.no_grad():
+        ref(x), fused(x)                                   # build both, then give them the same weights
+    fused.load_state_dict(ref.state_dict())
+    outs = []
+    for m in (ref, fused):
+        y = m(x)
+        (y.float() * torch.linspace(0.5, 1.5, 62, device=dev)).sum().backward()
+        outs.append((y.detach().float(), m.dense[0].layer.r.grad.clone(), m.dense[0].layer.bias.grad.clone(),
+                     m.convs[1].kernel.grad.clone(), m.conv.kernel.grad.clone()))
+    for a, b in zip(*outs):
+        assert a.shape == b.shape
+        assert float((a - b).abs().max()) <= tol * max(float(a.abs().max()), 1e-6)
