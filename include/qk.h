@@ -21,6 +21,8 @@
  *   qk_conv_bwd / qk_dense_bwd                    the same gradients in one fused call
  *   qk_conv_fold_taps    (no reference counterpart) im2col-style fold that turns a few-channel conv into
  *                        a 1x1 quaternion conv, so the first layer also runs on the MFMA kernels
+ *   qk_maxpool2d_fwd/bwd MaxPooling2D between the TIMIT convolutions (models/interspeech_model.py:99-103),
+ *                        channels_last, non-overlapping windows: HBM-bound helper
  *   qk_adam_step         the Keras Adam update the reference trains with
  *                        (working_example.py:106, keras.optimizers.Adam defaults) applied to a
  *                        flat fp32 parameter buffer -- used by the data-parallel step.
@@ -156,6 +158,24 @@ int qk_dense_bwd_weight(const qk_dense_desc_t *desc, const void *x, const void *
 
 int qk_dense_bwd(const qk_dense_desc_t *desc, const void *x, const void *dy, const void *y, const float *w,
                  void *dx, float *dw, float *dbias, void *workspace, size_t workspace_bytes, void *stream);
+
+/* Max pooling of a channels_last activation (N, H, W, C) -- the layer between the first and second
+ * TIMIT convolutions (MaxPooling2D((1,3), padding='same'), models/interspeech_model.py:99-103), which
+ * on a channels_first quaternion tensor pools the frequency axis.  Not part of the Hamilton product;
+ * it lives here because the engine keeps channels_first tensors physically channels_last and the
+ * framework kernels for that layout run at a third of HBM speed.  Windows must not overlap
+ * (stride == window) and TensorFlow's padding must fall on the high side only ('valid', or 'same'
+ * with no low-side padding): a partial last window simply ignores the missing elements.
+ * Ties go to the first maximum in (h, w) window order, NaN propagates (torch / TF semantics).
+ * bwd recomputes the arg-max from x (no index tensor) and writes EVERY element of dx. */
+typedef struct {
+    int32_t batch, in_h, in_w, channels;   /* x: (batch, in_h, in_w, channels)                   */
+    int32_t win_h, win_w;                  /* window == stride                                    */
+    int32_t out_h, out_w;                  /* ceil(in/win) for 'same', floor(in/win) for 'valid'  */
+    int32_t dtype;                         /* qk_dtype_t                                          */
+} qk_pool_desc_t;
+int qk_maxpool2d_fwd(const qk_pool_desc_t *desc, const void *x, void *y, void *stream);
+int qk_maxpool2d_bwd(const qk_pool_desc_t *desc, const void *x, const void *dy, void *dx, void *stream);
 
 /* Optimiser step on a flat fp32 buffer (Keras Adam: working_example.py:106).
  *   m = b1*m + (1-b1)*g ; v = b2*v + (1-b2)*g^2

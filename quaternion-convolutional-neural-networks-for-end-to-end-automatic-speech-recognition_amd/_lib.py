@@ -32,6 +32,15 @@ class DenseDesc(ctypes.Structure):
 # every symbol include/qk.h declares: name -> (restype, argtypes)
 _VP, _FP, _SZ = ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t
 _CD, _DD = ctypes.POINTER(ConvDesc), ctypes.POINTER(DenseDesc)
+class PoolDesc(ctypes.Structure):
+    """qk_pool_desc_t (include/qk.h)."""
+    _fields_ = [('batch', ctypes.c_int32), ('in_h', ctypes.c_int32), ('in_w', ctypes.c_int32),
+                ('channels', ctypes.c_int32), ('win_h', ctypes.c_int32), ('win_w', ctypes.c_int32),
+                ('out_h', ctypes.c_int32), ('out_w', ctypes.c_int32), ('dtype', ctypes.c_int32)]
+
+
+_PD = ctypes.POINTER(PoolDesc)
+
 SYMBOLS = {
     'qk_version': (ctypes.c_int, []),
     'qk_last_error': (ctypes.c_char_p, []),
@@ -46,6 +55,8 @@ SYMBOLS = {
     'qk_dense_fwd': (ctypes.c_int, [_DD, _VP, _FP, _FP, _VP, _VP, _SZ, _VP]),
     'qk_dense_bwd_data': (ctypes.c_int, [_DD, _VP, _VP, _FP, _VP, _VP, _SZ, _VP]),
     'qk_dense_bwd_weight': (ctypes.c_int, [_DD, _VP, _VP, _VP, _FP, _FP, _VP, _SZ, _VP]),
+    'qk_maxpool2d_fwd': (ctypes.c_int, [_PD, _VP, _VP, _VP]),
+    'qk_maxpool2d_bwd': (ctypes.c_int, [_PD, _VP, _VP, _VP, _VP]),
     'qk_adam_step': (ctypes.c_int, [_FP, _FP, _FP, _FP, _SZ, ctypes.c_float, ctypes.c_float,
                                     ctypes.c_float, ctypes.c_float, I32, ctypes.c_float, _VP]),
 }

@@ -414,6 +414,50 @@ int qk_conv_fold_taps(const qk_conv_desc_t *desc, const void *x, void *xcol, int
     return check_launch(launch_fold_taps(desc->dtype, x, xcol, g, cq2, (hipStream_t)stream), "qk_conv_fold_taps");
 }
 
+static int pool_geom(const qk_pool_desc_t *d, PoolGeom *g, const void *a, const void *b, const void *c)
+{
+    if (!d) { set_error("descriptor is NULL"); return QK_ERR_INVALID_ARG; }
+    if (!a || !b || !c) { set_error("maxpool: NULL buffer"); return QK_ERR_INVALID_ARG; }
+    if (d->batch <= 0 || d->in_h <= 0 || d->in_w <= 0 || d->channels <= 0 || d->win_h <= 0 || d->win_w <= 0 ||
+        d->out_h <= 0 || d->out_w <= 0) {
+        set_error("maxpool: extents must be positive"); return QK_ERR_INVALID_ARG;
+    }
+    if (d->dtype != QK_F32 && d->dtype != QK_BF16 && d->dtype != QK_F16) { set_error("maxpool: bad dtype"); return QK_ERR_INVALID_ARG; }
+    // windows tile the input from position 0; only the last one may be partial
+    if ((long long)(d->out_h - 1) * d->win_h >= d->in_h || (long long)(d->out_w - 1) * d->win_w >= d->in_w) {
+        set_error("maxpool: out extents %dx%d do not fit %dx%d with window %dx%d", d->out_h, d->out_w, d->in_h, d->in_w, d->win_h, d->win_w);
+        return QK_ERR_INVALID_ARG;
+    }
+    const int v = d->dtype == QK_F32 ? 4 : 8;
+    if (d->channels % v != 0) { set_error("maxpool: channels must be a multiple of %d", v); return QK_ERR_UNSUPPORTED; }
+    if (!aligned(a, 16) || !aligned(b, 16) || !aligned(c, 16)) { set_error("maxpool: buffers must be 16-byte aligned"); return QK_ERR_INVALID_ARG; }
+    if ((long long)d->batch * d->in_h * d->in_w * d->channels > INT_MAX) { set_error("maxpool: tensor has >= 2^31 elements"); return QK_ERR_UNSUPPORTED; }
+    g->batch = d->batch; g->ih = d->in_h; g->iw = d->in_w; g->C = d->channels;
+    g->wh = d->win_h; g->ww = d->win_w; g->oh = d->out_h; g->ow = d->out_w;
+    return 0;
+}
+
+int qk_maxpool2d_fwd(const qk_pool_desc_t *desc, const void *x, void *y, void *stream)
+{
+    PoolGeom g;
+    if (int rc = pool_geom(desc, &g, x, y, y)) return rc;
+    return check_launch(launch_maxpool(desc->dtype, false, x, nullptr, y, g, (hipStream_t)stream), "qk_maxpool2d_fwd");
+}
+
+int qk_maxpool2d_bwd(const qk_pool_desc_t *desc, const void *x, const void *dy, void *dx, void *stream)
+{
+    PoolGeom g;
+    if (int rc = pool_geom(desc, &g, x, dy, dx)) return rc;
+    // 'valid' pooling leaves trailing rows / columns outside every window: their gradient is zero
+    if ((long long)g.oh * g.wh < g.ih || (long long)g.ow * g.ww < g.iw) {
+        const size_t es = desc->dtype == QK_F32 ? 4 : 2;
+        if (hipMemsetAsync(dx, 0, (size_t)g.batch * g.ih * g.iw * g.C * es, (hipStream_t)stream) != hipSuccess) {
+            set_error("maxpool: memset failed"); return QK_ERR_LAUNCH;
+        }
+    }
+    return check_launch(launch_maxpool(desc->dtype, true, x, dy, dx, g, (hipStream_t)stream), "qk_maxpool2d_bwd");
+}
+
 int qk_adam_step(float *param, const float *grad, float *m, float *v, size_t n, float lr, float beta1,
                  float beta2, float eps, int32_t step, float grad_scale, void *stream)
 {

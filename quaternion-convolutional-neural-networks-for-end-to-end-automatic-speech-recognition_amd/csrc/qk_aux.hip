@@ -76,7 +76,90 @@ k_fold_taps(const T *__restrict__ x, T *__restrict__ xcol, const GemmGeom g, int
     }
 }
 
+// Max pooling, channels_last, non-overlapping windows.  One thread per (output position, group of V
+// channels); HBM-bound: forward reads x once and writes y, backward reads x and dy and writes dx.
+template <typename T, int V> struct VecOf;
+template <> struct VecOf<bf16, 8> { typedef uint4 type; };
+template <> struct VecOf<f16, 8> { typedef uint4 type; };
+template <> struct VecOf<float, 4> { typedef float4 type; };
+
+template <typename T, int V, bool BWD>
+__global__ void __launch_bounds__(256)
+k_maxpool(const T *__restrict__ x, const T *__restrict__ dy, T *__restrict__ out, const PoolGeom g)
+{
+    typedef typename VecOf<T, V>::type vec_t;
+    const int cg = g.C / V;
+    const long long total = (long long)g.batch * g.oh * g.ow * cg;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int c = (int)(idx % cg) * V;
+        long long r = idx / cg;
+        const int ow = (int)(r % g.ow); r /= g.ow;
+        const int oh = (int)(r % g.oh);
+        const int n = (int)(r / g.oh);
+        const int h0 = oh * g.wh, w0 = ow * g.ww;
+        const int h1 = min(h0 + g.wh, g.ih), w1 = min(w0 + g.ww, g.iw);
+        const T *xn = x + (long long)n * g.ih * g.iw * g.C + c;
+        float best[V];
+        int arg[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) { best[k] = -INFINITY; arg[k] = 0; }
+        int pos = 0;
+        for (int h = h0; h < h1; ++h)
+            for (int w = w0; w < w1; ++w, ++pos) {
+                __attribute__((aligned(16))) T v[V];
+                *reinterpret_cast<vec_t *>(v) = *reinterpret_cast<const vec_t *>(xn + ((long long)h * g.iw + w) * g.C);
+#pragma unroll
+                for (int k = 0; k < V; ++k) {
+                    const float f = to_f32(v[k]);
+                    if (f > best[k] || f != f) { best[k] = f; arg[k] = pos; }    // first maximum wins, NaN propagates
+                }
+            }
+        if constexpr (!BWD) {
+            __attribute__((aligned(16))) T v[V];
+#pragma unroll
+            for (int k = 0; k < V; ++k) v[k] = from_f32<T>(best[k]);
+            *reinterpret_cast<vec_t *>(out + (((long long)n * g.oh + oh) * g.ow + ow) * g.C + c) = *reinterpret_cast<const vec_t *>(v);
+        } else {
+            __attribute__((aligned(16))) T d[V];
+            *reinterpret_cast<vec_t *>(d) = *reinterpret_cast<const vec_t *>(dy + (((long long)n * g.oh + oh) * g.ow + ow) * g.C + c);
+            T *dn = out + (long long)n * g.ih * g.iw * g.C + c;
+            pos = 0;
+            for (int h = h0; h < h1; ++h)
+                for (int w = w0; w < w1; ++w, ++pos) {
+                    __attribute__((aligned(16))) T v[V];
+#pragma unroll
+                    for (int k = 0; k < V; ++k) v[k] = arg[k] == pos ? d[k] : from_f32<T>(0.f);
+                    *reinterpret_cast<vec_t *>(dn + ((long long)h * g.iw + w) * g.C) = *reinterpret_cast<const vec_t *>(v);
+                }
+        }
+    }
+}
+
+template <typename T, int V>
+int run_maxpool(bool backward, const void *x, const void *dy, void *out, const PoolGeom &g, hipStream_t stream)
+{
+    const long long total = (long long)g.batch * g.oh * g.ow * (g.C / V);
+    long long blocks = (total + 255) / 256;
+    if (blocks > 262144) blocks = 262144;
+    if (blocks < 1) blocks = 1;
+    if (backward)
+        hipLaunchKernelGGL((k_maxpool<T, V, true>), dim3((unsigned)blocks), dim3(256), 0, stream, (const T *)x, (const T *)dy, (T *)out, g);
+    else
+        hipLaunchKernelGGL((k_maxpool<T, V, false>), dim3((unsigned)blocks), dim3(256), 0, stream, (const T *)x, (const T *)dy, (T *)out, g);
+    return hipGetLastError() == hipSuccess ? 0 : QK_ERR_LAUNCH;
+}
+
 }  // namespace
+
+int launch_maxpool(int dtype, bool backward, const void *x, const void *dy, void *out, const PoolGeom &g, hipStream_t stream)
+{
+    switch (dtype) {
+    case QK_F32: return run_maxpool<float, 4>(backward, x, dy, out, g, stream);
+    case QK_BF16: return run_maxpool<bf16, 8>(backward, x, dy, out, g, stream);
+    case QK_F16: return run_maxpool<f16, 8>(backward, x, dy, out, g, stream);
+    default: return QK_ERR_INVALID_ARG;
+    }
+}
 
 int launch_fold_taps(int dtype, const void *x, void *xcol, const GemmGeom &g, int cq2, hipStream_t stream)
 {

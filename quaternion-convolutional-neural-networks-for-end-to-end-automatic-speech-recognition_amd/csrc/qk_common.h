@@ -135,6 +135,8 @@ int launch_hgemm(int dtype, const void *in, const void *mask, const float *wk, c
 int launch_wgrad(int dtype, const void *x, const void *dy, const void *ymask, float *dw,
                  float *dbias, WgradGeom g, bool vec_ok, hipStream_t stream);
 int launch_fold_taps(int dtype, const void *x, void *xcol, const GemmGeom &g, int cq2, hipStream_t stream);
+struct PoolGeom { int batch, ih, iw, C, wh, ww, oh, ow; };
+int launch_maxpool(int dtype, bool backward, const void *x, const void *dy, void *out, const PoolGeom &g, hipStream_t stream);
 int launch_adam(float *p, const float *g, float *m, float *v, size_t n, float lr, float b1,
                 float b2, float eps, int step, float gscale, hipStream_t stream);
 

@@ -331,3 +331,42 @@ def adam_step(param, grad, m, v, step, lr=0.001, beta1=0.9, beta2=0.999, eps=1e-
         rc = L.lib().qk_adam_step(_ptr(param), _ptr(grad), _ptr(m), _ptr(v), n, lr, beta1, beta2, eps,
                                   int(step), grad_scale, _stream(param))
     L.check(rc, 'qk_adam_step')
+
+
+class _MaxPoolCL(torch.autograd.Function):
+    """qk_maxpool2d_fwd / _bwd on a channels_last buffer (N, H, W, C); windows == strides."""
+
+    @staticmethod
+    def forward(ctx, x, win, out_hw):
+        n, h, w, c = x.shape
+        d = L.PoolDesc(n, h, w, c, win[0], win[1], out_hw[0], out_hw[1], _DTYPES[x.dtype])
+        y = torch.empty((n, out_hw[0], out_hw[1], c), dtype=x.dtype, device=x.device)
+        with _on_device(x.device):
+            rc = L.lib().qk_maxpool2d_fwd(ctypes.byref(d), _ptr(x), _ptr(y), _stream(x))
+        L.check(rc, 'qk_maxpool2d_fwd')
+        ctx.desc = d
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        with _on_device(x.device):
+            rc = L.lib().qk_maxpool2d_bwd(ctypes.byref(ctx.desc), _ptr(x), _ptr(dy), _ptr(dx), _stream(x))
+        L.check(rc, 'qk_maxpool2d_bwd')
+        return dx, None, None
+
+
+def maxpool2d_channels_last(x, window, out_hw):
+    """Max pooling of a contiguous (N, H, W, C) device tensor with non-overlapping windows and
+    high-side-only padding (see include/qk.h); returns (N, out_h, out_w, C)."""
+    _require_device(x, 'maxpool2d_channels_last')
+    return _MaxPoolCL.apply(x, tuple(window), tuple(out_hw))
+
+
+def maxpool2d_supported(x, window, strides):
+    vec = 4 if x.dtype == torch.float32 else 8
+    return (x.is_cuda and x.dtype in _DTYPES and x.dim() == 4 and tuple(window) == tuple(strides)
+            and x.shape[-1] % vec == 0 and x.numel() > 0 and x.numel() < 2 ** 31 and x.data_ptr() % 16 == 0)

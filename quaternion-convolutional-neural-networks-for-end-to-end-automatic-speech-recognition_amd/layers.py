@@ -15,6 +15,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
+from . import functional as Fq
 from ._shape import normalize_tuple, tf_pads
 from .keras_like import Layer, activations, initializers, regularizers
 
@@ -88,6 +89,12 @@ def _pool_nd(x, pool, strides, padding, axes, mode):
             if all(lo == 0 for lo, _ in lo_hi):
                 ceil = any(hi > 0 for _, hi in lo_hi)
                 if mode == 'max':
+                    xl = x.permute(0, 2, 3, 1)                      # (B, H, W, C) view
+                    if xl.is_contiguous() and Fq.maxpool2d_supported(xl, win[1:], step[1:]):
+                        # channels-last buffer, non-overlapping windows: the engine's own HBM-bound kernels
+                        out = [-(-x.shape[d] // step[d - 1]) if ceil else (x.shape[d] - win[d - 1]) // step[d - 1] + 1
+                               for d in (2, 3)]
+                        return Fq.maxpool2d_channels_last(xl, win[1:], out).permute(0, 3, 1, 2)
                     return F.max_pool2d(x, tuple(win[1:]), tuple(step[1:]), ceil_mode=ceil)
                 return F.avg_pool2d(x, tuple(win[1:]), tuple(step[1:]), ceil_mode=ceil, count_include_pad=False)
     perm = [0] + [i for i in range(1, x.dim()) if i not in axes] + list(axes)

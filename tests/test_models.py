@@ -165,3 +165,32 @@ def test_timit_head_as_convolution_equals_permute_reshape_dense(dtype, tol):
     for a, b in zip(*outs):
         assert a.shape == b.shape
         assert float((a - b).abs().max()) <= tol * max(float(a.abs().max()), 1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16], ids=['fp32', 'bf16', 'fp16'])
+@pytest.mark.parametrize('shape,pool,padding,axes', [
+    ((3, 128, 41, 20), (1, 3), 'same', (1, 2)),       # the TIMIT model's frequency pooling (partial last window)
+    ((2, 16, 41, 20), (1, 3), 'valid', (1, 2)),       # trailing rows outside every window: zero gradient
+    ((2, 8, 12, 10), (2, 2), 'same', (2, 3)),
+    ((2, 24, 9, 7), (2, 3), 'same', (2, 3)),
+])
+def test_engine_maxpool_matches_torch_including_ties(shape, pool, padding, axes, dtype):
+    """MaxPooling2D on a channels-last device buffer runs on qk_maxpool2d_*; it must agree with torch's
+    pooling exactly, ties included (relu outputs are full of equal zeros; the first maximum gets the
+    gradient)."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    dev = torch.device('cuda:0')
+    from qcnn_amd.layers import _pool_nd
+    g = torch.Generator(device=dev).manual_seed(9)
+    x = torch.relu(torch.randn(*shape, device=dev, generator=g)).to(dtype)        # many exact ties at 0
+    x = x.contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = _pool_nd(x, pool, pool, padding, axes, 'max')
+    dy = torch.randn(y.shape, device=dev, generator=g).to(dtype)
+    y.backward(dy)
+    xr = x.detach().clone().unsqueeze(-1).requires_grad_(True)                      # 5-D: torch's generic path
+    yr = _pool_nd(xr, pool, pool, padding, axes, 'max').squeeze(-1)
+    yr.backward(dy)
+    assert y.shape == yr.shape and torch.equal(y, yr)
+    assert torch.equal(x.grad, xr.grad.squeeze(-1))
