@@ -51,6 +51,11 @@ struct GemmGeom {
     int has_mask;       // gathered value is zeroed where mask[same index] <= 0 (relu backward)
     int ablate;         // profiling only (env QK_ABLATE): 4 = skip the MFMA loop, 8 = skip the epilogue
     int w_swapped;      // Wk is the compact kernel itself, read with q/j swapped (backward-data): no transposed copy
+    // band variant of the 16-bit kernel (qk_hgemm_bf16mfma.hip): rows of M run over PADDED lines of the
+    // innermost axis (b_wp = out extent + k - 1 positions per line, b_nlines lines), band row j of a tile
+    // holds input position (padded position + b_cshift); b_rev: taps walk the band backwards (bwd-data)
+    int b_wp, b_nlines, b_cshift, b_rev;
+    unsigned b_in_bytes, b_w_bytes;      // extents of the input tensor and of the re-laid-out kernel (buffer resources)
 };
 
 // Backward-weight geometry:  dW[t, c, p, f] = sum_{a^b=p} sgn(a,b) sum_m x_a[pos(m,t), c] * dy_b[m, f]

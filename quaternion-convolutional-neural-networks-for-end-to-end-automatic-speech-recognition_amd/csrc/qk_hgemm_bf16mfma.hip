@@ -332,6 +332,323 @@ k_hgemm16(const T *__restrict__ in, const T *__restrict__ mask, const uint4 *__r
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Band variant: the taps along the innermost spatial axis reuse ONE staged A tile.
+//
+// In k_hgemm16 every (tap, channel chunk) K step stages its own 128-row A tile, although the KIN
+// taps of one kernel row read the same input rows shifted by one position: A staging is ~15 % of
+// that kernel (ablation), B staging ~11 %.  Here the rows of a tile run over PADDED lines of the
+// innermost axis (out extent + KIN - 1 positions per line; the extra positions are computed and
+// dropped, 2 % at 200 columns), which makes "input position of (row, inner tap t)" exactly
+// "band row + t" -- no per-(row, tap) validity, out-of-line positions are zero rows of the band.
+// A group = (outer tap, channel chunk) stages one band of BM + KIN - 1 rows and runs KIN sub-steps
+// off it; the band of the next group is fetched during the first sub-steps and stored during the
+// following ones (two band buffers), B tiles are double-buffered per sub-step as before.
+// ---------------------------------------------------------------------------------------
+// buffer-resource loads (see qk_wgrad_bf16mfma.hip): 32-bit per-lane byte offset + wave-uniform offset,
+// no 64-bit address arithmetic, and offsets past the extent read as zeros (padding rows need no select
+// between a data pointer and a zero line)
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned kOutOfRange16 = 0xF0000000u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc16(const void *p, unsigned bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ uint4 buf_load16b(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
+// A-band staging schedule of one group: op code q < R loads row pass q of the NEXT band into its
+// registers, R <= q < 2R stores pass q - R into the other band buffer, -1 = nothing.  A store comes at
+// least one sub-step after its load (so it never waits on it), and at most three passes are in flight
+// (register pressure: five would spill).
+constexpr int kBandOpsMax = 5;
+constexpr int band_op(int R, int K, int ti, int k)
+{
+    if (R == 3 && K == 5) { const int t[5][5] = {{0, 1, -1, -1, -1}, {3, 2, -1, -1, -1}, {4, -1, -1, -1, -1}, {5, -1, -1, -1, -1}, {-1, -1, -1, -1, -1}}; return t[ti][k]; }
+    if (R == 3 && K == 3) { const int t[3][5] = {{0, 1, -1, -1, -1}, {3, 4, 2, -1, -1}, {5, -1, -1, -1, -1}}; return t[ti][k]; }
+    if (R == 5 && K == 5) { const int t[5][5] = {{0, 1, -1, -1, -1}, {5, 2, -1, -1, -1}, {6, 3, -1, -1, -1}, {7, 4, -1, -1, -1}, {8, 9, -1, -1, -1}}; return t[ti][k]; }
+    if (R == 5 && K == 3) { const int t[3][5] = {{0, 1, 2, -1, -1}, {5, 6, 7, 3, 4}, {8, 9, -1, -1, -1}}; return t[ti][k]; }
+    return -2;
+}
+
+template <typename T, int WM, int WN, int KIN, bool CONJ>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *__restrict__ zero_line,
+               const float *__restrict__ bias, T *__restrict__ out, const GemmGeom g)
+{
+    static_assert(WM * WN == 8, "8 waves per workgroup");
+    static_assert(KIN >= 2 && KIN <= 9, "inner taps per band");
+    constexpr int BM = WM * 32, BF = WN * 32;
+    constexpr int BU = (16 * BF) / 512;
+    constexpr unsigned TBL = CONJ ? kSignConj : kSignConv;
+    constexpr int BAND = BM + KIN - 1;             // rows of the A band
+    constexpr int A_U = (BM + 8) * 16;             // 16-byte units of one band buffer
+    constexpr int B_U = 16 * BF;
+    __shared__ __attribute__((aligned(16))) uint4 lds[2 * A_U + 2 * B_U];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int WP = g.b_wp;
+    const int total_p = g.b_nlines * WP;           // padded rows (host checked < 2^31)
+    const int n_mt = (total_p + BM - 1) / BM;
+    const int per_xcd = (n_mt + 7) / 8;
+    const int mtile = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+    if (mtile >= n_mt) return;
+    const int p0 = mtile * BM;
+    const int j0 = blockIdx.y * BF;
+    const int nkc = g.Q / 32;
+    const int groups = g.ks[0] * g.ks[1] * nkc;
+    const int substeps = groups * KIN;
+
+    // ---- band rows of this thread (decoded once) ------------------------------------------------
+    constexpr int RPT3 = (BAND + 63) / 64;
+    const int s_row = tid >> 3, s8 = tid & 7;
+    int base_off[RPT3];
+    unsigned omask[RPT3];                           // bit (t0 * ks1 + t1): outer tap inside the tensor
+#pragma unroll
+    for (int r = 0; r < RPT3; ++r) {
+        const int j = s_row + r * 64;
+        base_off[r] = 0; omask[r] = 0;
+        const int P = p0 + j;
+        const int line = P / WP;
+        const int col = P - line * WP + g.b_cshift;
+        if (j < BAND && line < g.b_nlines && col >= 0 && col < g.isp[2]) {
+            const int o1 = line % g.osp[1];
+            const int l2 = line / g.osp[1];
+            const int o0 = l2 % g.osp[0];
+            const int n = l2 / g.osp[0];
+            const int q0 = o0 * g.pa[0] + g.pc[0], q1 = o1 * g.pa[1] + g.pc[1];
+            base_off[r] = n * (int)g.in_sn + q0 * (int)g.in_ss[0] + q1 * (int)g.in_ss[1] + col * (int)g.in_ss[2];
+            int t = 0;
+            for (int t0 = 0; t0 < g.ks[0]; ++t0)
+                for (int t1 = 0; t1 < g.ks[1]; ++t1, ++t) {
+                    const int i0 = q0 + t0 * g.pb[0], i1 = q1 + t1 * g.pb[1];
+                    const bool ok = i0 >= 0 && i0 < g.isp[0] && i1 >= 0 && i1 < g.isp[1];
+                    omask[r] |= (ok ? 1u : 0u) << t;
+                }
+        }
+    }
+    const int cmp_lo = s8 >> 2, sub = (s8 & 3) * 8;
+    const __amdgpu_buffer_rsrc_t rin = make_rsrc16(in, g.b_in_bytes), rw = make_rsrc16(wq, g.b_w_bytes);
+    const unsigned a_thr = (unsigned)(cmp_lo * g.Q + sub) * 2u;        // this thread's (component, 8 channels) of a row
+    const unsigned a_hi = (unsigned)g.Q * 4u;                            // two components further (wave-uniform)
+    const unsigned b_thr0 = (unsigned)((tid / BF) * g.J + j0 + tid % BF) * 16u;
+    const unsigned b_thr1 = (unsigned)(((tid + 512) / BF) * g.J + j0 + (tid + 512) % BF) * 16u;
+    // (named registers, not an array: hipcc leaves a 128-byte by-reference-captured array in scratch
+    // here -- every staged unit then takes a scratch round trip)
+    constexpr int RPTF = RPT3 - 1;                  // full 64-row passes; pass RPTF is the KIN - 1 halo rows
+    static_assert(RPTF * 64 == BM && RPTF <= 4, "band = up to four full passes + one halo pass");
+    uint4 a0l, a0h, a1l, a1h, a2l, a2h, a3l, a3h, ah0, ah1, br0, br1;
+
+    // group the A loads fetch (outer tap at0/at1 = index aot, channel chunk akc); stops at the last
+    int at0 = 0, at1 = 0, aot = 0, akc = 0, a_next = 0, adelta = 0;
+    auto a_prep = [&]() {
+        adelta = at0 * g.pb[0] * (int)g.in_ss[0] + at1 * g.pb[1] * (int)g.in_ss[1] + akc * 32;
+    };
+    auto a_advance_if_more = [&]() {
+        if (a_next + 1 < groups) {
+            ++a_next;
+            if (++akc == nkc) { akc = 0; ++aot; if (++at1 == g.ks[1]) { at1 = 0; ++at0; } }
+        }
+    };
+    auto load_a = [&](int r) {
+        const bool ok = (omask[r] >> aot) & 1u;
+        const unsigned voff = ok ? (unsigned)(base_off[r] + adelta) * 2u + a_thr : kOutOfRange16;
+        if (r < RPTF || wave == 0) {                // the halo pass holds KIN - 1 <= 8 rows: wave 0 only
+            const uint4 vl = buf_load16b(rin, voff, 0);
+            const uint4 vh = buf_load16b(rin, voff, a_hi);
+            if (r == RPTF) { ah0 = vl; ah1 = vh; }
+            else if (r == 0) { a0l = vl; a0h = vh; }
+            else if (r == 1) { a1l = vl; a1h = vh; }
+            else if (r == 2) { a2l = vl; a2h = vh; }
+            else { a3l = vl; a3h = vh; }
+        }
+    };
+    auto store_a = [&](int r, int buf) {
+        const int row = s_row + r * 64;
+        uint4 *As = lds + buf * A_U;
+        if (r < RPTF || (wave == 0 && row < BAND)) {
+            const uint4 vl = r == RPTF ? ah0 : r == 0 ? a0l : r == 1 ? a1l : r == 2 ? a2l : a3l;
+            const uint4 vh = r == RPTF ? ah1 : r == 0 ? a0h : r == 1 ? a1h : r == 2 ? a2h : a3h;
+            As[row * 16 + (s8 ^ (row & 15))] = vl;
+            As[row * 16 + ((s8 + 8) ^ (row & 15))] = vh;
+        }
+    };
+    // sub-step the B loads fetch: (outer tap bot, chunk bkc, inner step bti); stops at the last
+    int bot = 0, bkc = 0, bti = 0, b_next = 0;
+    unsigned bsoff = 0;
+    auto b_prep = [&]() {
+        const int tap = bot * KIN + bti;           // sub-step ti IS inner tap ti; b_rev only mirrors the band offset
+        bsoff = (unsigned)((tap * nkc + bkc) * 16 * g.J) * 16u;
+    };
+    auto b_advance_if_more = [&]() {
+        if (b_next + 1 < substeps) {
+            ++b_next;
+            if (++bti == KIN) { bti = 0; if (++bkc == nkc) { bkc = 0; ++bot; } }
+        }
+    };
+    auto load_b = [&]() {
+        br0 = buf_load16b(rw, b_thr0, bsoff);
+        if constexpr (BU == 2) br1 = buf_load16b(rw, b_thr1, bsoff);
+    };
+    auto store_b = [&](int buf) {
+        uint4 *Bs = lds + 2 * A_U + buf * B_U;
+        Bs[tid] = br0;
+        if constexpr (BU == 2) Bs[tid + 512] = br1;
+    };
+
+    floatx16 acc[4], accn[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[b][r] = 0.f; accn[b][r] = 0.f; }
+
+    const int frow = wm * 32 + lr;                  // tile row this lane reads; band row = frow + tap offset
+    const int b_rd0 = 2 * A_U + wn * 32 + lr;
+
+    // ---- prologue: band 0, B tile 0 in LDS; B tile 1 in registers ---------------------------------
+    a_prep();
+#pragma unroll
+    for (int r = 0; r < RPT3; ++r) load_a(r);
+#pragma unroll
+    for (int r = 0; r < RPT3; ++r) store_a(r, 0);
+    a_advance_if_more();
+    b_prep(); load_b(); store_b(0); b_advance_if_more();
+    b_prep(); load_b(); b_advance_if_more();
+    __syncthreads();
+
+    static_assert(band_op(RPT3, KIN, 0, 0) != -2, "no staging schedule for this (row passes, inner taps)");
+
+    int s = 0;                                      // global sub-step
+    for (int gi = 0; gi < groups; ++gi) {
+        const uint4 *band = lds + (gi & 1) * A_U;
+        const int nband = (gi + 1) & 1;
+        a_prep();
+#pragma unroll
+        for (int ti = 0; ti < KIN; ++ti, ++s) {
+            const int toff = g.b_rev ? KIN - 1 - ti : ti;
+            const int arow = frow + toff;
+            const uint4 *a_rd = band + arow * 16;
+            const int fsw = arow & 15;
+            const uint4 *b_rd = lds + b_rd0 + (s & 1) * B_U;
+            const int nb = (s + 1) & 1;
+            b_prep();
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                uint4 A[4], B[4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) A[a] = a_rd[(a * 4 + ks * 2 + lh) ^ fsw];
+#pragma unroll
+                for (int p = 0; p < 4; ++p) B[p] = b_rd[((ks * 2 + lh) * 4 + p) * BF];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        constexpr unsigned tbl = TBL;
+                        if ((tbl >> (a * 4 + b)) & 1u) accn[b] = mfma16(T(), A[a], B[a ^ b], accn[b]);
+                        else acc[b] = mfma16(T(), A[a], B[a ^ b], acc[b]);
+                        const int f = ks * 16 + a * 4 + b;
+                        if (f % 2 == 1) {
+                            const int op = f / 2;                        // staging slot of this sub-step
+                            if (op < kBandOpsMax) {
+                                const int q = band_op(RPT3, KIN, ti, op);
+                                if (q >= RPT3) store_a(q - RPT3, nband);
+                                else if (q >= 0) load_a(q);
+                            } else if (op == kBandOpsMax) store_b(nb);
+                            else if (op == kBandOpsMax + 1) load_b();
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+            }
+            b_advance_if_more();
+            __syncthreads();
+        }
+        a_advance_if_more();
+    }
+
+    // ---- epilogue: bias + activation, per-wave LDS transpose, 16-byte stores (see k_hgemm16) --------
+    constexpr int EP_PITCH = 80;
+    char *ep = reinterpret_cast<char *>(lds) + wave * (32 * EP_PITCH);
+    const int e_row = lane >> 2, e_chunk = lane & 3;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int ch0 = b * g.J + j0 + wn * 32;
+        const float bia = g.has_bias ? bias[ch0 + lr] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = acc[b][r] - accn[b][r] + bia;
+            if (g.relu) v = v > 0.f ? v : 0.f;
+            *reinterpret_cast<T *>(ep + mfma32_row(r, lane) * EP_PITCH + lr * 2) = from_f32<T>(v);
+        }
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            const int row = e_row + 16 * pass;
+            const uint4 val = *reinterpret_cast<const uint4 *>(ep + row * EP_PITCH + e_chunk * 16);
+            const int P = p0 + wm * 32 + row;
+            const int line = P / WP;
+            const int u = P - line * WP;
+            if (line < g.b_nlines && u < g.osp[2])
+                *reinterpret_cast<uint4 *>(out + (long long)(line * g.osp[2] + u) * (int)g.out_ss + ch0 + e_chunk * 8) = val;
+        }
+    }
+}
+
+template <typename T, int WM, int WN, int KIN>
+int run16_band(const T *in, const uint4 *wq, const T *zero_line, const float *bias, T *out, const GemmGeom &g,
+               hipStream_t stream)
+{
+    constexpr int BM = WM * 32, BF = WN * 32;
+    const int n_mt = (int)(((long long)g.b_nlines * g.b_wp + BM - 1) / BM);
+    dim3 grid((n_mt + 7) / 8 * 8, g.J / BF, 1);
+    if (g.sign_tbl == kSignConj)
+        hipLaunchKernelGGL((k_hgemm16_band<T, WM, WN, KIN, true>), grid, dim3(512), 0, stream, in, wq, zero_line, bias, out, g);
+    else
+        hipLaunchKernelGGL((k_hgemm16_band<T, WM, WN, KIN, false>), grid, dim3(512), 0, stream, in, wq, zero_line, bias, out, g);
+    return hipGetLastError() == hipSuccess ? 1 : QK_ERR_LAUNCH;
+}
+
+// Geometry of the band variant, or false when the shape is outside it: the innermost used axis must
+// have unit stride and dilation and 3 or 5 taps, no relu mask to apply, and the padding positions
+// must stay a small part of the work.  Axes are rotated so that this axis is index 2 (unit axes move
+// to the front: neither the row order nor the tap order changes).
+bool band_geom(const GemmGeom &g, GemmGeom *o)
+{
+    if (g.has_mask || getenv("QK_NO_BAND16")) return false;
+    int ax = 2;
+    while (ax > 0 && g.osp[ax] == 1 && g.isp[ax] == 1 && g.ks[ax] == 1) --ax;
+    if (g.ks[ax] != 3 && g.ks[ax] != 5) return false;
+    if (g.pa[ax] != 1 || (g.pb[ax] != 1 && g.pb[ax] != -1)) return false;
+    *o = g;
+    const int sh = 2 - ax;                                  // rotate axes right by sh
+    for (int i = 0; i < 3; ++i) {
+        const int src = i - sh;
+        o->osp[i] = src >= 0 ? g.osp[src] : 1; o->isp[i] = src >= 0 ? g.isp[src] : 1; o->ks[i] = src >= 0 ? g.ks[src] : 1;
+        o->pa[i] = src >= 0 ? g.pa[src] : 1; o->pb[i] = src >= 0 ? g.pb[src] : 1; o->pc[i] = src >= 0 ? g.pc[src] : 0;
+        o->in_ss[i] = src >= 0 ? g.in_ss[src] : 0;
+    }
+    const int k = o->ks[2];
+    if (o->ks[0] * o->ks[1] > 32) return false;             // outer-tap bit mask
+    o->b_wp = o->osp[2] + k - 1;
+    if ((k - 1) * 12 > o->b_wp) return false;                // > 8 % of the rows would be padding
+    const long long lines = (long long)g.batch * o->osp[0] * o->osp[1];
+    if (lines * o->b_wp >= (1ll << 31) - 512) return false;
+    o->b_nlines = (int)lines;
+    const long long in_bytes = (long long)g.batch * g.in_sn * 2, w_bytes = (long long)g.taps * g.Q * 4 * g.J * 2 + 256;
+    if (in_bytes >= 0xF0000000ll || w_bytes >= 0xF0000000ll) return false;   // 32-bit buffer offsets
+    o->b_in_bytes = (unsigned)in_bytes;
+    o->b_w_bytes = (unsigned)w_bytes;
+    o->b_rev = o->pb[2] < 0;
+    o->b_cshift = o->b_rev ? o->pc[2] - (k - 1) : o->pc[2];
+    return true;
+}
+
 template <typename T, int MT, int WM, int WN>
 int run16(const T *in, const T *mask, const uint4 *wq, const T *zero_line, const float *bias, T *out,
           const GemmGeom &g_in, hipStream_t stream)
@@ -363,6 +680,17 @@ int go16(const void *in, const void *mask, const float *w, const float *bias, vo
     const uint4 *wq4 = reinterpret_cast<const uint4 *>(wq);
     const T *zero_line = wq + total;                 // 256 zeroed bytes behind the re-laid-out kernel
     const bool tall = getenv("QK_TALL16") != nullptr;     // tuning aid: 256-row tiles (MT = 2)
+    GemmGeom bg;
+    if (band_geom(g, &bg)) {
+        const T *ip = (const T *)in;
+        T *op = (T *)out;
+        if (bg.ks[2] == 5) {
+            if (g.J % 64 == 0) return run16_band<T, 4, 2, 5>(ip, wq4, zero_line, bias, op, bg, stream);
+            return run16_band<T, 8, 1, 5>(ip, wq4, zero_line, bias, op, bg, stream);
+        }
+        if (g.J % 64 == 0) return run16_band<T, 4, 2, 3>(ip, wq4, zero_line, bias, op, bg, stream);
+        return run16_band<T, 8, 1, 3>(ip, wq4, zero_line, bias, op, bg, stream);
+    }
     if (g.J % 64 == 0) {
         if (tall && !g.has_mask) return run16<T, 2, 4, 2>((const T *)in, (const T *)mask, wq4, zero_line, bias, (T *)out, g, stream);
         return run16<T, 1, 4, 2>((const T *)in, (const T *)mask, wq4, zero_line, bias, (T *)out, g, stream);
