@@ -1,10 +1,10 @@
 #!/bin/bash
 export TMPDIR=/tmp
 run() {
-  timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-hamilton-gemm "$@" 2>/dev/null | tail -1 | python -c "
+  timeout 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-hamilton-gemm "$@" 2>/dev/null | tail -1 | python -c "
 import sys, json
 d = json.loads(sys.stdin.read())
 print('   ms/step', round(d['ms_per_step'],4), ' '.join('%s %.1f (%.0f TF)' % (k, v['ms']*1e3, v['tflops']) for k,v in d.get('kernels',{}).items()))
 "
 }
-for ab in 0 16 32 48; do echo "ablate $ab"; QK_ABLATE=$ab run --workload cfg3_body_qconv2d_b256_bf16; done
+for ab in 0 4 8 12 1 2; do echo "ablate $ab"; QK_ABLATE=$ab run; done
