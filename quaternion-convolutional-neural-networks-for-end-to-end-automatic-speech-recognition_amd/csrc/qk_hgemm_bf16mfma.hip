@@ -679,7 +679,6 @@ int go16(const void *in, const void *mask, const float *w, const float *bias, vo
     if (hipGetLastError() != hipSuccess) return QK_ERR_LAUNCH;
     const uint4 *wq4 = reinterpret_cast<const uint4 *>(wq);
     const T *zero_line = wq + total;                 // 256 zeroed bytes behind the re-laid-out kernel
-    const bool tall = getenv("QK_TALL16") != nullptr;     // tuning aid: 256-row tiles (MT = 2)
     GemmGeom bg;
     if (band_geom(g, &bg)) {
         const T *ip = (const T *)in;
@@ -692,7 +691,7 @@ int go16(const void *in, const void *mask, const float *w, const float *bias, vo
         return run16_band<T, 8, 1, 3>(ip, wq4, zero_line, bias, op, bg, stream);
     }
     if (g.J % 64 == 0) {
-        if (tall && !g.has_mask) return run16<T, 2, 4, 2>((const T *)in, (const T *)mask, wq4, zero_line, bias, (T *)out, g, stream);
+        // (256-row tiles, MT = 2, were measured: no gain over 128 rows, and they spill)
         return run16<T, 1, 4, 2>((const T *)in, (const T *)mask, wq4, zero_line, bias, (T *)out, g, stream);
     }
     return run16<T, 1, 8, 1>((const T *)in, (const T *)mask, wq4, zero_line, bias, (T *)out, g, stream);
