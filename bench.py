@@ -41,6 +41,9 @@ WORKLOADS = {
                                         kernel=(3, 5), dtype='bf16'),
     'cfg3_body_qconv2d_b256_fp32': dict(kind='conv', rank=2, batch=256, spatial=(14, 200), cq=64, filters=64,
                                         kernel=(3, 5), dtype='fp32'),
+    # BASELINE.json configs[4] body layer: Cq = F = 256, fp16, 32 samples per GPU
+    'cfg5_body_qconv2d_b32_fp16': dict(kind='conv', rank=2, batch=32, spatial=(14, 200), cq=256, filters=256,
+                                       kernel=(3, 5), dtype='fp16'),
     # BASELINE.json configs[2]: the full TIMIT QCNN (models/interspeech_model.py:45-185), n=10, sf=32
     'cfg3_qcnn_timit_b256_bf16': dict(kind='model', batch=256, frames=200, sf=32, layers=10, dtype='bf16'),
     'cfg3_qcnn_timit_b64_fp32': dict(kind='model', batch=64, frames=200, sf=32, layers=10, dtype='fp32'),

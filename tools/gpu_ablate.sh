@@ -7,6 +7,4 @@ d = json.loads(sys.stdin.read())
 print('   ms/step', round(d['ms_per_step'],4), ' '.join('%s %.1f (%.0f TF)' % (k, v['ms']*1e3, v['tflops']) for k,v in d.get('kernels',{}).items()))
 "
 }
-run --workload cfg3_body_qconv2d_b256_bf16
-run --workload cfg3_body_qconv2d_b256_bf16 --activation linear
-run --workload cfg3_qcnn_timit_b256_bf16
+for wl in "$@"; do echo $wl; run --workload $wl; done
