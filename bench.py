@@ -141,6 +141,7 @@ class LayerTrainStep(object):
         # bwd-data on the masked gradient bwd-weight leaves behind (no second pass over y)
         self.relu = cfg.get('activation', 'relu') == 'relu'
         self.diag_mask_in_bwd_data = bool(os.environ.get('QK_DIAG_MASK_IN_BWD_DATA'))
+        self.acc_grads = not os.environ.get('QK_BENCH_FILL_GRADS')     # diagnostic: the fill-per-step form
         self.call_lin = F.conv_call(tuple(self.x.shape), tuple(kernel.shape), dt, len(ks), 1, 'same',
                                     'channels_last', 1, 'linear', True)
         self.call_lin.static_buffers = True
@@ -160,7 +161,10 @@ class LayerTrainStep(object):
         self.call.fwd(self.x, self.kernel.data, self.bias.data, out=self.y)
 
     def k_bwd_weight(self):
-        self.call.bwd_weight(self.x, self.dy, self.y, True, out=(self.dw, self.db), masked_dy_out=self.dym)
+        # the gradient buffer is zero on entry (initially, and after every Adam step: zero_grad), so the
+        # backward adds into it -- no 5 us fill per step
+        self.call.bwd_weight(self.x, self.dy, self.y, True, out=(self.dw, self.db), masked_dy_out=self.dym,
+                             accumulate=self.acc_grads)
 
     def k_bwd_data(self):
         if self.relu and not self.diag_mask_in_bwd_data:
@@ -170,10 +174,10 @@ class LayerTrainStep(object):
 
     def _adam(self):
         self.F.adam_step(self.flat.param, self.flat.grad, self.m, self.v, self.t, lr=5e-4,
-                         grad_scale=1.0 / self.world)
+                         grad_scale=1.0 / self.world, zero_grad=self.acc_grads)
 
     def step(self):
-        """Eager step: 7 launches through the C-ABI."""
+        """Eager step: 6 launches through the C-ABI."""
         self.t += 1
         self.k_fwd()
         self.k_bwd_weight()

@@ -132,6 +132,16 @@ int qk_conv_bwd_weight(const qk_conv_desc_t *desc, const void *x, const void *dy
                        float *dw, float *dbias, void *workspace, size_t workspace_bytes,
                        void *stream);
 
+/* Accumulating form: dw += ..., dbias += ... (nothing is zeroed first).  For gradient accumulation over
+ * micro-batches, and for training loops whose optimiser step leaves the gradient buffer zeroed
+ * (qk_adam_step_zero_grad): the 5 us fill in front of every backward-weight then disappears. */
+int qk_conv_bwd_weight_acc(const qk_conv_desc_t *desc, const void *x, const void *dy, const void *y,
+                           float *dw, float *dbias, void *workspace, size_t workspace_bytes,
+                           void *stream);
+int qk_dense_bwd_weight_acc(const qk_dense_desc_t *desc, const void *x, const void *dy, const void *y,
+                            float *dw, float *dbias, void *workspace, size_t workspace_bytes,
+                            void *stream);
+
 /* Fused backward: all three gradients in one call (what TF autodiff of conv.py:288-345 yields).
  * bwd-weight runs first and, for RELU, leaves the masked dy in the workspace so that bwd-data reads
  * one tensor instead of two.  dx must not be NULL.  Workspace: qk_*_workspace_bytes(desc, QK_OP_BWD). */
@@ -184,6 +194,12 @@ int qk_maxpool2d_bwd(const qk_pool_desc_t *desc, const void *x, const void *dy, 
 int qk_adam_step(float *param, const float *grad, float *m, float *v, size_t n, float lr,
                  float beta1, float beta2, float eps, int32_t step, float grad_scale,
                  void *stream);
+
+/* qk_adam_step that also writes zeros over `grad` once it has been consumed, so the next backward can
+ * accumulate into it (qk_*_bwd_weight_acc) without a separate fill. */
+int qk_adam_step_zero_grad(float *param, float *grad, float *m, float *v, size_t n, float lr,
+                           float beta1, float beta2, float eps, int32_t step, float grad_scale,
+                           void *stream);
 
 #ifdef __cplusplus
 }

@@ -49,12 +49,16 @@ SYMBOLS = {
     'qk_conv_fwd': (ctypes.c_int, [_CD, _VP, _FP, _FP, _VP, _VP, _SZ, _VP]),
     'qk_conv_bwd_data': (ctypes.c_int, [_CD, _VP, _VP, _FP, _VP, _VP, _SZ, _VP]),
     'qk_conv_bwd_weight': (ctypes.c_int, [_CD, _VP, _VP, _VP, _FP, _FP, _VP, _SZ, _VP]),
+    'qk_conv_bwd_weight_acc': (ctypes.c_int, [_CD, _VP, _VP, _VP, _FP, _FP, _VP, _SZ, _VP]),
+    'qk_dense_bwd_weight_acc': (ctypes.c_int, [_DD, _VP, _VP, _VP, _FP, _FP, _VP, _SZ, _VP]),
     'qk_conv_bwd': (ctypes.c_int, [_CD, _VP, _VP, _VP, _FP, _VP, _FP, _FP, _VP, _SZ, _VP]),
     'qk_dense_bwd': (ctypes.c_int, [_DD, _VP, _VP, _VP, _FP, _VP, _FP, _FP, _VP, _SZ, _VP]),
     'qk_conv_fold_taps': (ctypes.c_int, [_CD, _VP, _VP, I32, _VP]),
     'qk_dense_fwd': (ctypes.c_int, [_DD, _VP, _FP, _FP, _VP, _VP, _SZ, _VP]),
     'qk_dense_bwd_data': (ctypes.c_int, [_DD, _VP, _VP, _FP, _VP, _VP, _SZ, _VP]),
     'qk_dense_bwd_weight': (ctypes.c_int, [_DD, _VP, _VP, _VP, _FP, _FP, _VP, _SZ, _VP]),
+    'qk_adam_step_zero_grad': (ctypes.c_int, [_FP, _FP, _FP, _FP, _SZ, ctypes.c_float, ctypes.c_float,
+                                              ctypes.c_float, ctypes.c_float, I32, ctypes.c_float, _VP]),
     'qk_maxpool2d_fwd': (ctypes.c_int, [_PD, _VP, _VP, _VP]),
     'qk_maxpool2d_bwd': (ctypes.c_int, [_PD, _VP, _VP, _VP, _VP]),
     'qk_adam_step': (ctypes.c_int, [_FP, _FP, _FP, _FP, _SZ, ctypes.c_float, ctypes.c_float,

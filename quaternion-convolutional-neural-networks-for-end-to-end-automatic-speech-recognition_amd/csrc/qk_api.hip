@@ -215,7 +215,7 @@ int conv_bwd_data_impl(const qk_conv_desc_t *d, const void *dy, const void *y, c
 }
 
 int conv_bwd_weight_impl(const qk_conv_desc_t *d, const void *x, const void *dy, const void *y, float *dw,
-                         float *dbias, void *dy_masked_out, hipStream_t stream)
+                         float *dbias, void *dy_masked_out, hipStream_t stream, bool accumulate = false)
 {
     if (!x || !dy || !dw) { set_error("x/dy/dw must not be NULL"); return QK_ERR_INVALID_ARG; }
     const bool mask = d->activation == QK_ACT_RELU;
@@ -244,7 +244,9 @@ int conv_bwd_weight_impl(const qk_conv_desc_t *d, const void *x, const void *dy,
     const size_t dwb = w_floats(d) * sizeof(float), dbb = 4 * (size_t)d->fq * sizeof(float);
     const char *dw_end = reinterpret_cast<const char *>(dw) + dwb;
     const char *db_c = reinterpret_cast<const char *>(dbias);
-    if (g.want_dbias && db_c >= dw_end && db_c - dw_end <= 256) {
+    if (accumulate) {
+        // the caller's buffers already hold what this call adds to
+    } else if (g.want_dbias && db_c >= dw_end && db_c - dw_end <= 256) {
         if (hipMemsetAsync(dw, 0, (size_t)(db_c - reinterpret_cast<const char *>(dw)) + dbb, stream) != hipSuccess) { set_error("memset dw failed"); return QK_ERR_LAUNCH; }
     } else {
         if (hipMemsetAsync(dw, 0, dwb, stream) != hipSuccess) { set_error("memset dw failed"); return QK_ERR_LAUNCH; }
@@ -344,6 +346,24 @@ int qk_conv_bwd_weight(const qk_conv_desc_t *desc, const void *x, const void *dy
     if (int rc = validate(desc, false)) return rc;
     void *dym = (workspace && workspace_bytes >= dy_bytes(desc) && aligned(workspace, 16)) ? workspace : nullptr;
     return check_launch(conv_bwd_weight_impl(desc, x, dy, y, dw, dbias, dym, (hipStream_t)stream), "qk_conv_bwd_weight");
+}
+
+int qk_conv_bwd_weight_acc(const qk_conv_desc_t *desc, const void *x, const void *dy, const void *y,
+                           float *dw, float *dbias, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (int rc = validate(desc, false)) return rc;
+    void *dym = (workspace && workspace_bytes >= dy_bytes(desc) && aligned(workspace, 16)) ? workspace : nullptr;
+    return check_launch(conv_bwd_weight_impl(desc, x, dy, y, dw, dbias, dym, (hipStream_t)stream, true), "qk_conv_bwd_weight_acc");
+}
+
+int qk_dense_bwd_weight_acc(const qk_dense_desc_t *desc, const void *x, const void *dy, const void *y,
+                            float *dw, float *dbias, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!desc) { set_error("descriptor is NULL"); return QK_ERR_INVALID_ARG; }
+    const qk_conv_desc_t c = dense_as_conv(desc);
+    if (int rc = validate(&c, true)) return rc;
+    void *dym = (workspace && workspace_bytes >= dy_bytes(&c) && aligned(workspace, 16)) ? workspace : nullptr;
+    return check_launch(conv_bwd_weight_impl(&c, x, dy, y, dw, dbias, dym, (hipStream_t)stream, true), "qk_dense_bwd_weight_acc");
 }
 
 int qk_conv_bwd(const qk_conv_desc_t *desc, const void *x, const void *dy, const void *y, const float *w,
@@ -463,7 +483,15 @@ int qk_adam_step(float *param, const float *grad, float *m, float *v, size_t n, 
 {
     if (!param || !grad || !m || !v) { set_error("adam: NULL buffer"); return QK_ERR_INVALID_ARG; }
     if (step < 1) { set_error("adam: step must be >= 1"); return QK_ERR_INVALID_ARG; }
-    return check_launch(launch_adam(param, grad, m, v, n, lr, beta1, beta2, eps, step, grad_scale, (hipStream_t)stream), "qk_adam_step");
+    return check_launch(launch_adam(param, const_cast<float *>(grad), m, v, n, lr, beta1, beta2, eps, step, grad_scale, false, (hipStream_t)stream), "qk_adam_step");
+}
+
+int qk_adam_step_zero_grad(float *param, float *grad, float *m, float *v, size_t n, float lr, float beta1,
+                           float beta2, float eps, int32_t step, float grad_scale, void *stream)
+{
+    if (!param || !grad || !m || !v) { set_error("adam: NULL buffer"); return QK_ERR_INVALID_ARG; }
+    if (step < 1) { set_error("adam: step must be >= 1"); return QK_ERR_INVALID_ARG; }
+    return check_launch(launch_adam(param, grad, m, v, n, lr, beta1, beta2, eps, step, grad_scale, true, (hipStream_t)stream), "qk_adam_step_zero_grad");
 }
 
 }  // extern "C"

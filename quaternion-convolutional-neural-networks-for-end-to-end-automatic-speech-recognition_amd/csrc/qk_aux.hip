@@ -5,8 +5,9 @@ namespace qk {
 namespace {
 
 // Keras-2 Adam (keras/optimizers.py Adam.get_updates), the optimiser of working_example.py:106.
+template <bool ZERO>
 __global__ void __launch_bounds__(256)
-k_adam(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
+k_adam(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m,
        float *__restrict__ v, size_t n, float lr_t, float b1, float b2, float eps, float gscale)
 {
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -18,6 +19,7 @@ k_adam(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m
         m[i] = mi;
         v[i] = vi;
         p[i] -= lr_t * mi / (sqrtf(vi) + eps);
+        if constexpr (ZERO) g[i] = 0.f;
     }
 }
 
@@ -175,15 +177,18 @@ int launch_fold_taps(int dtype, const void *x, void *xcol, const GemmGeom &g, in
     return hipGetLastError() == hipSuccess ? 0 : QK_ERR_LAUNCH;
 }
 
-int launch_adam(float *p, const float *g, float *m, float *v, size_t n, float lr, float b1,
-                float b2, float eps, int step, float gscale, hipStream_t stream)
+int launch_adam(float *p, float *g, float *m, float *v, size_t n, float lr, float b1,
+                float b2, float eps, int step, float gscale, bool zero_grad, hipStream_t stream)
 {
     if (n == 0) return 0;
     const double t = (double)step;
     const float lr_t = (float)((double)lr * sqrt(1.0 - pow((double)b2, t)) / (1.0 - pow((double)b1, t)));
     size_t blocks = (n + 255) / 256;
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks), dim3(256), 0, stream, p, g, m, v, n, lr_t, b1, b2, eps, gscale);
+    if (zero_grad)
+        hipLaunchKernelGGL(k_adam<true>, dim3((unsigned)blocks), dim3(256), 0, stream, p, g, m, v, n, lr_t, b1, b2, eps, gscale);
+    else
+        hipLaunchKernelGGL(k_adam<false>, dim3((unsigned)blocks), dim3(256), 0, stream, p, g, m, v, n, lr_t, b1, b2, eps, gscale);
     return hipGetLastError() == hipSuccess ? 0 : QK_ERR_LAUNCH;
 }
 

@@ -142,8 +142,8 @@ int launch_wgrad(int dtype, const void *x, const void *dy, const void *ymask, fl
 int launch_fold_taps(int dtype, const void *x, void *xcol, const GemmGeom &g, int cq2, hipStream_t stream);
 struct PoolGeom { int batch, ih, iw, C, wh, ww, oh, ow; };
 int launch_maxpool(int dtype, bool backward, const void *x, const void *dy, void *out, const PoolGeom &g, hipStream_t stream);
-int launch_adam(float *p, const float *g, float *m, float *v, size_t n, float lr, float b1,
-                float b2, float eps, int step, float gscale, hipStream_t stream);
+int launch_adam(float *p, float *g, float *m, float *v, size_t n, float lr, float b1,
+                float b2, float eps, int step, float gscale, bool zero_grad, hipStream_t stream);
 
 void set_error(const char *fmt, ...);
 

@@ -101,8 +101,9 @@ class _Call(object):
         L.check(rc, self.names[1])
         return dx
 
-    def bwd_weight(self, x, dy, y, has_bias, out=None, masked_dy_out=None):
-        """dw, db.  `masked_dy_out` (a tensor like dy) receives dy*(y>0) for RELU layers."""
+    def bwd_weight(self, x, dy, y, has_bias, out=None, masked_dy_out=None, accumulate=False):
+        """dw, db.  `masked_dy_out` (a tensor like dy) receives dy*(y>0) for RELU layers.
+        accumulate=True adds into `out` instead of overwriting it (qk_*_bwd_weight_acc)."""
         if out is not None:
             dw, db = out
         else:
@@ -112,9 +113,12 @@ class _Call(object):
         if masked_dy_out is not None:
             ws, n = masked_dy_out, masked_dy_out.numel() * masked_dy_out.element_size()
         with _on_device(x.device):
-            rc = getattr(L.lib(), self.names[2])(ctypes.byref(self.desc), _ptr(x), _ptr(dy), _ptr(y),
-                                                 _ptr(dw), _ptr(db), _ptr(ws), n, _stream(x))
-        L.check(rc, self.names[2])
+            name = self.names[2] + ('_acc' if accumulate else '')
+            if accumulate and out is None:
+                raise ValueError('accumulate=True needs the buffers to add into (out=)')
+            rc = getattr(L.lib(), name)(ctypes.byref(self.desc), _ptr(x), _ptr(dy), _ptr(y),
+                                        _ptr(dw), _ptr(db), _ptr(ws), n, _stream(x))
+        L.check(rc, name)
         return dw, db
 
 
@@ -321,15 +325,16 @@ def quaternion_dense(x, kernel, bias=None, activation=None):
     return _HamiltonFn.apply(xp, kernel.contiguous(), bias, call)
 
 
-def adam_step(param, grad, m, v, step, lr=0.001, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0):
-    """Fused Keras-Adam update of a flat float32 buffer (qk_adam_step)."""
+def adam_step(param, grad, m, v, step, lr=0.001, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0, zero_grad=False):
+    """Fused Keras-Adam update of a flat float32 buffer (qk_adam_step); zero_grad=True also clears `grad`
+    once it has been consumed (qk_adam_step_zero_grad), ready for accumulating backward calls."""
     for t in (param, grad, m, v):
         if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
             raise RuntimeError('adam_step needs contiguous float32 device buffers')
     n = param.numel()
     with _on_device(param.device):
-        rc = L.lib().qk_adam_step(_ptr(param), _ptr(grad), _ptr(m), _ptr(v), n, lr, beta1, beta2, eps,
-                                  int(step), grad_scale, _stream(param))
+        fn = L.lib().qk_adam_step_zero_grad if zero_grad else L.lib().qk_adam_step
+        rc = fn(_ptr(param), _ptr(grad), _ptr(m), _ptr(v), n, lr, beta1, beta2, eps, int(step), grad_scale, _stream(param))
     L.check(rc, 'qk_adam_step')
 
 

@@ -437,6 +437,44 @@ def test_ragged_and_degenerate_shapes_match_oracle(case, dtype):
         assert err <= (tol16 if k in ('y', 'dx') else tol32), '%s: rel err %.3g' % (k, err)
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['fp32', 'bf16'])
+def test_accumulating_backward_weight_and_zeroing_adam(dtype):
+    """qk_*_bwd_weight_acc adds into dw / dbias; qk_adam_step_zero_grad == qk_adam_step + cleared gradient."""
+    import qcnn_amd
+    F = qcnn_amd.functional
+    dev = _dev()
+    g = torch.Generator(device=dev).manual_seed(8)
+    x = torch.randn(4, 40, 128, device=dev, generator=g).to(dtype)
+    w = torch.randn(3, 32, 128, device=dev, generator=g) / 20
+    b = torch.randn(128, device=dev, generator=g) / 10
+    call = F.conv_call(tuple(x.shape), tuple(w.shape), dtype, 1, 1, 'same', 'channels_last', 1, 'relu', True)
+    y = call.fwd(x, w, b)
+    dy = torch.randn(y.shape, device=dev, generator=g).to(dtype)
+    dw, db = call.bwd_weight(x, dy, y, True)
+    acc_w, acc_b = torch.full_like(dw, 0.5), torch.full_like(db, -0.25)
+    call.bwd_weight(x, dy, y, True, out=(acc_w, acc_b), accumulate=True)
+    call.bwd_weight(x, dy, y, True, out=(acc_w, acc_b), accumulate=True)
+    assert _rel_err((acc_w - 0.5).cpu().numpy(), (2 * dw).cpu().numpy()) <= 1e-5
+    assert _rel_err((acc_b + 0.25).cpu().numpy(), (2 * db).cpu().numpy()) <= 1e-5
+    xd = torch.randn(50, 128, device=dev, generator=g).to(dtype)
+    wd = torch.randn(32, 64, device=dev, generator=g) / 10
+    dcall = F.dense_call(tuple(xd.shape), tuple(wd.shape), dtype, 'linear', False)
+    dyd = torch.randn(50, 64, device=dev, generator=g).to(dtype)
+    dwd, _ = dcall.bwd_weight(xd, dyd, None, False)
+    accd = torch.ones_like(dwd)
+    dcall.bwd_weight(xd, dyd, None, False, out=(accd, None), accumulate=True)
+    assert _rel_err((accd - 1).cpu().numpy(), dwd.cpu().numpy()) <= 1e-5
+    # Adam
+    n = 1000
+    p1 = torch.randn(n, device=dev, generator=g); p2 = p1.clone()
+    gr = torch.randn(n, device=dev, generator=g); gr2 = gr.clone()
+    m1 = torch.zeros(n, device=dev); v1 = torch.zeros(n, device=dev); m2 = m1.clone(); v2 = v1.clone()
+    F.adam_step(p1, gr, m1, v1, 3, lr=1e-3, grad_scale=0.5)
+    F.adam_step(p2, gr2, m2, v2, 3, lr=1e-3, grad_scale=0.5, zero_grad=True)
+    assert torch.equal(p1, p2) and torch.equal(m1, m2) and torch.equal(v1, v2)
+    assert float(gr2.abs().max()) == 0.0 and float(gr.abs().max()) > 0.0
+
+
 def test_c_abi_reports_errors_instead_of_faulting():
     import ctypes
     import qcnn_amd
