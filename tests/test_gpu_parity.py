@@ -122,6 +122,12 @@ ORACLE_CASES = [
      dict(padding='same', strides=(2, 1), activation=None)),
     ('conv3d_small', 3, (2, 6, 7, 5, 16), (2, 3, 2, 4, 32),
      dict(padding='same', activation='relu')),
+    ('conv3d_32ch', 3, (1, 4, 5, 40, 128), (2, 3, 3, 32, 128),
+     dict(padding='same', activation='relu')),
+    ('conv2d_32ch_outer_stride_dil', 2, (2, 19, 40, 128), (3, 3, 32, 128),
+     dict(padding='same', strides=(2, 1), activation='relu')),
+    ('conv2d_64ch_valid_wide', 2, (1, 6, 70, 256), (3, 5, 64, 128),
+     dict(padding='valid', activation=None)),
     ('dense_qdnn0', 0, (32, 1000), (250, 512), dict(activation='relu')),
     ('dense_timit_head', 0, (300, 3584), (896, 256), dict(activation='relu')),
     ('dense_wide', 0, (130, 512), (128, 1024), dict(activation=None)),
@@ -142,7 +148,7 @@ def test_fp32_matches_oracle(case):
 HALF_CASES = [c for c in ORACLE_CASES if c[0] in (
     'cfg2_conv1d_b8_f64', 'conv1d_odd_channels', 'conv2d_body_small', 'conv2d_body64_small', 'conv2d_32to64', 'conv1d_64to32_valid',
     'conv2d_chfirst_body_small',
-    'conv2d_first_layer', 'dense_timit_head')]
+    'conv2d_first_layer', 'dense_timit_head', 'conv3d_32ch', 'conv2d_32ch_outer_stride_dil', 'conv2d_64ch_valid_wide')]
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16], ids=['bf16', 'fp16'])
