@@ -59,6 +59,44 @@ struct GemmGeom {
 };
 
 // Backward-weight geometry:  dW[t, c, p, f] = sum_{a^b=p} sgn(a,b) sum_m x_a[pos(m,t), c] * dy_b[m, f]
+// Geometry of the band variants of the forward / backward-data kernels (qk_hgemm_bf16mfma.hip,
+// qk_hgemm_f32mfma.inc), or false when the shape is outside them: the innermost used axis must have
+// unit stride and dilation and 3 or 5 taps, no relu mask to apply, unit-stride position map, and the
+// padding positions must stay a small part of the work.  Axes are rotated so that this axis is index 2
+// (unit axes move to the front: neither the row order nor the tap order changes).  `esize` = bytes per
+// activation element (extents for the buffer resources of the 16-bit kernel).
+inline bool band_geom(const GemmGeom &g, int esize, GemmGeom *o)
+{
+    if (g.has_mask) return false;
+    if (g.pd[0] != 1 || g.pd[1] != 1 || g.pd[2] != 1) return false;
+    int ax = 2;
+    while (ax > 0 && g.osp[ax] == 1 && g.isp[ax] == 1 && g.ks[ax] == 1) --ax;
+    if (g.ks[ax] != 3 && g.ks[ax] != 5) return false;
+    if (g.pa[ax] != 1 || (g.pb[ax] != 1 && g.pb[ax] != -1)) return false;
+    *o = g;
+    const int sh = 2 - ax;                                  // rotate axes right by sh
+    for (int i = 0; i < 3; ++i) {
+        const int src = i - sh;
+        o->osp[i] = src >= 0 ? g.osp[src] : 1; o->isp[i] = src >= 0 ? g.isp[src] : 1; o->ks[i] = src >= 0 ? g.ks[src] : 1;
+        o->pa[i] = src >= 0 ? g.pa[src] : 1; o->pb[i] = src >= 0 ? g.pb[src] : 1; o->pc[i] = src >= 0 ? g.pc[src] : 0;
+        o->in_ss[i] = src >= 0 ? g.in_ss[src] : 0;
+    }
+    const int k = o->ks[2];
+    if (o->ks[0] * o->ks[1] > 32) return false;             // outer-tap bit mask
+    o->b_wp = o->osp[2] + k - 1;
+    if ((k - 1) * 12 > o->b_wp) return false;                // > 8 % of the rows would be padding
+    const long long lines = (long long)g.batch * o->osp[0] * o->osp[1];
+    if (lines * o->b_wp >= (1ll << 31) - 512) return false;
+    o->b_nlines = (int)lines;
+    const long long in_bytes = (long long)g.batch * g.in_sn * esize, w_bytes = (long long)g.taps * g.Q * 4 * g.J * 2 + 256;
+    if (in_bytes >= 0xF0000000ll || w_bytes >= 0xF0000000ll) return false;   // 32-bit buffer offsets
+    o->b_in_bytes = (unsigned)in_bytes;
+    o->b_w_bytes = (unsigned)w_bytes;
+    o->b_rev = o->pb[2] < 0;
+    o->b_cshift = o->b_rev ? o->pc[2] - (k - 1) : o->pc[2];
+    return true;
+}
+
 struct WgradGeom {
     int M;
     int batch;

@@ -614,41 +614,6 @@ int run16_band(const T *in, const uint4 *wq, const T *zero_line, const float *bi
     return hipGetLastError() == hipSuccess ? 1 : QK_ERR_LAUNCH;
 }
 
-// Geometry of the band variant, or false when the shape is outside it: the innermost used axis must
-// have unit stride and dilation and 3 or 5 taps, no relu mask to apply, and the padding positions
-// must stay a small part of the work.  Axes are rotated so that this axis is index 2 (unit axes move
-// to the front: neither the row order nor the tap order changes).
-bool band_geom(const GemmGeom &g, GemmGeom *o)
-{
-    if (g.has_mask || getenv("QK_NO_BAND16")) return false;
-    int ax = 2;
-    while (ax > 0 && g.osp[ax] == 1 && g.isp[ax] == 1 && g.ks[ax] == 1) --ax;
-    if (g.ks[ax] != 3 && g.ks[ax] != 5) return false;
-    if (g.pa[ax] != 1 || (g.pb[ax] != 1 && g.pb[ax] != -1)) return false;
-    *o = g;
-    const int sh = 2 - ax;                                  // rotate axes right by sh
-    for (int i = 0; i < 3; ++i) {
-        const int src = i - sh;
-        o->osp[i] = src >= 0 ? g.osp[src] : 1; o->isp[i] = src >= 0 ? g.isp[src] : 1; o->ks[i] = src >= 0 ? g.ks[src] : 1;
-        o->pa[i] = src >= 0 ? g.pa[src] : 1; o->pb[i] = src >= 0 ? g.pb[src] : 1; o->pc[i] = src >= 0 ? g.pc[src] : 0;
-        o->in_ss[i] = src >= 0 ? g.in_ss[src] : 0;
-    }
-    const int k = o->ks[2];
-    if (o->ks[0] * o->ks[1] > 32) return false;             // outer-tap bit mask
-    o->b_wp = o->osp[2] + k - 1;
-    if ((k - 1) * 12 > o->b_wp) return false;                // > 8 % of the rows would be padding
-    const long long lines = (long long)g.batch * o->osp[0] * o->osp[1];
-    if (lines * o->b_wp >= (1ll << 31) - 512) return false;
-    o->b_nlines = (int)lines;
-    const long long in_bytes = (long long)g.batch * g.in_sn * 2, w_bytes = (long long)g.taps * g.Q * 4 * g.J * 2 + 256;
-    if (in_bytes >= 0xF0000000ll || w_bytes >= 0xF0000000ll) return false;   // 32-bit buffer offsets
-    o->b_in_bytes = (unsigned)in_bytes;
-    o->b_w_bytes = (unsigned)w_bytes;
-    o->b_rev = o->pb[2] < 0;
-    o->b_cshift = o->b_rev ? o->pc[2] - (k - 1) : o->pc[2];
-    return true;
-}
-
 template <typename T, int MT, int WM, int WN>
 int run16(const T *in, const T *mask, const uint4 *wq, const T *zero_line, const float *bias, T *out,
           const GemmGeom &g_in, hipStream_t stream)
@@ -680,7 +645,7 @@ int go16(const void *in, const void *mask, const float *w, const float *bias, vo
     const uint4 *wq4 = reinterpret_cast<const uint4 *>(wq);
     const T *zero_line = wq + total;                 // 256 zeroed bytes behind the re-laid-out kernel
     GemmGeom bg;
-    if (band_geom(g, &bg)) {
+    if (!getenv("QK_NO_BAND16") && band_geom(g, 2, &bg)) {
         const T *ip = (const T *)in;
         T *op = (T *)out;
         if (bg.ks[2] == 5) {
