@@ -27,24 +27,22 @@ _QUATERNION_INIT_NAMES = ["complex", "complex_independent", "glorot_complex", "h
 
 
 def sanitizedInitGet(init):
-    if init in ["sqrt_init"]:
+    """Initializer lookup of conv.py:796-804: 'sqrt_init' and the quaternion-family names pass through,
+    everything else goes to the Keras registry."""
+    if init == "sqrt_init":
         return sqrt_init
-    elif isinstance(init, str) and init in _QUATERNION_INIT_NAMES:
+    if isinstance(init, str) and init in _QUATERNION_INIT_NAMES:
         return init
-    else:
-        return initializers.get(init)
+    return initializers.get(init)
 
 
 def sanitizedInitSer(init):
     """What conv.py:806-814 intends (its isinstance checks name undefined classes)."""
     if init is sqrt_init or isinstance(init, sqrt_init):
         return "sqrt_init"
-    elif isinstance(init, str):
-        return init
-    elif isinstance(init, qconv_init):
+    if isinstance(init, qconv_init):
         return "quaternion"
-    else:
-        return initializers.serialize(init)
+    return init if isinstance(init, str) else initializers.serialize(init)
 
 
 def _instantiate(init):
@@ -60,81 +58,49 @@ class QuaternionConv(Layer):
     `filters` counts QUATERNION filters: the layer emits 4*filters real channels.
     """
 
-    def __init__(self, rank,
-                 filters,
-                 kernel_size,
-                 strides=1,
-                 padding='valid',
-                 data_format='channels_last',
-                 dilation_rate=1,
-                 activation=None,
-                 use_bias=True,
-                 normalize_weight=False,
-                 kernel_initializer='quaternion',
-                 bias_initializer='zeros',
-                 gamma_diag_initializer=sqrt_init,
-                 gamma_off_initializer='zeros',
-                 kernel_regularizer=None,
-                 bias_regularizer=None,
-                 gamma_diag_regularizer=None,
-                 gamma_off_regularizer=None,
-                 activity_regularizer=None,
-                 kernel_constraint=None,
-                 bias_constraint=None,
-                 gamma_diag_constraint=None,
-                 gamma_off_constraint=None,
-                 init_criterion='he',
-                 seed=None,
-                 spectral_parametrization=False,
-                 epsilon=1e-7,
-                 internal_layout='channels_last',
-                 **kwargs):
+    # constructor arguments resolved through a registry, grouped by how (get, serialize)
+    _INITIALIZERS = ('kernel_initializer', 'bias_initializer', 'gamma_diag_initializer', 'gamma_off_initializer')
+    _REGULARIZERS = ('kernel_regularizer', 'bias_regularizer', 'gamma_diag_regularizer', 'gamma_off_regularizer',
+                     'activity_regularizer')
+    _CONSTRAINTS = ('kernel_constraint', 'bias_constraint', 'gamma_diag_constraint', 'gamma_off_constraint')
+    _PLAIN = ('use_bias', 'normalize_weight', 'init_criterion', 'spectral_parametrization', 'epsilon')
+
+    def __init__(self, rank, filters, kernel_size, strides=1, padding='valid', data_format='channels_last',
+                 dilation_rate=1, activation=None, use_bias=True, normalize_weight=False,
+                 kernel_initializer='quaternion', bias_initializer='zeros', gamma_diag_initializer=sqrt_init,
+                 gamma_off_initializer='zeros', kernel_regularizer=None, bias_regularizer=None,
+                 gamma_diag_regularizer=None, gamma_off_regularizer=None, activity_regularizer=None,
+                 kernel_constraint=None, bias_constraint=None, gamma_diag_constraint=None,
+                 gamma_off_constraint=None, init_criterion='he', seed=None, spectral_parametrization=False,
+                 epsilon=1e-7, internal_layout='channels_last', **kwargs):
+        given = dict(locals())
         super(QuaternionConv, self).__init__(**kwargs)
-        self.rank = rank
-        self.filters = filters
-        self.kernel_size = normalize_tuple(kernel_size, rank, 'kernel_size')
-        self.strides = normalize_tuple(strides, rank, 'strides')
+        self.rank, self.filters = rank, filters
+        for attr in ('kernel_size', 'strides', 'dilation_rate'):          # int or tuple -> rank-tuple
+            setattr(self, attr, normalize_tuple(given[attr], rank, attr))
         self.padding = normalize_padding(padding)
         self.data_format = normalize_data_format(data_format)
-        self.dilation_rate = normalize_tuple(dilation_rate, rank, 'dilation_rate')
         self.activation = activations.get(activation)
-        self.use_bias = use_bias
-        self.normalize_weight = normalize_weight
-        self.init_criterion = init_criterion
-        self.spectral_parametrization = spectral_parametrization
-        self.epsilon = epsilon
-        self.kernel_initializer = sanitizedInitGet(kernel_initializer)
-        self.bias_initializer = sanitizedInitGet(bias_initializer)
-        self.gamma_diag_initializer = sanitizedInitGet(gamma_diag_initializer)
-        self.gamma_off_initializer = sanitizedInitGet(gamma_off_initializer)
-        self.kernel_regularizer = regularizers.get(kernel_regularizer)
-        self.bias_regularizer = regularizers.get(bias_regularizer)
-        self.gamma_diag_regularizer = regularizers.get(gamma_diag_regularizer)
-        self.gamma_off_regularizer = regularizers.get(gamma_off_regularizer)
-        self.activity_regularizer = regularizers.get(activity_regularizer)
-        self.kernel_constraint = constraints.get(kernel_constraint)
-        self.bias_constraint = constraints.get(bias_constraint)
-        self.gamma_diag_constraint = constraints.get(gamma_diag_constraint)
-        self.gamma_off_constraint = constraints.get(gamma_off_constraint)
-        if seed is None:
-            self.seed = np.random.randint(1, 10e6)
-        else:
-            self.seed = seed
+        for attr in self._PLAIN:
+            setattr(self, attr, given[attr])
+        for attr in self._INITIALIZERS:
+            setattr(self, attr, sanitizedInitGet(given[attr]))
+        for attr in self._REGULARIZERS:
+            setattr(self, attr, regularizers.get(given[attr]))
+        for attr in self._CONSTRAINTS:
+            setattr(self, attr, constraints.get(given[attr]))
+        self.seed = int(np.random.randint(1, 10e6)) if seed is None else seed    # never used afterwards (conv.py:148-151)
         # where channels_first data physically lives (not a reference option): 'channels_last'
         # keeps it NHWC-style in HBM behind a channels_first-shaped view; 'native' does not.
         if internal_layout not in ('channels_last', 'native'):
             raise ValueError('internal_layout must be "channels_last" or "native"')
         self.internal_layout = internal_layout
-        self.input_spec = InputSpec(ndim=self.rank + 2)
+        self.input_spec = InputSpec(ndim=rank + 2)
 
     def build(self, input_shape):
-        if self.data_format == 'channels_first':
-            channel_axis = 1
-        else:
-            channel_axis = -1
-        if input_shape[channel_axis] is None:
-            raise ValueError('The channel dimension of the inputs '
-                             'should be defined. Found `None`.')
+        channel_axis = 1 if self.data_format == 'channels_first' else -1
+        if input_shape[channel_axis] is None:                      # same error as conv.py:161-163
+            raise ValueError('The channel dimension of the inputs should be defined. Found `None`.')
         input_dim = input_shape[channel_axis] // 4
         # the attribute keeps the reference's (misleading) value; the variable is (*k, Cq, 4F)
         self.kernel_shape = self.kernel_size + (input_dim, self.filters)
@@ -182,47 +148,29 @@ class QuaternionConv(Layer):
         return out
 
     def compute_output_shape(self, input_shape):
-        if self.data_format == 'channels_last':
-            space = input_shape[1:-1]
-        else:
-            space = input_shape[2:]
-        new_space = [conv_output_length(space[i], self.kernel_size[i], padding=self.padding,
-                                        stride=self.strides[i], dilation=self.dilation_rate[i])
-                     for i in range(len(space))]
-        if self.data_format == 'channels_last':
-            return (input_shape[0],) + tuple(new_space) + (4 * self.filters,)
-        return (input_shape[0],) + (4 * self.filters,) + tuple(new_space)
+        first = self.data_format == 'channels_first'
+        space = input_shape[2:] if first else input_shape[1:-1]
+        out = tuple(conv_output_length(n, k, padding=self.padding, stride=st, dilation=dl)
+                    for n, k, st, dl in zip(space, self.kernel_size, self.strides, self.dilation_rate))
+        channels = (4 * self.filters,)
+        return (input_shape[0],) + (channels + out if first else out + channels)
 
     def get_config(self):
-        config = {
-            'rank': self.rank,
-            'filters': self.filters,
-            'kernel_size': self.kernel_size,
-            'strides': self.strides,
-            'padding': self.padding,
-            'data_format': self.data_format,
-            'dilation_rate': self.dilation_rate,
-            'activation': activations.serialize(self.activation),
-            'use_bias': self.use_bias,
-            'normalize_weight': self.normalize_weight,
-            'kernel_initializer': sanitizedInitSer(self.kernel_initializer),
-            'bias_initializer': sanitizedInitSer(self.bias_initializer),
-            'gamma_diag_initializer': sanitizedInitSer(self.gamma_diag_initializer),
-            'gamma_off_initializer': sanitizedInitSer(self.gamma_off_initializer),
-            'kernel_regularizer': regularizers.serialize(self.kernel_regularizer),
-            'bias_regularizer': regularizers.serialize(self.bias_regularizer),
-            'gamma_diag_regularizer': regularizers.serialize(self.gamma_diag_regularizer),
-            'gamma_off_regularizer': regularizers.serialize(self.gamma_off_regularizer),
-            'activity_regularizer': regularizers.serialize(self.activity_regularizer),
-            'kernel_constraint': constraints.serialize(self.kernel_constraint),
-            'bias_constraint': constraints.serialize(self.bias_constraint),
-            'gamma_diag_constraint': constraints.serialize(self.gamma_diag_constraint),
-            'gamma_off_constraint': constraints.serialize(self.gamma_off_constraint),
-            'init_criterion': self.init_criterion,
-            'spectral_parametrization': self.spectral_parametrization,
-        }
-        base_config = super(QuaternionConv, self).get_config()
-        return dict(list(base_config.items()) + list(config.items()))
+        cfg = super(QuaternionConv, self).get_config()
+        for attr in ('rank', 'filters', 'kernel_size', 'strides', 'padding', 'data_format', 'dilation_rate'):
+            cfg[attr] = getattr(self, attr)
+        cfg['activation'] = activations.serialize(self.activation)
+        for attr in ('use_bias', 'normalize_weight'):
+            cfg[attr] = getattr(self, attr)
+        for attr in self._INITIALIZERS:
+            cfg[attr] = sanitizedInitSer(getattr(self, attr))
+        for attr in self._REGULARIZERS:
+            cfg[attr] = regularizers.serialize(getattr(self, attr))
+        for attr in self._CONSTRAINTS:
+            cfg[attr] = constraints.serialize(getattr(self, attr))
+        for attr in ('init_criterion', 'spectral_parametrization'):
+            cfg[attr] = getattr(self, attr)
+        return cfg
 
 
 def _subclass_kwargs(local):

@@ -23,38 +23,26 @@ class QuaternionDense(Layer):
     qdense_init (dense.py:101) and the bias always starts at zero (dense.py:115).
     """
 
-    def __init__(self, units,
-                 activation=None,
-                 use_bias=True,
-                 init_criterion='he',
-                 kernel_initializer='quaternion',
-                 bias_initializer='zeros',
-                 kernel_regularizer=None,
-                 bias_regularizer=None,
-                 activity_regularizer=None,
-                 kernel_constraint=None,
-                 bias_constraint=None,
-                 seed=None,
-                 **kwargs):
-        if 'input_shape' not in kwargs and 'input_dim' in kwargs:
+    # (getter module, attribute) of the Keras-style arguments that are resolved through a registry
+    _RESOLVED = (('bias_initializer', initializers), ('kernel_regularizer', regularizers),
+                 ('bias_regularizer', regularizers), ('activity_regularizer', regularizers),
+                 ('kernel_constraint', constraints), ('bias_constraint', constraints))
+
+    def __init__(self, units, activation=None, use_bias=True, init_criterion='he',
+                 kernel_initializer='quaternion', bias_initializer='zeros', kernel_regularizer=None,
+                 bias_regularizer=None, activity_regularizer=None, kernel_constraint=None,
+                 bias_constraint=None, seed=None, **kwargs):
+        given = dict(locals())
+        if 'input_dim' in kwargs and 'input_shape' not in kwargs:       # Keras shorthand (dense.py:71-72)
             kwargs['input_shape'] = (kwargs.pop('input_dim'),)
         super(QuaternionDense, self).__init__(**kwargs)
-        self.units = units
-        self.q_units = units // 4
+        self.units, self.q_units = units, units // 4
+        self.use_bias, self.init_criterion = use_bias, init_criterion
         self.activation = activations.get(activation)
-        self.use_bias = use_bias
-        self.init_criterion = init_criterion
-        self.kernel_initializer = kernel_initializer
-        self.bias_initializer = initializers.get(bias_initializer)
-        self.kernel_regularizer = regularizers.get(kernel_regularizer)
-        self.bias_regularizer = regularizers.get(bias_regularizer)
-        self.activity_regularizer = regularizers.get(activity_regularizer)
-        self.kernel_constraint = constraints.get(kernel_constraint)
-        self.bias_constraint = constraints.get(bias_constraint)
-        if seed is None:
-            self.seed = np.random.randint(1, 10e6)
-        else:
-            self.seed = seed
+        self.kernel_initializer = kernel_initializer                      # stored, never used (dense.py:101)
+        for attr, registry in self._RESOLVED:
+            setattr(self, attr, registry.get(given[attr]))
+        self.seed = int(np.random.randint(1, 10e6)) if seed is None else seed   # drawn, unused (dense.py:86-89)
         self.input_spec = InputSpec(ndim=2)
         self.supports_masking = True
 
@@ -63,25 +51,24 @@ class QuaternionDense(Layer):
         return self.r          # the reference names the variable 'r' (dense.py:103-109)
 
     def build(self, input_shape):
-        assert len(input_shape) == 2
-        assert input_shape[-1] % 2 == 0
-        if input_shape[-1] % 4 or self.units % 4:
-            # the reference passes its assert for in%4==2 and then dies inside K.dot with a
+        width = input_shape[-1] if len(input_shape) == 2 else None
+        assert len(input_shape) == 2                       # same assertions as dense.py:94-95
+        assert width % 2 == 0
+        if width % 4 or self.units % 4:
+            # the reference passes its assert for width % 4 == 2 and then dies inside K.dot with a
             # shape mismatch; fail here with a message instead
             raise ValueError('QuaternionDense needs input width and units divisible by 4, got %d / %d'
-                             % (input_shape[-1], self.units))
-        input_dim = input_shape[-1] // 4
-        kernel_shape = (input_dim, self.units)
-        init_shape = (input_dim, self.q_units)
-        self.kernel_init = qdense_init(init_shape, self.init_criterion)
-        self.add_weight('r', kernel_shape, initializer=self.kernel_init,
+                             % (width, self.units))
+        in_q = width // 4
+        self.kernel_init = qdense_init((in_q, self.q_units), self.init_criterion)
+        self.add_weight('r', (in_q, self.units), initializer=self.kernel_init,
                         regularizer=self.kernel_regularizer, constraint=self.kernel_constraint)
         if self.use_bias:
             self.add_weight('bias', (self.units,), initializer='zeros',
                             regularizer=self.bias_regularizer, constraint=self.bias_constraint)
         else:
             self.bias = None
-        self.input_spec = InputSpec(ndim=2, axes={-1: 4 * input_dim})
+        self.input_spec = InputSpec(ndim=2, axes={-1: width})
         self.built = True
 
     def call(self, inputs):
@@ -96,30 +83,16 @@ class QuaternionDense(Layer):
         return out
 
     def compute_output_shape(self, input_shape):
-        assert input_shape and len(input_shape) == 2
-        assert input_shape[-1]
-        output_shape = list(input_shape)
-        output_shape[-1] = self.units
-        return tuple(output_shape)
+        assert input_shape and len(input_shape) == 2 and input_shape[-1]
+        return tuple(input_shape[:-1]) + (self.units,)
 
     def get_config(self):
-        if self.kernel_initializer == 'quaternion':
-            ki = self.kernel_init
-        else:
-            ki = initializers.serialize(self.kernel_initializer)
-        config = {
-            'units': self.units,
-            'activation': activations.serialize(self.activation),
-            'use_bias': self.use_bias,
-            'init_criterion': self.init_criterion,
-            'kernel_initializer': ki,
-            'bias_initializer': initializers.serialize(self.bias_initializer),
-            'kernel_regularizer': regularizers.serialize(self.kernel_regularizer),
-            'bias_regularizer': regularizers.serialize(self.bias_regularizer),
-            'activity_regularizer': regularizers.serialize(self.activity_regularizer),
-            'kernel_constraint': constraints.serialize(self.kernel_constraint),
-            'bias_constraint': constraints.serialize(self.bias_constraint),
-            'seed': self.seed,
-        }
-        base_config = super(QuaternionDense, self).get_config()
-        return dict(list(base_config.items()) + list(config.items()))
+        cfg = super(QuaternionDense, self).get_config()
+        cfg.update(units=self.units, activation=activations.serialize(self.activation), use_bias=self.use_bias,
+                   init_criterion=self.init_criterion,
+                   kernel_initializer=(self.kernel_init if self.kernel_initializer == 'quaternion'
+                                       else initializers.serialize(self.kernel_initializer)))
+        for attr, registry in self._RESOLVED:
+            cfg[attr] = registry.serialize(getattr(self, attr))
+        cfg['seed'] = self.seed
+        return cfg
