@@ -104,6 +104,9 @@ ORACLE_CASES = [
      dict(padding='same', activation='relu')),
     ('cfg2_conv1d_b64_f32', 1, (64, 200, 160), (3, 40, 128),
      dict(padding='same', activation='relu')),
+    # BASELINE config 2 exactly as benched (batch 64, 64 filters): the oracle needs ~8 s for it
+    ('cfg2_conv1d_b64_f64_full', 1, (64, 200, 160), (3, 40, 256),
+     dict(padding='same', activation='relu')),
     ('conv1d_odd_channels', 1, (5, 37, 28), (5, 7, 36),
      dict(padding='same', strides=2, activation='relu')),
     ('conv2d_body_small', 2, (2, 14, 40, 128), (3, 5, 32, 128),
