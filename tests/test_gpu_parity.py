@@ -3,7 +3,9 @@
   (2) the CPU oracle on seeded inputs at sizes the oracle finishes in seconds.
 
 Tolerances (stated per BASELINE.json north_star: fwd/bwd within 1e-4 relative, fp32):
-  fp32 : max|got-want| <= 1e-4 * max|want|        (observed ~1e-6: the fp32 MFMA is an fmaf chain)
+  fp32 : max|got-want| <= 1e-4 * max|want|        (observed ~1e-6: the fp32 MFMA is an fmaf chain);
+         for relu layers the backward is compared on the GPU's own relu mask (outputs that are zero up
+         to rounding may land on either side of 0; the number of such sign differences is bounded)
   bf16 : x, kernel and dy are rounded to bf16 first and the oracle runs on the ROUNDED values in float64;
          16-bit outputs (y, dx) carry one bf16 rounding -> 1e-2 * max|want|; fp32 outputs
          (dkernel, dbias) -> 2e-3 (y feeding the relu mask is itself bf16-rounded)
@@ -143,6 +145,18 @@ def test_fp32_matches_oracle(case):
     _, rank, xs, ws, kw = case
     x, w, b, dy, want = _oracle_case(rank, xs, ws, kw, seed=7)
     got = _run_layer(qcnn_amd.functional, x, w, b, dy, rank, kw, torch.float32)
+    assert _rel_err(got['y'], want['y']) <= 1e-4
+    if kw.get('activation') == 'relu':
+        # The gradients depend on the relu mask, i.e. on the SIGN of outputs that are zero up to rounding:
+        # among millions of outputs a handful (|y| ~ 1e-7) come out on the other side of zero in float32
+        # than in the float64 oracle, and each such element moves dx by one full dy*w term (2.6 % of
+        # max|dx| at the full config-2 size).  The forward is compared above; the backward is compared
+        # on the SAME mask -- the oracle's backward run with the GPU's y.
+        from oracle import oracle
+        flipped = int(((got['y'] > 0) != (want['y'] > 0)).sum())
+        assert flipped <= max(4, got['y'].size // 100000), 'relu mask differs in %d outputs' % flipped
+        dx, dw, db = oracle.backward(x, w, b, dy, rank, y=got['y'].astype(np.float64), **kw)
+        want = dict(want, dx=dx, dkernel=dw, dbias=db)
     for k, v in got.items():
         err = _rel_err(v, want[k])
         assert err <= 1e-4, '%s: rel err %.3g' % (k, err)
