@@ -285,6 +285,8 @@ FULL_SIZE_16BIT = [
     ('cfg3_32to64_b256_bf16', torch.bfloat16, (256, 14, 200, 128), (3, 5, 32, 256)),
     # config 5 body layer (Cq = F = 256, fp16), 32 samples per GPU
     ('cfg5_body_b32_fp16', torch.float16, (32, 14, 200, 1024), (3, 5, 256, 1024)),
+    # config 3 head: TimeDistributed(QuaternionDense(256)) on B*T = 51 200 rows of 3584 features
+    ('cfg3_head_dense_bf16', torch.bfloat16, (51200, 3584), (896, 256)),
 ]
 
 
@@ -303,9 +305,12 @@ def test_full_size_16bit_mfma_kernels_agree_with_exact_fp32_kernels(case):
     g = torch.Generator(device=dev).manual_seed(21)
     x = torch.randn(xs, device=dev, generator=g).to(dtype)
     # kernel values exactly representable in 16 bits: both paths then multiply identical numbers
-    w = (torch.randn(ws, device=dev, generator=g) / (4.0 * (ws[-2] * 15) ** 0.5)).to(dtype).float()
+    w = (torch.randn(ws, device=dev, generator=g) / (4.0 * (ws[-2] * (15 if len(ws) > 2 else 1)) ** 0.5)).to(dtype).float()
     b = (torch.randn(ws[-1], device=dev, generator=g) / 10).to(dtype).float()
-    call = F.conv_call(tuple(xs), tuple(ws), dtype, 2, 1, 'same', 'channels_last', 1, 'relu', True)
+    if len(xs) == 2:
+        call = F.dense_call(tuple(xs), tuple(ws), dtype, 'relu', True)
+    else:
+        call = F.conv_call(tuple(xs), tuple(ws), dtype, 2, 1, 'same', 'channels_last', 1, 'relu', True)
 
     dy = torch.randn(call.y_shape, device=dev, generator=g).to(dtype)
 
