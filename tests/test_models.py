@@ -194,3 +194,31 @@ def test_engine_maxpool_matches_torch_including_ties(shape, pool, padding, axes,
     yr.backward(dy)
     assert y.shape == yr.shape and torch.equal(y, yr)
     assert torch.equal(x.grad, xr.grad.squeeze(-1))
+
+
+@pytest.mark.gpu
+def test_example_qcnn_learns_a_toy_problem():
+    """End to end through the C-ABI kernels: the example QCNN (models/example_model.py:15-40 counterpart)
+    trained with Adam(5e-4-style) on a separable toy problem -- the cross-entropy must drop markedly."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    dev = torch.device('cuda:0')
+    np.random.seed(4)
+    torch.manual_seed(4)
+    net = qcnn_amd.models.CNN(types.SimpleNamespace(model='QCNN'))
+    g = torch.Generator(device=dev).manual_seed(4)
+    labels = torch.randint(0, 8, (64,), device=dev, generator=g)
+    x = torch.rand(64, 250, 4, device=dev, generator=g) * 0.2
+    x[torch.arange(64, device=dev), labels * 30, :] += 2.0          # the class moves one "topic" spike
+    net(x[:2])                                                         # build
+    opt = torch.optim.Adam(net.parameters(), lr=2e-3)
+    losses = []
+    for _ in range(60):
+        opt.zero_grad()
+        p = net(x)
+        loss = -torch.log(p[torch.arange(64, device=dev), labels].clamp_min(1e-7)).mean()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert all(np.isfinite(losses))
+    assert losses[-1] < 0.5 * losses[0], (losses[0], losses[-1])
