@@ -148,6 +148,24 @@ int qk_dense_bwd_weight_acc(const qk_dense_desc_t *desc, const void *x, const vo
 int qk_conv_bwd(const qk_conv_desc_t *desc, const void *x, const void *dy, const void *y, const float *w,
                 void *dx, float *dw, float *dbias, void *workspace, size_t workspace_bytes, void *stream);
 
+/* Fused backward inside a chain of relu layers.  The relu derivative of layer L, dy * (y_L > 0), costs
+ * backward-weight a second input stream (every tap block re-reads y_L); the cheap place for it is the
+ * epilogue of layer L+1's backward-data, whose input x IS y_L.  Flags:
+ *   QK_BWD_MASK_DX      dx is returned as dx * (x > 0): the gradient w.r.t. the pre-activation of the layer
+ *                       that produced x (valid when x is a relu output);
+ *   QK_BWD_DY_PREMASKED dy already carries this layer's relu mask (its consumer was called with
+ *                       QK_BWD_MASK_DX): the mask is not applied again and y is not read (may be NULL).
+ * With flags == 0 this is qk_conv_bwd / qk_dense_bwd.  Applying a mask twice is harmless (idempotent);
+ * omitting QK_BWD_DY_PREMASKED is therefore always safe, setting it on an unmasked dy is not. */
+#define QK_BWD_MASK_DX 1
+#define QK_BWD_DY_PREMASKED 2
+int qk_conv_bwd_chain(const qk_conv_desc_t *desc, const void *x, const void *dy, const void *y, const float *w,
+                      void *dx, float *dw, float *dbias, int32_t flags, void *workspace, size_t workspace_bytes,
+                      void *stream);
+int qk_dense_bwd_chain(const qk_dense_desc_t *desc, const void *x, const void *dy, const void *y, const float *w,
+                       void *dx, float *dw, float *dbias, int32_t flags, void *workspace, size_t workspace_bytes,
+                       void *stream);
+
 /* Tap folding for layers with very few input channels (the first TIMIT layer has cq = 1: K = 4*taps).
  *   xcol[m, a*cq2 + t*cq + c] = x[pos(m, t), a*cq + c]      (0 in the padding and for t*cq + c >= taps*cq)
  * xcol is channels_last (N, *out_spatial, 4*cq2), cq2 a multiple of 8 with cq2 >= taps*cq.  The layer

@@ -13,6 +13,7 @@ QK_F32, QK_BF16, QK_F16 = 0, 1, 2
 QK_CH_LAST, QK_CH_FIRST = 0, 1
 QK_ACT_LINEAR, QK_ACT_RELU = 0, 1
 QK_OP_FWD, QK_OP_BWD_DATA, QK_OP_BWD_WEIGHT, QK_OP_BWD = 0, 1, 2, 3
+QK_BWD_MASK_DX, QK_BWD_DY_PREMASKED = 1, 2      # flags of qk_*_bwd_chain
 
 I32 = ctypes.c_int32
 
@@ -49,6 +50,8 @@ SYMBOLS = {
     'qk_conv_fwd': (ctypes.c_int, [_CD, _VP, _FP, _FP, _VP, _VP, _SZ, _VP]),
     'qk_conv_bwd_data': (ctypes.c_int, [_CD, _VP, _VP, _FP, _VP, _VP, _SZ, _VP]),
     'qk_conv_bwd_weight': (ctypes.c_int, [_CD, _VP, _VP, _VP, _FP, _FP, _VP, _SZ, _VP]),
+    'qk_conv_bwd_chain': (ctypes.c_int, [_CD, _VP, _VP, _VP, _FP, _VP, _FP, _FP, I32, _VP, _SZ, _VP]),
+    'qk_dense_bwd_chain': (ctypes.c_int, [_DD, _VP, _VP, _VP, _FP, _VP, _FP, _FP, I32, _VP, _SZ, _VP]),
     'qk_conv_bwd_weight_acc': (ctypes.c_int, [_CD, _VP, _VP, _VP, _FP, _FP, _VP, _SZ, _VP]),
     'qk_dense_bwd_weight_acc': (ctypes.c_int, [_DD, _VP, _VP, _VP, _FP, _FP, _VP, _SZ, _VP]),
     'qk_conv_bwd': (ctypes.c_int, [_CD, _VP, _VP, _VP, _FP, _VP, _FP, _FP, _VP, _SZ, _VP]),

@@ -176,7 +176,7 @@ int conv_fwd_impl(const qk_conv_desc_t *d, const void *x, const float *w, const 
 }
 
 int conv_bwd_data_impl(const qk_conv_desc_t *d, const void *dy, const void *y, const float *w, void *dx,
-                       void *ws, size_t wsb, hipStream_t stream)
+                       void *ws, size_t wsb, hipStream_t stream, const void *dx_mask = nullptr)
 {
     if (!dy || !w || !dx) { set_error("dy/w/dx must not be NULL"); return QK_ERR_INVALID_ARG; }
     const bool mask = d->activation == QK_ACT_RELU;
@@ -204,14 +204,23 @@ int conv_bwd_data_impl(const qk_conv_desc_t *d, const void *dy, const void *y, c
     g.sign_tbl = d->conj ? kSignConv : kSignConj;   // transposed table
     g.relu = 0; g.has_bias = 0; g.has_mask = mask ? 1 : 0;
     if (d->dtype != QK_F32) {
+        // the 16-bit kernels apply an epilogue mask themselves (needs 16-byte aligned rows of dx_mask)
+        g.ep_mask = (dx_mask && aligned(dx_mask, 16)) ? dx_mask : nullptr;
         const int r = try_hgemm_16(d->dtype, dy, mask ? y : nullptr, w, nullptr, dx, g, true, ws, wsb, stream);
-        if (r != 0) return r < 0 ? r : 0;
+        if (r < 0) return r;
+        if (r > 0) {
+            if (dx_mask && !g.ep_mask) return launch_mask_gt0(d->dtype, dx, dx_mask, (size_t)g.M * 4 * d->cq, stream);
+            return 0;
+        }
+        g.ep_mask = nullptr;
     }
     // the fp32-MFMA kernel stages the compact kernel in place with the channel/filter roles swapped
     g.w_swapped = 1;
     const bool vec = d->layout == QK_CH_LAST && d->cq % 4 == 0 && d->fq % 4 == 0 && aligned(w, 16) &&
                      vec_aligned(dy, d->dtype) && (!mask || vec_aligned(y, d->dtype));
-    return launch_hgemm(d->dtype, dy, mask ? y : nullptr, w, nullptr, dx, g, vec, stream);
+    if (int rc = launch_hgemm(d->dtype, dy, mask ? y : nullptr, w, nullptr, dx, g, vec, stream)) return rc;
+    if (dx_mask) return launch_mask_gt0(d->dtype, dx, dx_mask, (size_t)g.M * 4 * d->cq, stream);
+    return 0;
 }
 
 int conv_bwd_weight_impl(const qk_conv_desc_t *d, const void *x, const void *dy, const void *y, float *dw,
@@ -264,21 +273,29 @@ int conv_bwd_weight_impl(const qk_conv_desc_t *d, const void *x, const void *dy,
 // Fused backward: bwd-weight first (it reads dy and y once and, for RELU, also writes the masked dy
 // into the workspace), then bwd-data on the masked copy with no mask loads of its own.
 int conv_bwd_impl(const qk_conv_desc_t *d, const void *x, const void *dy, const void *y, const float *w,
-                  void *dx, float *dw, float *dbias, void *ws, size_t wsb, hipStream_t stream)
+                  void *dx, float *dw, float *dbias, void *ws, size_t wsb, hipStream_t stream, int flags = 0)
 {
     if (!dx) { set_error("dx must not be NULL (use qk_*_bwd_weight when d(input) is not needed)"); return QK_ERR_INVALID_ARG; }
+    if (flags & ~(QK_BWD_MASK_DX | QK_BWD_DY_PREMASKED)) { set_error("unknown backward flags 0x%x", flags); return QK_ERR_INVALID_ARG; }
+    const void *dx_mask = (flags & QK_BWD_MASK_DX) ? x : nullptr;
+    const bool relu = d->activation == QK_ACT_RELU && !(flags & QK_BWD_DY_PREMASKED);
+    const size_t bd = ws_bytes_impl(d, QK_OP_BWD_DATA);
+    if (!relu) {
+        // linear layer, or dy arrives with the relu mask applied: both gradients straight from dy
+        if (bd && (!ws || wsb < bd)) { set_error("bwd needs %zu workspace bytes, got %zu", bd, wsb); return QK_ERR_WORKSPACE; }
+        qk_conv_desc_t lin = *d;
+        lin.activation = QK_ACT_LINEAR;
+        if (int rc = conv_bwd_weight_impl(&lin, x, dy, nullptr, dw, dbias, nullptr, stream)) return rc;
+        return conv_bwd_data_impl(&lin, dy, nullptr, w, dx, ws, bd, stream, dx_mask);
+    }
     const size_t need = ws_bytes_impl(d, QK_OP_BWD);
     if (need && (!ws || wsb < need)) { set_error("bwd needs %zu workspace bytes, got %zu", need, wsb); return QK_ERR_WORKSPACE; }
-    const bool relu = d->activation == QK_ACT_RELU;
-    const size_t bd = ws_bytes_impl(d, QK_OP_BWD_DATA);
-    void *dym = relu ? static_cast<char *>(ws) + (bd + 255) / 256 * 256 : nullptr;
-    if (relu && (bd + 255) / 256 * 256 + dy_bytes(d) > wsb + 255) { set_error("workspace too small for the masked dy"); return QK_ERR_WORKSPACE; }
-    int rc = conv_bwd_weight_impl(d, x, dy, y, dw, dbias, dym, stream);
-    if (rc) return rc;
-    if (!relu) return conv_bwd_data_impl(d, dy, y, w, dx, ws, bd, stream);
+    void *dym = static_cast<char *>(ws) + (bd + 255) / 256 * 256;
+    if ((bd + 255) / 256 * 256 + dy_bytes(d) > wsb + 255) { set_error("workspace too small for the masked dy"); return QK_ERR_WORKSPACE; }
+    if (int rc = conv_bwd_weight_impl(d, x, dy, y, dw, dbias, dym, stream)) return rc;
     qk_conv_desc_t lin = *d;
     lin.activation = QK_ACT_LINEAR;
-    return conv_bwd_data_impl(&lin, dym, nullptr, w, dx, ws, bd, stream);
+    return conv_bwd_data_impl(&lin, dym, nullptr, w, dx, ws, bd, stream, dx_mask);
 }
 
 qk_conv_desc_t dense_as_conv(const qk_dense_desc_t *d)
@@ -346,6 +363,26 @@ int qk_conv_bwd_weight(const qk_conv_desc_t *desc, const void *x, const void *dy
     if (int rc = validate(desc, false)) return rc;
     void *dym = (workspace && workspace_bytes >= dy_bytes(desc) && aligned(workspace, 16)) ? workspace : nullptr;
     return check_launch(conv_bwd_weight_impl(desc, x, dy, y, dw, dbias, dym, (hipStream_t)stream), "qk_conv_bwd_weight");
+}
+
+int qk_conv_bwd_chain(const qk_conv_desc_t *desc, const void *x, const void *dy, const void *y, const float *w,
+                      void *dx, float *dw, float *dbias, int32_t flags, void *workspace, size_t workspace_bytes,
+                      void *stream)
+{
+    if (int rc = validate(desc, false)) return rc;
+    if ((flags & QK_BWD_MASK_DX) && !x) { set_error("QK_BWD_MASK_DX needs x"); return QK_ERR_INVALID_ARG; }
+    return check_launch(conv_bwd_impl(desc, x, dy, y, w, dx, dw, dbias, workspace, workspace_bytes, (hipStream_t)stream, flags), "qk_conv_bwd_chain");
+}
+
+int qk_dense_bwd_chain(const qk_dense_desc_t *desc, const void *x, const void *dy, const void *y, const float *w,
+                       void *dx, float *dw, float *dbias, int32_t flags, void *workspace, size_t workspace_bytes,
+                       void *stream)
+{
+    if (!desc) { set_error("descriptor is NULL"); return QK_ERR_INVALID_ARG; }
+    const qk_conv_desc_t c = dense_as_conv(desc);
+    if (int rc = validate(&c, true)) return rc;
+    if ((flags & QK_BWD_MASK_DX) && !x) { set_error("QK_BWD_MASK_DX needs x"); return QK_ERR_INVALID_ARG; }
+    return check_launch(conv_bwd_impl(&c, x, dy, y, w, dx, dw, dbias, workspace, workspace_bytes, (hipStream_t)stream, flags), "qk_dense_bwd_chain");
 }
 
 int qk_conv_bwd_weight_acc(const qk_conv_desc_t *desc, const void *x, const void *dy, const void *y,

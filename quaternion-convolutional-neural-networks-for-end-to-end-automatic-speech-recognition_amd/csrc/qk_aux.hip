@@ -78,6 +78,15 @@ k_fold_taps(const T *__restrict__ x, T *__restrict__ xcol, const GemmGeom g, int
     }
 }
 
+// data *= (mask > 0), elementwise (fallback of QK_BWD_MASK_DX for the kernels without an epilogue mask)
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_mask_gt0(T *__restrict__ data, const T *__restrict__ mask, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        if (!(to_f32(mask[i]) > 0.f)) data[i] = from_f32<T>(0.f);
+}
+
 // Max pooling, channels_last, non-overlapping windows.  One thread per (output position, group of V
 // channels); HBM-bound: forward reads x once and writes y, backward reads x and dy and writes dx.
 template <typename T, int V> struct VecOf;
@@ -152,6 +161,20 @@ int run_maxpool(bool backward, const void *x, const void *dy, void *out, const P
 }
 
 }  // namespace
+
+int launch_mask_gt0(int dtype, void *data, const void *mask, size_t n, hipStream_t stream)
+{
+    if (n == 0) return 0;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    switch (dtype) {
+    case QK_F32: hipLaunchKernelGGL(k_mask_gt0<float>, dim3((unsigned)blocks), dim3(256), 0, stream, (float *)data, (const float *)mask, n); break;
+    case QK_BF16: hipLaunchKernelGGL(k_mask_gt0<bf16>, dim3((unsigned)blocks), dim3(256), 0, stream, (bf16 *)data, (const bf16 *)mask, n); break;
+    case QK_F16: hipLaunchKernelGGL(k_mask_gt0<f16>, dim3((unsigned)blocks), dim3(256), 0, stream, (f16 *)data, (const f16 *)mask, n); break;
+    default: return QK_ERR_INVALID_ARG;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : QK_ERR_LAUNCH;
+}
 
 int launch_maxpool(int dtype, bool backward, const void *x, const void *dy, void *out, const PoolGeom &g, hipStream_t stream)
 {

@@ -54,6 +54,7 @@ struct GemmGeom {
     // band variant of the 16-bit kernel (qk_hgemm_bf16mfma.hip): rows of M run over PADDED lines of the
     // innermost axis (b_wp = out extent + k - 1 positions per line, b_nlines lines), band row j of a tile
     // holds input position (padded position + b_cshift); b_rev: taps walk the band backwards (bwd-data)
+    const void *ep_mask;                 // optional epilogue mask: out *= (ep_mask > 0), same layout as out (16-bit kernels)
     int b_wp, b_nlines, b_cshift, b_rev;
     unsigned b_in_bytes, b_w_bytes;      // extents of the input tensor and of the re-laid-out kernel (buffer resources)
 };
@@ -178,6 +179,7 @@ int launch_hgemm(int dtype, const void *in, const void *mask, const float *wk, c
 int launch_wgrad(int dtype, const void *x, const void *dy, const void *ymask, float *dw,
                  float *dbias, WgradGeom g, bool vec_ok, hipStream_t stream);
 int launch_fold_taps(int dtype, const void *x, void *xcol, const GemmGeom &g, int cq2, hipStream_t stream);
+int launch_mask_gt0(int dtype, void *data, const void *mask, size_t n, hipStream_t stream);   // data *= (mask > 0)
 struct PoolGeom { int batch, ih, iw, C, wh, ww, oh, ow; };
 int launch_maxpool(int dtype, bool backward, const void *x, const void *dy, void *out, const PoolGeom &g, hipStream_t stream);
 int launch_adam(float *p, float *g, float *m, float *v, size_t n, float lr, float b1,

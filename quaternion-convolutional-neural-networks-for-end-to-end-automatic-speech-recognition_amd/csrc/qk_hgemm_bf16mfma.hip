@@ -325,8 +325,12 @@ k_hgemm16(const T *__restrict__ in, const T *__restrict__ mask, const uint4 *__r
                 const int row = e_row + 16 * pass;
                 const uint4 val = *reinterpret_cast<const uint4 *>(ep + row * EP_PITCH + e_chunk * 16);
                 const int m = m0 + (wm * MT + mt) * 32 + row;
-                if (m < g.M)
-                    *reinterpret_cast<uint4 *>(out + (long long)m * (int)g.out_ss + ch0 + e_chunk * 8) = val;
+                if (m < g.M) {
+                    const long long o = (long long)m * (int)g.out_ss + ch0 + e_chunk * 8;
+                    uint4 v = val;
+                    if (g.ep_mask) v = mask8(v, *reinterpret_cast<const uint4 *>(static_cast<const T *>(g.ep_mask) + o));
+                    *reinterpret_cast<uint4 *>(out + o) = v;
+                }
             }
         }
     }
@@ -594,8 +598,12 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
             const int P = p0 + wm * 32 + row;
             const int line = P / WP;
             const int u = P - line * WP;
-            if (line < g.b_nlines && u < g.osp[2])
-                *reinterpret_cast<uint4 *>(out + (long long)(line * g.osp[2] + u) * (int)g.out_ss + ch0 + e_chunk * 8) = val;
+            if (line < g.b_nlines && u < g.osp[2]) {
+                const long long o = (long long)(line * g.osp[2] + u) * (int)g.out_ss + ch0 + e_chunk * 8;
+                uint4 v = val;
+                if (g.ep_mask) v = mask8(v, *reinterpret_cast<const uint4 *>(static_cast<const T *>(g.ep_mask) + o));
+                *reinterpret_cast<uint4 *>(out + o) = v;
+            }
         }
     }
 }

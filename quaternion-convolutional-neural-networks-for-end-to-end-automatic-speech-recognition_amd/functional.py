@@ -122,8 +122,8 @@ class _Call(object):
         return dw, db
 
 
-    def bwd(self, x, dy, y, w, has_bias, out=None):
-        """Fused backward (qk_*_bwd): returns (dx, dw, db)."""
+    def bwd(self, x, dy, y, w, has_bias, out=None, flags=0):
+        """Fused backward (qk_*_bwd, or qk_*_bwd_chain with L.QK_BWD_* flags): returns (dx, dw, db)."""
         if out is not None:
             dx, dw, db = out
         else:
@@ -133,8 +133,13 @@ class _Call(object):
         ws, n = self._ws(L.QK_OP_BWD, x)
         name = self.names[1].replace('_bwd_data', '_bwd')
         with _on_device(x.device):
-            rc = getattr(L.lib(), name)(ctypes.byref(self.desc), _ptr(x), _ptr(dy), _ptr(y), _ptr(w), _ptr(dx),
-                                        _ptr(dw), _ptr(db), _ptr(ws), n, _stream(x))
+            if flags:
+                name += '_chain'
+                rc = getattr(L.lib(), name)(ctypes.byref(self.desc), _ptr(x), _ptr(dy), _ptr(y), _ptr(w), _ptr(dx),
+                                            _ptr(dw), _ptr(db), int(flags), _ptr(ws), n, _stream(x))
+            else:
+                rc = getattr(L.lib(), name)(ctypes.byref(self.desc), _ptr(x), _ptr(dy), _ptr(y), _ptr(w), _ptr(dx),
+                                            _ptr(dw), _ptr(db), _ptr(ws), n, _stream(x))
         L.check(rc, name)
         return dx, dw, db
 
@@ -375,3 +380,61 @@ def maxpool2d_supported(x, window, strides):
     vec = 4 if x.dtype == torch.float32 else 8
     return (x.is_cuda and x.dtype in _DTYPES and x.dim() == 4 and tuple(window) == tuple(strides)
             and x.shape[-1] % vec == 0 and x.numel() > 0 and x.numel() < 2 ** 31 and x.data_ptr() % 16 == 0)
+
+
+class _ConvChainFn(torch.autograd.Function):
+    """A run of quaternion convolutions applied back to back (y_i = act_i(W_i (x) y_{i-1} + b_i)) as ONE
+    autograd node, so that the backward knows the structure: where layer i-1 ends in a fused relu, layer
+    i's backward-data returns its input gradient already multiplied by (y_{i-1} > 0) (epilogue of the
+    kernel, QK_BWD_MASK_DX) and layer i-1 runs its backward without the relu mask and without reading
+    y_{i-1} again (QK_BWD_DY_PREMASKED).  Gradients are identical to the layer-by-layer form."""
+
+    @staticmethod
+    def forward(ctx, x, calls, *params):
+        n = len(calls)
+        ws, bs = params[:n], params[n:]
+        acts = [x]
+        for call, w, b in zip(calls, ws, bs):
+            acts.append(call.fwd(acts[-1], w, b))
+        ctx.calls = calls
+        ctx.has_bias = [b is not None for b in bs]
+        ctx.save_for_backward(*acts, *ws)
+        return acts[-1]
+
+    @staticmethod
+    def backward(ctx, dy):
+        calls = ctx.calls
+        n = len(calls)
+        saved = ctx.saved_tensors
+        acts, ws = saved[:n + 1], saved[n + 1:]
+        dy = dy.contiguous()
+        dws, dbs = [None] * n, [None] * n
+        for i in range(n - 1, -1, -1):
+            flags = 0
+            if i > 0 and calls[i - 1].relu:
+                flags |= L.QK_BWD_MASK_DX
+            if i < n - 1 and calls[i].relu:
+                flags |= L.QK_BWD_DY_PREMASKED
+            dy, dws[i], dbs[i] = calls[i].bwd(acts[i], dy, acts[i + 1], ws[i], ctx.has_bias[i], flags=flags)
+        return (dy, None) + tuple(dws) + tuple(dbs)
+
+
+def quaternion_conv_chain(x, layers):
+    """Apply consecutive quaternion convolutions as one autograd node (see _ConvChainFn).
+    `layers`: sequence of (kernel, bias, kwargs) with the keyword arguments of quaternion_conv
+    (strides, padding, dilation_rate, activation ('relu' / 'linear' / None)); x and every layer are
+    channels_last here -- channels_first callers pass the channels-last view and move the axis back."""
+    _require_device(x, 'quaternion_conv_chain')
+    xp = x.contiguous()
+    calls, ws, bs = [], [], []
+    shape = tuple(xp.shape)
+    for kernel, bias, kw in layers:
+        rank = kernel.dim() - 2
+        _check_weights(kernel, bias, kernel.shape[-1])
+        call = conv_call(shape, tuple(kernel.shape), xp.dtype, rank, kw.get('strides', 1), kw.get('padding', 'valid'),
+                         'channels_last', kw.get('dilation_rate', 1), kw.get('activation'), bias is not None, False)
+        calls.append(call)
+        ws.append(kernel.contiguous())
+        bs.append(bias)
+        shape = tuple(call.y_shape)
+    return _ConvChainFn.apply(xp, tuple(calls), *ws, *bs)

@@ -7,6 +7,8 @@ n/2 convs of 2*sf filters (PReLU + Dropout after each) -> Permute/reshape to (B,
 `d` is the reference's attribute bag (num_layers, start_filter, act, aact, dropout, l2, model,
 quat_init); only the quaternion branch (`d.model == 'quaternion'`) is built.
 """
+import os
+
 import torch
 
 from ..complexnn import QuaternionConv2D, QuaternionDense
@@ -16,7 +18,7 @@ from ..layers import Dense, Dropout, MaxPooling2D, PReLU, TimeDistributed, ctc_b
 
 class TimitQCNN(torch.nn.Module):
     def __init__(self, num_layers=10, start_filter=32, act='relu', aact='none', dropout=0.0, l2=0.0,
-                 quat_init='quaternion', internal_layout='channels_last', fuse_head=True):
+                 quat_init='quaternion', internal_layout='channels_last', fuse_head=True, chain_convs=True):
         super(TimitQCNN, self).__init__()
         n, sf = num_layers, start_filter
         if aact != 'none':
@@ -29,6 +31,8 @@ class TimitQCNN(torch.nn.Module):
                           bias_initializer='zeros', use_bias=True)
         self.aact, self.rate = aact, dropout
         self.fuse_head = fuse_head          # first TimeDistributed dense as an (F, 1) convolution (no transpose copy)
+        self.chain_convs = (chain_convs and internal_layout == 'channels_last'      # body convs as one autograd node
+                            and not os.environ.get('QK_NO_CONV_CHAIN'))
         self.conv = QuaternionConv2D(sf, (3, 5), name='conv', **conv_args)
         self.pool = MaxPooling2D(pool_size=(1, 3), padding='same')
         widths = [sf] * (n // 2) + [2 * sf] * (n // 2)
@@ -48,9 +52,13 @@ class TimitQCNN(torch.nn.Module):
         o = self._act(self.conv(x), 0)
         o = self.pool(o)
         k = 1
-        for c in self.convs:
-            o = self.drop(self._act(c(o), k))
-            k += 1
+        if self.chain_convs and o.is_cuda and self.prelu is None and not (self.training and self.rate > 0) and len(self.convs) > 1:
+            o = self._convs_as_chain(o)
+            k += len(self.convs)
+        else:
+            for c in self.convs:
+                o = self.drop(self._act(c(o), k))
+                k += 1
         first = 0
         if self.fuse_head and o.is_cuda:
             o = self._act(self._head_as_conv(o), k)
@@ -65,6 +73,32 @@ class TimitQCNN(torch.nn.Module):
             if i < 2:
                 o = self.drop(o)
         return self.pred(o)
+
+    def _convs_as_chain(self, o):
+        """The n body convolutions (interspeech_model.py:105-137 with no advanced activation and no active
+        dropout) through functional.quaternion_conv_chain: same values and gradients as calling the layers
+        one by one, but each relu derivative is applied where it is cheapest."""
+        from .. import functional as Fq
+        from ..keras_like import activations
+        shape = tuple(o.shape)
+        layers, tail = [], []
+        for c in self.convs:
+            if not c.built:
+                c._build_device = o.device
+                c.build(shape)
+            shape = c.compute_output_shape(shape)
+            name = activations.serialize(c.activation)
+            if name not in ('linear', 'relu'):
+                return self._convs_one_by_one(o)
+            layers.append((c.kernel, c.bias, dict(strides=c.strides, padding=c.padding,
+                                                  dilation_rate=c.dilation_rate, activation=name)))
+        y = Fq.quaternion_conv_chain(o.movedim(1, -1), layers)       # (B, F, T, C) channels-last buffer
+        return y.movedim(-1, 1)
+
+    def _convs_one_by_one(self, o):
+        for c in self.convs:
+            o = c(o)
+        return o
 
     def _head_as_conv(self, o):
         """Permute((3,1,2)) + reshape + TimeDistributed(QuaternionDense) (interspeech_model.py:141-149) on

@@ -222,3 +222,31 @@ def test_example_qcnn_learns_a_toy_problem():
         losses.append(float(loss.detach()))
     assert all(np.isfinite(losses))
     assert losses[-1] < 0.5 * losses[0], (losses[0], losses[-1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype,tol', [(torch.float32, 1e-5), (torch.bfloat16, 3e-2)], ids=['fp32', 'bf16'])
+def test_conv_chain_node_equals_layer_by_layer(dtype, tol):
+    """TimitQCNN(chain_convs=True) runs its body convolutions as one autograd node whose backward moves
+    each relu derivative into the next layer's backward-data epilogue (qk_conv_bwd_chain flags); values
+    and every gradient must match the layer-by-layer model."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    dev = torch.device('cuda:0')
+    from qcnn_amd.models import TimitQCNN
+    x = torch.randn(2, 41, 40, 4, device=dev, generator=torch.Generator(device=dev).manual_seed(1)).to(dtype).permute(0, 3, 1, 2)
+    np.random.seed(5)
+    ref = TimitQCNN(num_layers=4, start_filter=32, act='relu', aact='none', dropout=0.0, chain_convs=False)
+    new = TimitQCNN(num_layers=4, start_filter=32, act='relu', aact='none', dropout=0.0, chain_convs=True)
+    with torch.no_grad():
+        ref(x), new(x)
+    new.load_state_dict(ref.state_dict())
+    outs = []
+    for m in (ref, new):
+        y = m(x)
+        (y.float() * torch.linspace(0.5, 1.5, 62, device=dev)).sum().backward()
+        outs.append([y.detach().float()] + [c.kernel.grad.clone() for c in m.convs] + [c.bias.grad.clone() for c in m.convs]
+                    + [m.conv.kernel.grad.clone()])
+    for a, b in zip(*outs):
+        assert a.shape == b.shape
+        assert float((a - b).abs().max()) <= tol * max(float(a.abs().max()), 1e-6)
