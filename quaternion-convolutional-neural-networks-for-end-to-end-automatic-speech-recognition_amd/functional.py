@@ -422,7 +422,7 @@ class _ConvChainFn(torch.autograd.Function):
 def quaternion_conv_chain(x, layers):
     """Apply consecutive quaternion convolutions as one autograd node (see _ConvChainFn).
     `layers`: sequence of (kernel, bias, kwargs) with the keyword arguments of quaternion_conv
-    (strides, padding, dilation_rate, activation ('relu' / 'linear' / None)); x and every layer are
+    (strides, padding, dilation_rate, activation ('relu' / 'linear' / None), conj); x and every layer are
     channels_last here -- channels_first callers pass the channels-last view and move the axis back."""
     _require_device(x, 'quaternion_conv_chain')
     xp = x.contiguous()
@@ -432,7 +432,8 @@ def quaternion_conv_chain(x, layers):
         rank = kernel.dim() - 2
         _check_weights(kernel, bias, kernel.shape[-1])
         call = conv_call(shape, tuple(kernel.shape), xp.dtype, rank, kw.get('strides', 1), kw.get('padding', 'valid'),
-                         'channels_last', kw.get('dilation_rate', 1), kw.get('activation'), bias is not None, False)
+                         'channels_last', kw.get('dilation_rate', 1), kw.get('activation'), bias is not None,
+                         bool(kw.get('conj', False)))
         calls.append(call)
         ws.append(kernel.contiguous())
         bs.append(bias)
