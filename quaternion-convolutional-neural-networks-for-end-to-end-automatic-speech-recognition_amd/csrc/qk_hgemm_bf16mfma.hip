@@ -581,10 +581,31 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
     constexpr int EP_PITCH = 80;
     char *ep = reinterpret_cast<char *>(lds) + wave * (32 * EP_PITCH);
     const int e_row = lane >> 2, e_chunk = lane & 3;
+    // output rows of this lane's two passes (rows of padded lines -> real rows), and -- for the chain
+    // backward (QK_BWD_MASK_DX) -- the eight 16-byte pieces of the mask tensor it will need, requested
+    // up front so that their latency hides under the transposes (the staging registers are idle here)
+    long long o_row[2];
+    bool o_ok[2];
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int P = p0 + wm * 32 + e_row + 16 * pass;
+        const int line = P / WP;
+        const int u = P - line * WP;
+        o_ok[pass] = line < g.b_nlines && u < g.osp[2];
+        o_row[pass] = (long long)(line * g.osp[2] + u) * (int)g.out_ss + j0 + wn * 32 + e_chunk * 8;
+    }
+    uint4 em[4][2];
+    if (g.ep_mask) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass)
+                em[b][pass] = o_ok[pass] ? *reinterpret_cast<const uint4 *>(static_cast<const T *>(g.ep_mask) + o_row[pass] + b * g.J)
+                                         : make_uint4(0u, 0u, 0u, 0u);
+    }
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-        const int ch0 = b * g.J + j0 + wn * 32;
-        const float bia = g.has_bias ? bias[ch0 + lr] : 0.f;
+        const float bia = g.has_bias ? bias[b * g.J + j0 + wn * 32 + lr] : 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             float v = acc[b][r] - accn[b][r] + bia;
@@ -594,15 +615,10 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
             const int row = e_row + 16 * pass;
-            const uint4 val = *reinterpret_cast<const uint4 *>(ep + row * EP_PITCH + e_chunk * 16);
-            const int P = p0 + wm * 32 + row;
-            const int line = P / WP;
-            const int u = P - line * WP;
-            if (line < g.b_nlines && u < g.osp[2]) {
-                const long long o = (long long)(line * g.osp[2] + u) * (int)g.out_ss + ch0 + e_chunk * 8;
-                uint4 v = val;
-                if (g.ep_mask) v = mask8(v, *reinterpret_cast<const uint4 *>(static_cast<const T *>(g.ep_mask) + o));
-                *reinterpret_cast<uint4 *>(out + o) = v;
+            uint4 v = *reinterpret_cast<const uint4 *>(ep + row * EP_PITCH + e_chunk * 16);
+            if (o_ok[pass]) {
+                if (g.ep_mask) v = mask8(v, em[b][pass]);
+                *reinterpret_cast<uint4 *>(out + o_row[pass] + b * g.J) = v;
             }
         }
     }
