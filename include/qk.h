@@ -124,6 +124,9 @@ int qk_conv_bwd_data(const qk_conv_desc_t *desc, const void *dy, const void *y, 
                      void *dx, void *workspace, size_t workspace_bytes, void *stream);
 
 /* dw [*kernel, cq, 4*fq] and dbias [4*fq] (NULL when !has_bias) are OVERWRITTEN.
+ * Layout contract: when dbias starts on the first 256-byte boundary behind the end of dw (less than 256
+ * bytes away), the bytes between the two are alignment padding OWNED BY THIS CALL and are zeroed with
+ * them (one fill instead of two).  Any other placement touches dw and dbias only.
  * Optional: with activation == RELU and a 16-byte-aligned workspace of at least |dy| bytes (rounded
  * up to 256), the masked gradient dy * (y > 0) is left at the start of the workspace in dy's layout;
  * qk_conv_bwd_data may then be called on it with activation = LINEAR (no y reads).  This is how a

@@ -255,7 +255,10 @@ int conv_bwd_weight_impl(const qk_conv_desc_t *d, const void *x, const void *dy,
     const char *db_c = reinterpret_cast<const char *>(dbias);
     if (accumulate) {
         // the caller's buffers already hold what this call adds to
-    } else if (g.want_dbias && db_c >= dw_end && db_c - dw_end <= 256) {
+    } else if (g.want_dbias && (db_c == dw_end ||
+                                (db_c > dw_end && db_c - dw_end < 256 && reinterpret_cast<uintptr_t>(db_c) % 256 == 0))) {
+        // adjacent, or dbias on the first 256-byte boundary behind dw (a flat gradient buffer with aligned
+        // views): the bytes in between are alignment padding by contract (include/qk.h) -- one fill
         if (hipMemsetAsync(dw, 0, (size_t)(db_c - reinterpret_cast<const char *>(dw)) + dbb, stream) != hipSuccess) { set_error("memset dw failed"); return QK_ERR_LAUNCH; }
     } else {
         if (hipMemsetAsync(dw, 0, dwb, stream) != hipSuccess) { set_error("memset dw failed"); return QK_ERR_LAUNCH; }

@@ -95,7 +95,7 @@ k_hgemm16(const T *__restrict__ in, const T *__restrict__ mask, const uint4 *__r
     static_assert(BM % 64 == 0 && (16 * BF) % 512 == 0, "tile/threads");
     constexpr unsigned TBL = CONJ ? kSignConj : kSignConv;
     constexpr int TILE_U = BM * 16 + 16 * BF;       // 16-byte units of one (A, B) tile pair
-    __shared__ __attribute__((aligned(16))) uint4 lds[2 * TILE_U];   // double buffered
+    __shared__ __attribute__((aligned(16))) uint4 lds[2 * TILE_U + 1];   // double buffered (+ one word: tile tap mask)
     // A: [row][slot ^ (row & 15)] at lds + buf*TILE_U ; B: [slot][part][j] right behind it
 
     const int tid = threadIdx.x;
@@ -113,7 +113,6 @@ k_hgemm16(const T *__restrict__ in, const T *__restrict__ mask, const uint4 *__r
     const int m0 = mtile * BM;
     const int j0 = blockIdx.y * BF;
     const int nkc = g.Q / 32;
-    const int iters = g.taps * nkc;
 
     // ---- staging ---------------------------------------------------------------------------
     // 8 threads per row, each moving 2 of the row's 16 slots (slot = s8 and s8 + 8): the 8 lanes a
@@ -147,6 +146,23 @@ k_hgemm16(const T *__restrict__ in, const T *__restrict__ mask, const uint4 *__r
                     }
         }
     }
+    // Taps that no row of this tile can use contribute exact zeros: they are skipped altogether (K steps,
+    // loads, MFMAs).  That is the whole backward-data of a 'valid' convolution whose kernel spans an axis
+    // -- the TimeDistributed dense head run as an (F, 1) convolution: one of the F taps per row -- and the
+    // border image rows of every 'same' convolution.  The mask is the OR of the rows' masks, via one LDS word.
+    unsigned tile_taps;
+    {
+        unsigned *tw = reinterpret_cast<unsigned *>(lds + 2 * TILE_U);
+        if (tid == 0) *tw = 0u;
+        __syncthreads();
+        unsigned mine = 0;
+#pragma unroll
+        for (int r = 0; r < RPT2; ++r) mine |= tapmask[r];
+        if (mine) atomicOr(tw, mine);
+        __syncthreads();
+        tile_taps = __builtin_amdgcn_readfirstlane(*tw);
+    }
+    const int iters = __builtin_popcount(tile_taps) * nkc;
     // slot s8 / s8+8 -> (component, 8-channel group) -> element offset inside the row
     const int cmp_lo = s8 >> 2, cmp_hi = cmp_lo + 2, sub = (s8 & 3) * 8;
     static_assert(BU == 1 || BU == 2, "B prefetch registers are named, not an array: hipcc parks a\n"
@@ -161,12 +177,20 @@ k_hgemm16(const T *__restrict__ in, const T *__restrict__ mask, const uint4 *__r
                  lt2 * g.pb[2] * (int)g.in_ss[2] + lkc * 32 + sub;
         lwsrc = wq + (long long)(ltap * nkc + lkc) * 16 * g.J;
     };
-    auto advance_loads = [&]() {
+    auto advance_loads = [&]() {                            // only called while a further valid tile exists
         if (++lkc == nkc) {
-            lkc = 0; ++ltap;
-            if (++lt2 == g.ks[2]) { lt2 = 0; if (++lt1 == g.ks[1]) { lt1 = 0; ++lt0; } }
+            lkc = 0;
+            do {
+                ++ltap;
+                if (++lt2 == g.ks[2]) { lt2 = 0; if (++lt1 == g.ks[1]) { lt1 = 0; ++lt0; } }
+            } while (!((tile_taps >> ltap) & 1u));
         }
     };
+    if (tile_taps)                                          // first tap any row uses
+        while (!((tile_taps >> ltap) & 1u)) {
+            ++ltap;
+            if (++lt2 == g.ks[2]) { lt2 = 0; if (++lt1 == g.ks[1]) { lt1 = 0; ++lt0; } }
+        }
     auto load_a = [&](int r) {
         const bool ok = (tapmask[r] >> ltap) & 1u;
         const int off = base_off[r] + ldelta;
@@ -391,7 +415,7 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
     constexpr int BAND = BM + KIN - 1;             // rows of the A band
     constexpr int A_U = (BM + 8) * 16;             // 16-byte units of one band buffer
     constexpr int B_U = 16 * BF;
-    __shared__ __attribute__((aligned(16))) uint4 lds[2 * A_U + 2 * B_U];
+    __shared__ __attribute__((aligned(16))) uint4 lds[2 * A_U + 2 * B_U + 1];   // (+ one word: tile tap mask)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -407,8 +431,6 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
     const int p0 = mtile * BM;
     const int j0 = blockIdx.y * BF;
     const int nkc = g.Q / 32;
-    const int groups = g.ks[0] * g.ks[1] * nkc;
-    const int substeps = groups * KIN;
 
     // ---- band rows of this thread (decoded once) ------------------------------------------------
     constexpr int RPT3 = (BAND + 63) / 64;
@@ -438,6 +460,21 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
                 }
         }
     }
+    // outer taps no row of this band can use are skipped altogether (see k_hgemm16): border image rows
+    unsigned tile_ot;
+    {
+        unsigned *tw = reinterpret_cast<unsigned *>(lds + 2 * A_U + 2 * B_U);
+        if (tid == 0) *tw = 0u;
+        __syncthreads();
+        unsigned mine = 0;
+#pragma unroll
+        for (int r = 0; r < RPT3; ++r) mine |= omask[r];
+        if (mine) atomicOr(tw, mine);
+        __syncthreads();
+        tile_ot = __builtin_amdgcn_readfirstlane(*tw);
+    }
+    const int groups = __builtin_popcount(tile_ot) * nkc;
+    const int substeps = groups * KIN;
     const int cmp_lo = s8 >> 2, sub = (s8 & 3) * 8;
     const __amdgpu_buffer_rsrc_t rin = make_rsrc16(in, g.b_in_bytes), rw = make_rsrc16(wq, g.b_w_bytes);
     const unsigned a_thr = (unsigned)(cmp_lo * g.Q + sub) * 2u;        // this thread's (component, 8 channels) of a row
@@ -455,10 +492,20 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
     auto a_prep = [&]() {
         adelta = at0 * g.pb[0] * (int)g.in_ss[0] + at1 * g.pb[1] * (int)g.in_ss[1] + akc * 32;
     };
+    // next used outer tap = lowest set bit above the current one; (t0, t1) = divmod by ks[1] through a
+    // 16-bit reciprocal (exact for these < 32 values).  Written loop-free on purpose: a data-dependent
+    // loop here made hipcc keep base_off[] / omask[] in LDS and scratch.
+    const unsigned inv_ks1 = (65536u + (unsigned)g.ks[1] - 1u) / (unsigned)g.ks[1];
+    auto a_set_outer = [&](unsigned ot) {
+        aot = (int)ot;
+        at0 = (int)((ot * inv_ks1) >> 16);
+        at1 = (int)ot - at0 * g.ks[1];
+    };
+    if (tile_ot) a_set_outer((unsigned)__builtin_ctz(tile_ot));         // first outer tap any row uses
     auto a_advance_if_more = [&]() {
         if (a_next + 1 < groups) {
             ++a_next;
-            if (++akc == nkc) { akc = 0; ++aot; if (++at1 == g.ks[1]) { at1 = 0; ++at0; } }
+            if (++akc == nkc) { akc = 0; a_set_outer((unsigned)__builtin_ctz(tile_ot & (~1u << aot))); }
         }
     };
     auto load_a = [&](int r) {
@@ -491,10 +538,11 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
         const int tap = bot * KIN + bti;           // sub-step ti IS inner tap ti; b_rev only mirrors the band offset
         bsoff = (unsigned)((tap * nkc + bkc) * 16 * g.J) * 16u;
     };
+    if (tile_ot) bot = __builtin_ctz(tile_ot);
     auto b_advance_if_more = [&]() {
         if (b_next + 1 < substeps) {
             ++b_next;
-            if (++bti == KIN) { bti = 0; if (++bkc == nkc) { bkc = 0; ++bot; } }
+            if (++bti == KIN) { bti = 0; if (++bkc == nkc) { bkc = 0; bot = __builtin_ctz(tile_ot & (~1u << bot)); } }
         }
     };
     auto load_b = [&]() {

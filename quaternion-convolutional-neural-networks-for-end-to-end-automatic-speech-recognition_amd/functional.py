@@ -303,7 +303,10 @@ def _folded_conv(x, kernel, bias, rank, strides, padding, data_format, dilation_
     ch_first = data_format == 'channels_first'
     xp = x.contiguous()
     taps, cq = int(math.prod(kernel.shape[:rank])), kernel.shape[-2]
-    cq2 = 32 if x.dtype != torch.float32 else (taps * cq + 7) // 8 * 8     # 16-bit MFMA path wants cq2 % 32 == 0
+    # folded channel count: a multiple of 8 (fp32 kernels) / of 32 (the 16-bit MFMA path) that holds every
+    # (tap, channel) pair -- 32 for the 15-tap TIMIT layer, 64 for e.g. a 7x7 kernel on one channel
+    gran = 32 if x.dtype != torch.float32 else 8
+    cq2 = (taps * cq + gran - 1) // gran * gran
     call = conv_call(tuple(xp.shape), tuple(kernel.shape), xp.dtype, rank, strides, padding, data_format,
                      dilation_rate, None, False, False)
     d = call.desc

@@ -158,22 +158,44 @@ class AveragePooling2D(_Pooling):
 
 
 class PReLU(Layer):
-    """keras.layers.PReLU: alpha has the input's shape without the batch axis, broadcast (size 1)
-    on `shared_axes`; axes of unknown length are shared too (the TIMIT model's time axis)."""
+    """keras.layers.PReLU: alpha has the input's shape without the batch axis, with size 1 on the shared
+    axes.  Keras writes `param_shape[i - 1] = 1` for every i in `shared_axes`, so axis 0 -- which the TIMIT
+    model passes, PReLU(shared_axes=[1, 0]), interspeech_model.py:99-101 -- lands on index -1 and shares the
+    LAST axis: alpha is (1, F, 1) behind a (B, C, F, T) convolution (one slope per frequency row, shared over
+    channels and over the variable-length time axis) and (1, 1) behind a TimeDistributed dense layer.
+    An axis whose length is unknown (None) is shared as well -- it could not be sized."""
 
-    def __init__(self, alpha_initializer='zeros', shared_axes=None, **kwargs):
+    def __init__(self, alpha_initializer='zeros', alpha_regularizer=None, alpha_constraint=None,
+                 shared_axes=None, **kwargs):
         super(PReLU, self).__init__(**kwargs)
-        self.shared_axes = [a for a in (shared_axes or []) if a != 0]
+        if shared_axes is None:
+            self.shared_axes = None
+        elif not isinstance(shared_axes, (list, tuple)):
+            self.shared_axes = [shared_axes]
+        else:
+            self.shared_axes = list(shared_axes)
         self.alpha_initializer = initializers.get(alpha_initializer)
+        self.alpha_regularizer = regularizers.get(alpha_regularizer)
+        self.alpha_constraint = alpha_constraint
 
     def build(self, input_shape):
-        shape = [1 if (i + 1) in self.shared_axes or d is None else d for i, d in enumerate(input_shape[1:])]
-        self.add_weight('alpha', tuple(shape), initializer=self.alpha_initializer)
+        shape = [1 if d is None else d for d in input_shape[1:]]
+        for i in self.shared_axes or []:
+            shape[i - 1] = 1                                   # i == 0 -> index -1, as in Keras
+        self.add_weight('alpha', tuple(shape), initializer=self.alpha_initializer,
+                        regularizer=self.alpha_regularizer, constraint=self.alpha_constraint)
         self.built = True
 
     def call(self, inputs):
         a = self.alpha.to(inputs.dtype)
         return torch.relu(inputs) - a * torch.relu(-inputs)
+
+    def get_config(self):
+        cfg = super(PReLU, self).get_config()
+        cfg.update(alpha_initializer=initializers.serialize(self.alpha_initializer),
+                   alpha_regularizer=regularizers.serialize(self.alpha_regularizer),
+                   shared_axes=self.shared_axes)
+        return cfg
 
 
 class Permute(Layer):
@@ -199,10 +221,12 @@ class TimeDistributed(Layer):
 
 
 def ctc_batch_cost(y_pred, labels, input_length, label_length, blank=None):
-    """K.ctc_batch_cost (interspeech_model.py:37-39): y_pred (B, T, C) softmax outputs, blank = last
-    class; returns the per-sample negative log-likelihood (B, 1)."""
+    """K.ctc_batch_cost (interspeech_model.py:37-39): y_pred (B, T, C) softmax outputs, blank = last class; returns
+    the per-sample negative log-likelihood (B, 1).  Keras 2.x hands log(y_pred + epsilon()) to tf.nn.ctc_loss as
+    LOGITS, and that op normalises them again (softmax), so the log-probabilities are
+    log_softmax(log(y_pred + 1e-7)); ctc_merge_repeated=True, no collapse of repeated labels (TF defaults)."""
     blank = y_pred.shape[-1] - 1 if blank is None else blank
-    logp = torch.log(y_pred.float().clamp_min(1e-7)).transpose(0, 1)
+    logp = torch.log_softmax(torch.log(y_pred.float() + 1e-7), dim=-1).transpose(0, 1)
     loss = F.ctc_loss(logp, labels.long(), input_length.reshape(-1).long(), label_length.reshape(-1).long(),
                       blank=blank, reduction='none', zero_infinity=False)
     return loss.reshape(-1, 1)

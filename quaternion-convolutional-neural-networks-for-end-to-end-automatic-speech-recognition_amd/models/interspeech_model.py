@@ -12,7 +12,7 @@ import os
 import torch
 
 from ..complexnn import QuaternionConv2D, QuaternionDense
-from ..keras_like import regularizers
+from ..keras_like import Layer, regularizers
 from ..layers import Dense, Dropout, MaxPooling2D, PReLU, TimeDistributed, ctc_batch_cost
 
 
@@ -52,19 +52,22 @@ class TimitQCNN(torch.nn.Module):
         o = self._act(self.conv(x), 0)
         o = self.pool(o)
         k = 1
-        if self.chain_convs and o.is_cuda and self.prelu is None and not (self.training and self.rate > 0) and len(self.convs) > 1:
-            o = self._convs_as_chain(o)
+        plain = self.prelu is None and not (self.training and self.rate > 0)
+        first = 0
+        if self.chain_convs and o.is_cuda and plain and len(self.convs) > 1:
+            o, with_head = self._convs_as_chain(o)
             k += len(self.convs)
+            if with_head:                                    # first TimeDistributed dense ran inside the chain
+                k, first = k + 1, 1
         else:
             for c in self.convs:
                 o = self.drop(self._act(c(o), k))
                 k += 1
-        first = 0
-        if self.fuse_head and o.is_cuda:
+        if first == 0 and self.fuse_head and o.is_cuda:
             o = self._act(self._head_as_conv(o), k)
             o = self.drop(o)
             k, first = k + 1, 1
-        else:
+        elif first == 0:
             o = o.permute(0, 3, 1, 2)                        # Permute((3,1,2)): (B, T, C, F)
             o = o.reshape(o.shape[0], o.shape[1], o.shape[2] * o.shape[3])
         for i in range(first, len(self.dense)):
@@ -74,14 +77,27 @@ class TimitQCNN(torch.nn.Module):
                 o = self.drop(o)
         return self.pred(o)
 
+    def _head_kernel(self, o_shape, device):
+        """The first dense layer's weight r[(cq*F + f), :] viewed as the (F, 1, Cq, units) kernel of the
+        equivalent 'valid' conj-convolution over (F, T) (see _head_as_conv)."""
+        dl = self.dense[0].layer
+        b, c, f, t = o_shape
+        if not dl.built:
+            dl._build_device = device
+            dl.build((None, c * f))
+        return dl, dl.r.view(c // 4, f, dl.r.shape[-1]).permute(1, 0, 2).unsqueeze(1).contiguous()
+
     def _convs_as_chain(self, o):
         """The n body convolutions (interspeech_model.py:105-137 with no advanced activation and no active
         dropout) through functional.quaternion_conv_chain: same values and gradients as calling the layers
-        one by one, but each relu derivative is applied where it is cheapest."""
+        one by one, but each relu derivative is applied where it is cheapest.
+        With fuse_head the first TimeDistributed dense layer (as an (F, 1) convolution) is the last link
+        of the chain, so the last body convolution's relu derivative also moves into a backward-data
+        epilogue.  Returns (tensor, head_included)."""
         from .. import functional as Fq
         from ..keras_like import activations
         shape = tuple(o.shape)
-        layers, tail = [], []
+        layers = []
         for c in self.convs:
             if not c.built:
                 c._build_device = o.device
@@ -89,11 +105,20 @@ class TimitQCNN(torch.nn.Module):
             shape = c.compute_output_shape(shape)
             name = activations.serialize(c.activation)
             if name not in ('linear', 'relu'):
-                return self._convs_one_by_one(o)
+                return self._convs_one_by_one(o), False
             layers.append((c.kernel, c.bias, dict(strides=c.strides, padding=c.padding,
                                                   dilation_rate=c.dilation_rate, activation=name)))
+        with_head = False
+        if self.fuse_head:
+            dl, w = self._head_kernel(shape, o.device)
+            name = activations.serialize(dl.activation)
+            if name in ('linear', 'relu'):
+                layers.append((w, dl.bias, dict(strides=1, padding='valid', dilation_rate=1, activation=name, conj=True)))
+                with_head = True
         y = Fq.quaternion_conv_chain(o.movedim(1, -1), layers)       # (B, F, T, C) channels-last buffer
-        return y.movedim(-1, 1)
+        if with_head:
+            return y.reshape(y.shape[0], y.shape[2], y.shape[3]), True   # (B, 1, T, units) -> (B, T, units)
+        return y.movedim(-1, 1), False
 
     def _convs_one_by_one(self, o):
         for c in self.convs:
@@ -108,26 +133,37 @@ class TimitQCNN(torch.nn.Module):
         r[(cq*F + f), :] re-indexed to [f, 0, cq, :].  Parameters stay the reference's (in_q, units)."""
         from .. import functional as Fq
         from ..keras_like import activations
-        dl = self.dense[0].layer
         b, c, f, t = o.shape
-        if not dl.built:
-            dl._build_device = o.device
-            dl.build((None, c * f))
-        w = dl.r.view(c // 4, f, dl.r.shape[-1]).permute(1, 0, 2).unsqueeze(1)       # (F, 1, Cq, units)
+        dl, w = self._head_kernel(tuple(o.shape), o.device)
         name = activations.serialize(dl.activation)
         fused = name if name in ('linear', 'relu') else 'linear'
-        y = Fq.quaternion_conv(o, w.contiguous(), dl.bias, 1, 'valid', 'channels_first', 1, fused, conj=True)
+        y = Fq.quaternion_conv(o, w, dl.bias, 1, 'valid', 'channels_first', 1, fused, conj=True)
         if fused != name:
             y = dl.activation(y)
         return y.reshape(b, dl.r.shape[-1], t).permute(0, 2, 1)                      # (B, units, 1, T) -> (B, T, units)
 
     def ctc_loss(self, x, labels, input_length, label_length):
+        """The model output of the reference: K.ctc_batch_cost per sample, shape (B, 1) (interspeech_model.py:178)."""
         return ctc_batch_cost(self(x), labels, input_length, label_length)
+
+    def regularization_loss(self):
+        """Sum of the kernel regularisers (l2(d.l2) on every conv / dense kernel, interspeech_model.py:63,68,173):
+        the term Keras adds to the compiled model's loss on top of the CTC cost."""
+        terms = [t for m in self.modules() if isinstance(m, Layer) for t in m.regularization_losses()]
+        if not terms:
+            return next(self.parameters()).new_zeros(())
+        return torch.stack([t.float() for t in terms]).sum()
+
+    def training_loss(self, x, labels, input_length, label_length):
+        """What training the reference model minimises: mean CTC cost over the batch (the usual
+        `loss={'ctc': lambda y_true, y_pred: y_pred}` compile) + the regularisation terms."""
+        return self.ctc_loss(x, labels, input_length, label_length).mean() + self.regularization_loss()
 
 
 def getTimitModel2D(d):
     """(model, val_function) like the reference: `model(x)` gives the (B, T, 62) posteriors,
-    `model.ctc_loss(...)` the CTC cost of interspeech_model.py:178; val_function(x) == model(x)."""
+    `model.ctc_loss(...)` the CTC cost of interspeech_model.py:178, `model.training_loss(...)` that cost
+    averaged over the batch plus the l2 terms Keras adds (d.l2); val_function(x) == model(x)."""
     if getattr(d, 'model', 'quaternion') != 'quaternion':
         raise NotImplementedError('only the quaternion branch of getTimitModel2D is provided')
     m = TimitQCNN(d.num_layers, d.start_filter, d.act, d.aact, d.dropout, getattr(d, 'l2', 0.0),

@@ -1,0 +1,174 @@
+"""TEST INFRASTRUCTURE -- float64 numpy composition of the TIMIT quaternion CNN around the CPU oracle.
+
+What models/interspeech_model.py:getTimitModel2D (:45-185) of the reference builds, restated layer by layer:
+the quaternion layers are the oracle's (oracle/oracle.py: conv.py:288-345, dense.py:126-164 and their
+autodiff), the stock Keras layers around them are a few lines of numpy each (the third-party semantics
+are cited at each function).  Forward AND backward, so a GPU model can be compared gradient by gradient.
+Only tests import this.
+"""
+import numpy as np
+
+from oracle import oracle
+
+
+def _ident(a):
+    return a
+
+
+def maxpool_freq_same(x, win=3):
+    """keras MaxPooling2D((1, win), padding='same') with the default channels_last data_format applied to a
+    channels_first (B, C, F, T) tensor (interspeech_model.py:103): pools axis 2.  TF 'same': out = ceil(F/win),
+    padding on the high side only here (F=41, win=3 -> one cell), padded cells never win."""
+    b, c, f, t = x.shape
+    out = -(-f // win)
+    y = np.empty((b, c, out, t))
+    arg = np.empty((b, c, out, t), dtype=np.int64)
+    for o in range(out):
+        seg = x[:, :, o * win:min((o + 1) * win, f), :]
+        arg[:, :, o, :] = seg.argmax(2) + o * win          # first maximum wins (TF / torch)
+        y[:, :, o, :] = seg.max(2)
+    return y, arg
+
+
+def maxpool_freq_same_bwd(dy, arg, f):
+    b, c, out, t = dy.shape
+    dx = np.zeros((b, c, f, t))
+    bi, ci, oi, ti = np.meshgrid(np.arange(b), np.arange(c), np.arange(out), np.arange(t), indexing='ij')
+    np.add.at(dx, (bi, ci, arg, ti), dy)
+    return dx
+
+
+def prelu(x, alpha):
+    """keras.layers.PReLU: relu(x) - alpha * relu(-x), alpha broadcast over its size-1 (shared) axes."""
+    return np.maximum(x, 0) - alpha[None] * np.maximum(-x, 0)
+
+
+def prelu_bwd(x, alpha, dy):
+    dx = dy * np.where(x > 0, 1.0, 0.0) + dy * alpha[None] * np.where(x < 0, 1.0, 0.0)
+    full = dy * np.minimum(x, 0)                           # d/d alpha of -alpha * relu(-x) = min(x, 0)
+    axes = tuple(i + 1 for i, n in enumerate(alpha.shape) if n == 1)
+    dalpha = full.sum(axis=(0,) + axes, keepdims=True)[0]
+    return dx, dalpha.reshape(alpha.shape)
+
+
+def keras_prelu_alpha_shape(input_shape, shared_axes):
+    """param_shape of keras.layers.PReLU.build: input_shape[1:] with `param_shape[i - 1] = 1` for every shared axis
+    (so axis 0 lands on index -1)."""
+    shape = [1 if d is None else d for d in input_shape[1:]]
+    for i in shared_axes:
+        shape[i - 1] = 1
+    return tuple(shape)
+
+
+class TimitRef(object):
+    """Parameters pulled from a qcnn_amd.models.TimitQCNN instance (as float64 numpy); forward/backward in float64.
+
+    `rnd` emulates 16-bit storage of activations (identity for fp32 runs); `rnd_w` the rounding of the kernels
+    the 16-bit matrix-core path applies (identity for fp32 runs)."""
+
+    def __init__(self, model, act='relu', rnd=_ident, rnd_w=_ident):
+        g = lambda t: t.detach().cpu().double().numpy()
+        self.act = act if model.prelu is None else None
+        self.rnd, self.rnd_w = rnd, rnd_w
+        self.conv = (g(model.conv.kernel), g(model.conv.bias))
+        self.convs = [(g(c.kernel), g(c.bias)) for c in model.convs]
+        self.dense = [(g(d.layer.r), g(d.layer.bias)) for d in model.dense]
+        self.pred = (g(model.pred.layer.kernel), g(model.pred.layer.bias))
+        self.alphas = [g(p.alpha) for p in model.prelu] if model.prelu is not None else None
+
+    # ---- forward ----------------------------------------------------------------------------
+    def forward(self, x):
+        rnd, rw = self.rnd, self.rnd_w
+        self.saved = s = {}
+        kw = dict(padding='same', data_format='channels_first', activation=self.act)
+        k = 0
+
+        def activate(pre, k):
+            if self.alphas is None:
+                return pre
+            s['pre%d' % k] = pre
+            return rnd(prelu(pre, self.alphas[k]))
+
+        s['x'] = x
+        h = rnd(oracle.forward(x, rw(self.conv[0]), self.conv[1], 2, **kw))
+        s['y_conv'] = h
+        h = activate(h, k); k += 1
+        s['pool_in_f'] = h.shape[2]
+        h, s['pool_arg'] = maxpool_freq_same(h, 3)
+        for i, (w, b) in enumerate(self.convs):
+            s['x_c%d' % i] = h
+            h = rnd(oracle.forward(h, rw(w), b, 2, **kw))
+            s['y_c%d' % i] = h
+            h = activate(h, k); k += 1
+        bsz, c, f, t = h.shape
+        s['perm_shape'] = h.shape
+        h = h.transpose(0, 3, 1, 2).reshape(bsz * t, c * f)        # Permute((3,1,2)) + reshape, TimeDistributed
+        for i, (w, b) in enumerate(self.dense):
+            s['x_d%d' % i] = h
+            y = rnd(oracle.forward(h, rw(w), b, 0, activation=self.act))
+            s['y_d%d' % i] = y
+            if self.alphas is not None:
+                # TimeDistributed output is (B, T, units): alpha (1, 1) broadcasts over everything
+                s['pre%d' % k] = y
+                y = rnd(prelu(y.reshape(bsz, t, -1), self.alphas[k]).reshape(bsz * t, -1))
+            k += 1
+            h = y
+        s['x_pred'] = h
+        z = rnd(rnd(h @ rw(self.pred[0])) + rw(self.pred[1]))
+        e = np.exp(z - z.max(1, keepdims=True))
+        p = rnd(e / e.sum(1, keepdims=True))
+        s['p'] = p
+        return p.reshape(bsz, t, -1)
+
+    # ---- backward of sum(pred * dpred) --------------------------------------------------------
+    def backward(self, dpred):
+        s = self.saved
+        grads = {}
+        bsz, c, f, t = s['perm_shape']
+        p = s['p']
+        dp = dpred.reshape(p.shape)
+        dz = p * (dp - (dp * p).sum(1, keepdims=True))
+        grads['pred.kernel'] = s['x_pred'].T @ dz
+        grads['pred.bias'] = dz.sum(0)
+        dh = dz @ self.rnd_w(self.pred[0]).T
+        n_act = 1 + len(self.convs) + len(self.dense)
+        k = n_act - 1
+        for i in reversed(range(len(self.dense))):
+            w, b = self.dense[i]
+            if self.alphas is not None:
+                d3, da = prelu_bwd(s['pre%d' % k].reshape(bsz, t, -1), self.alphas[k], dh.reshape(bsz, t, -1))
+                grads['alpha%d' % k] = da
+                dh = d3.reshape(bsz * t, -1)
+            k -= 1
+            dh, dw, db = oracle.backward(s['x_d%d' % i], self.rnd_w(w), b, dh, 0, y=s['y_d%d' % i], activation=self.act)
+            grads['dense%d.r' % i], grads['dense%d.bias' % i] = dw, db
+        dh = dh.reshape(bsz, t, c, f).transpose(0, 2, 3, 1)
+        kw = dict(padding='same', data_format='channels_first', activation=self.act)
+        for i in reversed(range(len(self.convs))):
+            w, b = self.convs[i]
+            if self.alphas is not None:
+                dh, grads['alpha%d' % k] = prelu_bwd(s['pre%d' % k], self.alphas[k], dh)
+            k -= 1
+            dh, dw, db = oracle.backward(s['x_c%d' % i], self.rnd_w(w), b, dh, 2, y=s['y_c%d' % i], **kw)
+            grads['conv%d.kernel' % i], grads['conv%d.bias' % i] = dw, db
+        dh = maxpool_freq_same_bwd(dh, s['pool_arg'], s['pool_in_f'])
+        if self.alphas is not None:
+            dh, grads['alpha0'] = prelu_bwd(s['pre0'], self.alphas[0], dh)
+        dx, dw, db = oracle.backward(s['x'], self.rnd_w(self.conv[0]), self.conv[1], dh, 2, y=s['y_conv'], **kw)
+        grads['conv.kernel'], grads['conv.bias'], grads['x'] = dw, db, dx
+        return grads
+
+
+def model_grads(model):
+    """The same dictionary keys from a TimitQCNN after backward()."""
+    g = lambda t: None if t.grad is None else t.grad.detach().cpu().double().numpy()
+    out = {'conv.kernel': g(model.conv.kernel), 'conv.bias': g(model.conv.bias),
+           'pred.kernel': g(model.pred.layer.kernel), 'pred.bias': g(model.pred.layer.bias)}
+    for i, c in enumerate(model.convs):
+        out['conv%d.kernel' % i], out['conv%d.bias' % i] = g(c.kernel), g(c.bias)
+    for i, d in enumerate(model.dense):
+        out['dense%d.r' % i], out['dense%d.bias' % i] = g(d.layer.r), g(d.layer.bias)
+    if model.prelu is not None:
+        for i, pl in enumerate(model.prelu):
+            out['alpha%d' % i] = g(pl.alpha)
+    return out

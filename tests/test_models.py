@@ -50,7 +50,7 @@ def test_dense_prelu_timedistributed_ctc_on_cpu():
     assert tuple(y.shape) == (2, 7, 5) and torch.allclose(y.sum(-1), torch.ones(2, 7), atol=1e-6)
     p = PReLU(shared_axes=[1, 0])
     z = p(torch.tensor([[[-2.0, 3.0]]]))
-    assert tuple(p.alpha.shape) == (1, 2) and torch.equal(z, torch.tensor([[[0.0, 3.0]]]))
+    assert tuple(p.alpha.shape) == (1, 1) and torch.equal(z, torch.tensor([[[0.0, 3.0]]]))   # Keras: axis 0 -> index -1
     cost = ctc_batch_cost(y, torch.tensor([[1, 2], [3, 0]]), torch.tensor([[7], [7]]), torch.tensor([[2], [1]]))
     assert tuple(cost.shape) == (2, 1) and torch.isfinite(cost).all() and (cost > 0).all()
     assert tuple(Flatten()(torch.zeros(3, 4, 5)).shape) == (3, 20)

@@ -1,0 +1,175 @@
+"""f2 parity: the TIMIT quaternion CNN (models/interspeech_model.py:45-185) on the GPU against the
+float64 oracle composition of tests/np_model_ref.py -- forward AND every gradient, with the fused paths on
+(first layer tap-folded, engine max-pool, body convolutions + head as one chain node, head as an (F, 1)
+conj-convolution): conj = 1 convolutions at rank 2, QK_BWD_MASK_DX / QK_BWD_DY_PREMASKED, qk_conv_fold_taps and
+qk_maxpool2d meet the oracle here directly, not another HIP kernel.
+
+Tolerances: fp32 <= 1e-4 of max|want| per tensor (BASELINE.json north_star); bf16: the composition emulates
+the 16-bit storage of every activation and the 16-bit kernels of the matrix-core path, forward <= 2e-2,
+gradients <= 6e-2 of max|want| (ten chained 16-bit roundings in the backward, which the composition does not emulate).
+"""
+import numpy as np
+import pytest
+import torch
+
+from np_model_ref import TimitRef, keras_prelu_alpha_shape, model_grads
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    return torch.device('cuda:0')
+
+
+def _rel(got, want):
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    assert got.shape == want.shape, (got.shape, want.shape)
+    return float(np.abs(got - want).max()) / max(float(np.abs(want).max()), 1e-30)
+
+
+def _build(dev, dtype, sf, n, aact, bsz, t, seed, **kw):
+    from qcnn_amd.models import TimitQCNN
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    model = TimitQCNN(num_layers=n, start_filter=sf, act='relu', aact=aact, dropout=0.0, **kw)
+    rng = np.random.RandomState(seed + 1)
+    x = rng.randn(bsz, 4, 41, t).astype(np.float32)
+    xt = torch.tensor(x, device=dev).to(dtype)
+    with torch.no_grad():
+        model(xt)                                           # build
+        # biases / PReLU slopes away from their zero initial values, so that their paths carry signal
+        for name, p in model.named_parameters():
+            if name.endswith('bias'):
+                p.copy_(torch.tensor(0.1 * rng.randn(*p.shape), dtype=torch.float32))
+            if name.endswith('alpha'):
+                p.copy_(torch.tensor(0.05 + 0.3 * rng.rand(*p.shape), dtype=torch.float32))
+    dpred = rng.randn(bsz, t, 62)
+    return model, xt, dpred
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('aact', ['none', 'prelu'])
+@pytest.mark.parametrize('fused', [True, False], ids=['fused', 'layerwise'])
+def test_timit_qcnn_fp32_matches_oracle_composition(aact, fused):
+    dev = _dev()
+    model, xt, dpred = _build(dev, torch.float32, 8, 4, aact, 2, 20, seed=11, fuse_head=fused, chain_convs=fused)
+    xt.requires_grad_(False)
+    pred = model(xt)
+    (pred.double() * torch.tensor(dpred, device=dev)).sum().backward()
+    ref = TimitRef(model, act='relu')
+    want = ref.forward(xt.detach().cpu().double().numpy())
+    assert _rel(pred.detach().cpu().numpy(), want) <= 1e-4
+    wg = ref.backward(dpred)
+    got = model_grads(model)
+    for k, v in got.items():
+        assert v is not None, k
+        err = _rel(v, wg[k])
+        assert err <= 1e-4, '%s: rel err %.3g' % (k, err)
+
+
+def _round_fn(dtype):
+    return lambda a: torch.tensor(a).to(dtype).double().numpy()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16], ids=['bf16', 'fp16'])
+def test_timit_qcnn_16bit_matches_oracle_composition(dtype):
+    """sf = 32: every quaternion layer is on the 16-bit MFMA path (band kernels, chain flags, conj head, fold)."""
+    dev = _dev()
+    model, xt, dpred = _build(dev, dtype, 32, 4, 'none', 2, 24, seed=13)
+    pred = model(xt)
+    (pred.float() * torch.tensor(dpred, device=dev, dtype=torch.float32)).sum().backward()
+    rnd = _round_fn(dtype)
+    ref = TimitRef(model, act='relu', rnd=rnd, rnd_w=rnd)
+    want = ref.forward(xt.detach().cpu().double().numpy())
+    tol_f, tol_g = (2e-2, 6e-2) if dtype == torch.bfloat16 else (4e-3, 1.5e-2)
+    assert _rel(pred.detach().float().cpu().numpy(), want) <= tol_f
+    wg = ref.backward(dpred)
+    got = model_grads(model)
+    for k, v in got.items():
+        assert v is not None, k
+        err = _rel(v, wg[k])
+        assert err <= tol_g, '%s: rel err %.3g' % (k, err)
+
+
+@pytest.mark.gpu
+def test_prelu_alpha_follows_keras_shared_axes_and_accepts_other_lengths():
+    """PReLU(shared_axes=[1, 0]) (interspeech_model.py:99-101): Keras shares axis 1 and -- through index 0 - 1 = -1 --
+    the LAST axis; a second batch with another number of frames must run on the same parameters."""
+    dev = _dev()
+    model, xt, _ = _build(dev, torch.float32, 8, 2, 'prelu', 2, 16, seed=3)
+    shapes = [tuple(p.alpha.shape) for p in model.prelu]
+    assert shapes[0] == keras_prelu_alpha_shape((None, 32, 41, None), [1, 0]) == (1, 41, 1)
+    assert shapes[1] == shapes[2] == keras_prelu_alpha_shape((None, 32, 14, None), [1, 0]) == (1, 14, 1)
+    assert shapes[3] == shapes[4] == shapes[5] == keras_prelu_alpha_shape((None, None, 256), [1, 0]) == (1, 1)
+    x2 = torch.randn(3, 4, 41, 23, device=dev)
+    assert tuple(model(x2).shape) == (3, 23, 62)
+
+
+def test_prelu_shapes_on_cpu():
+    from qcnn_amd.layers import PReLU
+    p = PReLU(shared_axes=[1, 0])
+    p(torch.randn(2, 8, 14, 5))
+    assert tuple(p.alpha.shape) == (1, 14, 1)
+    q = PReLU(shared_axes=[1, 0])
+    y = q(torch.tensor([[[-2.0, 3.0]]]))
+    assert tuple(q.alpha.shape) == (1, 1) and torch.equal(y, torch.tensor([[[0.0, 3.0]]]))
+    r = PReLU(shared_axes=[2])
+    r(torch.randn(2, 3, 4, 5))
+    assert tuple(r.alpha.shape) == (3, 1, 5)
+    p(torch.randn(1, 8, 14, 9))                              # another time length, same parameters
+
+
+def test_numpy_model_composition_agrees_with_torch_autograd_on_cpu():
+    """The float64 composition the GPU tests compare against, checked here against torch autograd through the
+    reference op sequence (oracle/ref_port.py): two independent restatements of the same model."""
+    import types
+    from oracle import ref_port
+    rng = np.random.RandomState(0)
+    n, sf, bsz, t = 2, 2, 2, 7
+    widths = [sf] * (n // 2) + [2 * sf] * (n // 2)
+    P = lambda *s: torch.tensor(rng.randn(*s) / np.sqrt(max(np.prod(s[:-1]), 1)), dtype=torch.float64, requires_grad=True)
+    conv = (P(3, 5, 1, 4 * sf), P(4 * sf))
+    convs, cin = [], sf
+    for w in widths:
+        convs.append((P(3, 5, cin, 4 * w), P(4 * w)))
+        cin = w
+    dense = [(P(14 * cin, 16), P(16)), (P(4, 16), P(16)), (P(4, 16), P(16))]
+    pred = (P(16, 5), P(5))
+    a_shapes = [(1, 41, 1)] + [(1, 14, 1)] * n + [(1, 1)] * 3
+    alphas = [torch.tensor(0.05 + 0.3 * rng.rand(*s), dtype=torch.float64, requires_grad=True) for s in a_shapes]
+    x = torch.tensor(rng.randn(bsz, 4, 41, t), dtype=torch.float64, requires_grad=True)
+    dpred = rng.randn(bsz, t, 5)
+    for use_prelu in (False, True):
+        act = None if use_prelu else 'relu'
+        pl = (lambda h, k: torch.relu(h) - alphas[k] * torch.relu(-h)) if use_prelu else (lambda h, k: h)
+        kw = dict(padding='same', data_format='channels_first', activation=act)
+        h = pl(ref_port.conv_forward(x, conv[0], conv[1], 2, **kw), 0)
+        h = torch.nn.functional.max_pool2d(h, (3, 1), (3, 1), ceil_mode=True)
+        for i, (w, b) in enumerate(convs):
+            h = pl(ref_port.conv_forward(h, w, b, 2, **kw), 1 + i)
+        h = h.permute(0, 3, 1, 2).reshape(bsz, t, -1)
+        for i, (w, b) in enumerate(dense):
+            h = pl(ref_port.dense_forward(h.reshape(bsz * t, -1), w, b, activation=act).reshape(bsz, t, -1), 1 + n + i)
+        p = torch.softmax(h @ pred[0] + pred[1], dim=-1)
+        leaves = [x, conv[0], conv[1]] + [t_ for wb in convs for t_ in wb] + [t_ for wb in dense for t_ in wb] + list(pred)
+        if use_prelu:
+            leaves += alphas
+        grads = torch.autograd.grad((p * torch.tensor(dpred)).sum(), leaves)
+        # the same model through the numpy composition
+        fake = types.SimpleNamespace(
+            conv=types.SimpleNamespace(kernel=conv[0], bias=conv[1]),
+            convs=[types.SimpleNamespace(kernel=w, bias=b) for w, b in convs],
+            dense=[types.SimpleNamespace(layer=types.SimpleNamespace(r=w, bias=b)) for w, b in dense],
+            pred=types.SimpleNamespace(layer=types.SimpleNamespace(kernel=pred[0], bias=pred[1])),
+            prelu=[types.SimpleNamespace(alpha=a) for a in alphas] if use_prelu else None)
+        ref = TimitRef(fake, act='relu')
+        want = ref.forward(x.detach().numpy())
+        assert np.abs(want - p.detach().numpy()).max() <= 1e-12
+        g = ref.backward(dpred)
+        names = ['x', 'conv.kernel', 'conv.bias'] + [s % i for i in range(n) for s in ('conv%d.kernel', 'conv%d.bias')] \
+            + [s % i for i in range(3) for s in ('dense%d.r', 'dense%d.bias')] + ['pred.kernel', 'pred.bias']
+        if use_prelu:
+            names += ['alpha%d' % i for i in range(len(alphas))]
+        for name, tg in zip(names, grads):
+            assert np.abs(g[name] - tg.numpy()).max() <= 1e-10 * max(1.0, float(tg.abs().max())), name
