@@ -16,6 +16,14 @@ keras + tensorflow, unpinned in setup.py:15-16):
                   array the initializer RETURNS (needed by conv.py:165-181 where the
                   requested shape is (*k,Cq,F) and qconv_init returns (*k,Cq,4F)).
 
+Round 2: the stock layers the reference's MODEL BUILDERS put around the quaternion layers
+(models/example_model.py, models/interspeech_model.py) are restated too -- Input (hands out fed tensors: the
+builders then run eagerly on concrete data), Dense, Flatten, Dropout (identity: inference / rate 0),
+AveragePooling1D / MaxPooling2D with TensorFlow 'same' semantics, PReLU(shared_axes) exactly as
+keras.layers.PReLU.build writes it, Permute, Lambda, TimeDistributed, Model, K.function, K.reshape,
+K.ctc_batch_cost, regularizers.l2 -- so that getTimitModel2D / CNN / DNN execute as written and torch
+autograd differentiates through them (fixtures g13_*, g17_*).
+
 This file cannot travel to the GPU box in any useful way (the reference does not exist
 there); it is committed so the goldens are reproducible here.
 """
@@ -149,6 +157,23 @@ def _build_backend():
                dilation_rate=(1, 1, 1)):
         return _conv_nd(x, kernel, 3, strides, padding, data_format, dilation_rate)
     K.conv1d, K.conv2d, K.conv3d = conv1d, conv2d, conv3d
+    K.reshape = lambda x, shape: x.reshape(tuple(int(v) for v in shape))
+    K.epsilon = lambda: 1e-7
+    K.function = lambda inputs, outputs, **kw: (lambda *a, **k: list(outputs))
+    K.learning_phase = lambda: 0
+
+    def ctc_batch_cost(y_true, y_pred, input_length, label_length):
+        """keras.backend.ctc_batch_cost (Keras 2.x, TF backend): tf.nn.ctc_loss on inputs = log(y_pred + epsilon)
+        taken as LOGITS (the op normalises them again), time-major, blank = last class, ctc_merge_repeated=True;
+        returns (batch, 1)."""
+        logits = torch.log(y_pred + 1e-7).transpose(0, 1)
+        logp = torch.log_softmax(logits, dim=-1)
+        il = torch.as_tensor(input_length).reshape(-1).long()
+        ll = torch.as_tensor(label_length).reshape(-1).long()
+        loss = F.ctc_loss(logp, torch.as_tensor(y_true).long(), il, ll, blank=y_pred.shape[-1] - 1,
+                          reduction='none', zero_infinity=False)
+        return loss.reshape(-1, 1)
+    K.ctc_batch_cost = ctc_batch_cost
     return K
 
 
@@ -213,11 +238,26 @@ def _build_initializers():
         rfs = int(np.prod(shape[:-2]))
         return shape[-2] * rfs, shape[-1] * rfs
 
+    class RandomUniform(Initializer):
+        def __init__(self, minval=-0.05, maxval=0.05, seed=None):
+            self.minval, self.maxval = minval, maxval
+
+        def __call__(self, shape, dtype=None):
+            return np.random.uniform(self.minval, self.maxval, shape)
+
+    class GlorotUniform(Initializer):
+        def __call__(self, shape, dtype=None):
+            fan_in, fan_out = _compute_fans(shape)
+            limit = np.sqrt(6.0 / (fan_in + fan_out))
+            return np.random.uniform(-limit, limit, shape)
+    m.RandomUniform, m.Orthogonal = RandomUniform, Initializer
+
     def get(identifier):
         if identifier is None:
             return None
         if isinstance(identifier, str):
-            return {'zeros': Zeros, 'ones': Ones}[identifier]()
+            return {'zeros': Zeros, 'ones': Ones, 'random_uniform': RandomUniform,
+                    'glorot_uniform': GlorotUniform}[identifier]()
         if callable(identifier):
             return identifier
         raise ValueError('Could not interpret initializer identifier: ' + str(identifier))
@@ -256,6 +296,13 @@ class InputSpec(object):
 
 
 _uid = {}
+ALL_WEIGHTS = []          # every variable created through add_weight, in creation order (reset by the caller)
+WEIGHT_HOOK = [None]      # optional callable(layer): runs once after build(), before the first call()
+_FEED = []                # tensors handed out by Input(), in call order
+
+
+def feed_inputs(tensors):
+    _FEED[:] = list(tensors)
 
 
 class Layer(object):
@@ -298,7 +345,9 @@ class Layer(object):
             t = torch.tensor(np.asarray(value), dtype=DTYPE)
         t.requires_grad_(True)
         t.keras_name = kwargs.get('name')
+        t.keras_layer = self.name
         self._weights.append(t)
+        ALL_WEIGHTS.append(t)
         return t
 
     def build(self, input_shape):
@@ -310,6 +359,8 @@ class Layer(object):
     def __call__(self, inputs):
         if not self.built:
             self.build(tuple(inputs.shape))
+            if WEIGHT_HOOK[0] is not None:
+                WEIGHT_HOOK[0](self)
         return self.call(inputs)
 
     def get_config(self):
@@ -318,6 +369,169 @@ class Layer(object):
     @property
     def weights(self):
         return list(self._weights)
+
+
+# ---- stock layers used by the reference's model builders (restated Keras 2.x / TF semantics) ----------
+def Input(shape=None, batch_shape=None, name=None, dtype=None, **kwargs):
+    """keras.layers.Input: the stand-in runs eagerly, so an Input IS the next fed tensor."""
+    if not _FEED:
+        raise RuntimeError('keras stand-in: Input(%r) called with no fed tensor left (feed_inputs)' % (name,))
+    return _FEED.pop(0)
+
+
+class Dense(Layer):
+    def __init__(self, units, activation=None, use_bias=True, kernel_initializer='glorot_uniform',
+                 bias_initializer='zeros', kernel_regularizer=None, bias_regularizer=None,
+                 activity_regularizer=None, kernel_constraint=None, bias_constraint=None, **kwargs):
+        super(Dense, self).__init__(**kwargs)
+        self.units, self.use_bias = units, use_bias
+        self.activation = sys.modules['keras.activations'].get(activation)
+        self.kernel_initializer, self.bias_initializer = kernel_initializer, bias_initializer
+
+    def build(self, input_shape):
+        self.kernel = self.add_weight(shape=(input_shape[-1], self.units), initializer=self.kernel_initializer,
+                                      name='kernel')
+        self.bias = self.add_weight(shape=(self.units,), initializer=self.bias_initializer, name='bias') \
+            if self.use_bias else None
+        self.built = True
+
+    def call(self, inputs):
+        out = inputs @ self.kernel
+        if self.bias is not None:
+            out = out + self.bias
+        return self.activation(out)
+
+
+class Flatten(Layer):
+    def call(self, inputs):
+        return inputs.reshape(inputs.shape[0], -1)
+
+
+class Dropout(Layer):
+    """Identity: the fixtures are taken at inference / with rate 0 (K.in_train_phase(dropped, inputs))."""
+
+    def __init__(self, rate, noise_shape=None, seed=None, **kwargs):
+        super(Dropout, self).__init__(**kwargs)
+        self.rate = rate
+
+
+class Permute(Layer):
+    def __init__(self, dims, **kwargs):
+        super(Permute, self).__init__(**kwargs)
+        self.dims = tuple(dims)
+
+    def call(self, inputs):
+        return inputs.permute((0,) + self.dims)
+
+
+class Lambda(Layer):
+    def __init__(self, function, output_shape=None, mask=None, arguments=None, **kwargs):
+        super(Lambda, self).__init__(**kwargs)
+        self.function, self.arguments = function, arguments or {}
+
+    def __call__(self, inputs):
+        return self.function(inputs, **self.arguments)
+
+
+class TimeDistributed(Layer):
+    """keras.layers.TimeDistributed: (B, T, ...) -> reshape to (B*T, ...), apply the layer, reshape back."""
+
+    def __init__(self, layer, **kwargs):
+        super(TimeDistributed, self).__init__(**kwargs)
+        self.layer = layer
+
+    def __call__(self, inputs):
+        b, t = inputs.shape[0], inputs.shape[1]
+        y = self.layer(inputs.reshape((b * t,) + tuple(inputs.shape[2:])))
+        return y.reshape((b, t) + tuple(y.shape[1:]))
+
+
+class PReLU(Layer):
+    """keras.layers.PReLU: param_shape = input_shape[1:], `param_shape[i - 1] = 1` for i in shared_axes
+    (axis 0 therefore shares the LAST axis); f(x) = relu(x) - alpha * relu(-x)."""
+
+    def __init__(self, alpha_initializer='zeros', alpha_regularizer=None, alpha_constraint=None,
+                 shared_axes=None, **kwargs):
+        super(PReLU, self).__init__(**kwargs)
+        self.alpha_initializer = alpha_initializer
+        if shared_axes is None:
+            self.shared_axes = None
+        elif not isinstance(shared_axes, (list, tuple)):
+            self.shared_axes = [shared_axes]
+        else:
+            self.shared_axes = list(shared_axes)
+
+    def build(self, input_shape):
+        param_shape = list(input_shape[1:])
+        if self.shared_axes is not None:
+            for i in self.shared_axes:
+                param_shape[i - 1] = 1
+        self.alpha = self.add_weight(shape=tuple(param_shape), name='alpha', initializer=self.alpha_initializer)
+        self.built = True
+
+    def call(self, inputs):
+        return torch.relu(inputs) - self.alpha * torch.relu(-inputs)
+
+
+def _pool_same_valid(x, pool, strides, padding, mode):
+    """Pool the LAST len(pool) axes of x (any leading axes) with TensorFlow padding: 'same' pads
+    total = max((ceil(n/s) - 1) * s + k - n, 0) as (total // 2, rest); padded cells never win a max and are
+    left out of an average's divisor."""
+    rank = len(pool)
+    lead = x.shape[:-rank]
+    xp = x.reshape((-1, 1) + tuple(x.shape[-rank:]))
+    pads = []
+    for ax in reversed(range(rank)):
+        lo, hi = _tf_pads(xp.shape[2 + ax], pool[ax], strides[ax], 1, padding)
+        pads += [lo, hi]
+    fmax = {1: F.max_pool1d, 2: F.max_pool2d}[rank]
+    favg = {1: F.avg_pool1d, 2: F.avg_pool2d}[rank]
+    if mode == 'max':
+        y = fmax(F.pad(xp, pads, value=float('-inf')) if any(pads) else xp, pool, strides)
+    elif any(pads):
+        y = favg(F.pad(xp, pads), pool, strides) / favg(F.pad(torch.ones_like(xp), pads), pool, strides)
+    else:
+        y = favg(xp, pool, strides)
+    return y.reshape(tuple(lead) + tuple(y.shape[-rank:]))
+
+
+class _Pool(Layer):
+    rank, mode = 1, 'max'
+
+    def __init__(self, pool_size=2, strides=None, padding='valid', data_format=None, **kwargs):
+        super(_Pool, self).__init__(**kwargs)
+        self.pool_size = normalize_tuple(pool_size, self.rank, 'pool_size')
+        self.strides = normalize_tuple(self.pool_size if strides is None else strides, self.rank, 'strides')
+        self.padding = normalize_padding(padding)
+        # keras: data_format None -> K.image_data_format() == 'channels_last' (1-D pooling is always (B, steps, C))
+        self.data_format = _normalize_data_format(data_format)
+
+    def call(self, inputs):
+        if self.data_format == 'channels_last':             # spatial axes 1..rank, channels last
+            x = inputs.movedim(-1, 1)
+            return _pool_same_valid(x, self.pool_size, self.strides, self.padding, self.mode).movedim(1, -1)
+        return _pool_same_valid(inputs, self.pool_size, self.strides, self.padding, self.mode)
+
+
+class AveragePooling1D(_Pool):
+    rank, mode = 1, 'avg'
+
+
+class MaxPooling1D(_Pool):
+    rank, mode = 1, 'max'
+
+
+class MaxPooling2D(_Pool):
+    rank, mode = 2, 'max'
+
+
+class AveragePooling2D(_Pool):
+    rank, mode = 2, 'avg'
+
+
+class Model(object):
+    def __init__(self, inputs=None, outputs=None, **kwargs):
+        self.inputs, self.outputs = inputs, outputs
 
 
 class _Placeholder(object):
@@ -339,9 +553,14 @@ def install():
 
     layers = types.ModuleType('keras.layers')
     layers.Layer, layers.InputSpec = Layer, InputSpec
-    for n in ('Lambda', 'Convolution1D', 'Convolution2D', 'add', 'multiply', 'Activation',
-              'Input', 'concatenate'):
+    for n in ('Convolution1D', 'Convolution2D', 'add', 'multiply', 'Activation', 'concatenate', 'Conv1D', 'Conv2D',
+              'AveragePooling3D', 'Add', 'Concatenate', 'BatchNormalization', 'Reshape', 'ConvLSTM2D',
+              'SpatialDropout1D'):
         setattr(layers, n, _Placeholder)
+    for cls in (Dense, Flatten, Dropout, Permute, Lambda, TimeDistributed, PReLU, AveragePooling1D, MaxPooling1D,
+                MaxPooling2D, AveragePooling2D):
+        setattr(layers, cls.__name__, cls)
+    layers.Input = Input
     convolutional = types.ModuleType('keras.layers.convolutional')
     convolutional._Conv = _Placeholder
     merge = types.ModuleType('keras.layers.merge')
@@ -351,7 +570,26 @@ def install():
     layers.convolutional, layers.merge, layers.recurrent = convolutional, merge, recurrent
 
     models = types.ModuleType('keras.models')
-    models.Model = _Placeholder
+    models.Model = Model
+    models.load_model = models.save_model = _Placeholder
+    regs.l2 = lambda l=0.01: (lambda w: l * (w * w).sum())
+    extra = {}
+    for modname, names in (('keras.callbacks', ('Callback', 'ModelCheckpoint', 'LearningRateScheduler')),
+                           ('keras.datasets', ('cifar10', 'cifar100')),
+                           ('keras.optimizers', ('SGD', 'Adam', 'RMSprop')),
+                           ('keras.preprocessing', ()), ('keras.preprocessing.image', ('ImageDataGenerator',)),
+                           ('keras.utils.np_utils', ('to_categorical',)),
+                           ('keras.utils.training_utils', ('multi_gpu_model',)),
+                           ('keras.backend.tensorflow_backend', ('set_session',)),
+                           ('tensorflow', ())):
+        mod = types.ModuleType(modname)
+        for n in names:
+            setattr(mod, n, _Placeholder)
+        extra[modname] = mod
+    extra['keras.preprocessing'].image = extra['keras.preprocessing.image']
+    keras.callbacks, keras.datasets, keras.optimizers = extra['keras.callbacks'], extra['keras.datasets'], extra['keras.optimizers']
+    keras.preprocessing = extra['keras.preprocessing']
+    K.tensorflow_backend = extra['keras.backend.tensorflow_backend']
 
     utils = types.ModuleType('keras.utils')
     conv_utils = types.ModuleType('keras.utils.conv_utils')
@@ -362,6 +600,7 @@ def install():
     generic_utils.serialize_keras_object = lambda o: o
     generic_utils.deserialize_keras_object = lambda o, **k: o
     utils.conv_utils, utils.generic_utils = conv_utils, generic_utils
+    utils.np_utils, utils.training_utils = extra['keras.utils.np_utils'], extra['keras.utils.training_utils']
 
     keras.backend, keras.activations, keras.initializers = K, acts, inits
     keras.regularizers, keras.constraints = regs, cons
@@ -374,6 +613,7 @@ def install():
         'keras.models': models, 'keras.utils': utils,
         'keras.utils.conv_utils': conv_utils, 'keras.utils.generic_utils': generic_utils,
     }
+    mods.update(extra)
     sys.modules.update(mods)
     return K
 

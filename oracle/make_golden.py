@@ -202,6 +202,112 @@ def api_goldens(cn):
     return out
 
 
+def _capture(weights):
+    """[(layer name, weight name, tensor)] -> arrays w000.. (float32-representable values) + a JSON manifest."""
+    rec, names = {}, []
+    for i, t in enumerate(weights):
+        rec['w%03d' % i] = t.detach().numpy().astype(np.float32)
+        names.append([t.keras_layer, t.keras_name, list(t.shape)])
+    return rec, names
+
+
+def _randomise_small_weights(rng):
+    """Post-build hook: biases and PReLU slopes start at zero in the reference; give them float32-representable
+    non-zero values so that the fixtures exercise their paths; round every kernel to float32."""
+    def hook(layer):
+        with torch.no_grad():
+            for t in layer.weights:
+                if t.keras_name == 'bias':
+                    t.copy_(f32(torch.tensor(0.1 * rng.randn(*t.shape))))
+                elif t.keras_name == 'alpha':
+                    t.copy_(f32(torch.tensor(0.05 + 0.3 * rng.rand(*t.shape))))
+                else:
+                    t.copy_(f32(t))
+    return hook
+
+
+def example_net_goldens():
+    """G13: the reference's OWN model builders (models/example_model.py:15-81, imported where they
+    lie) on the first 8 documents of the bundled DECODA DEV set, parsed by the reference's OWN reader
+    (working_example.py:19-66): class posteriors + the gradient of sum(p * dp) w.r.t. every weight."""
+    import ast
+    import types
+    import models.example_model as em
+    # working_example.py runs its whole training script at import time (and needs the missing TRAIN file), so
+    # only its reader function is taken -- compiled from the file where it lies, nothing is copied
+    src = open('/root/reference/working_example.py').read()
+    fn = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == 'dataPrepDecodaQuaternion']
+    ns = {'np': np}
+    exec(compile(ast.Module(body=fn, type_ignores=[]), '/root/reference/working_example.py', 'exec'), ns)
+    x_all, y_all = ns['dataPrepDecodaQuaternion']('/root/reference/decoda/250_DEV_Q.data', isquat=True)
+    x = torch.tensor(x_all[:8], dtype=torch.float64)
+    out = {'x': x_all[:8].astype(np.float32), 'labels': y_all[:8].astype(np.float32),
+           'dev_shape': np.array(x_all.shape), 'dev_label_counts': y_all.sum(0)}
+    manifest = {}
+    for tag, builder, params in (('qcnn', em.CNN, 'QCNN'), ('qdnn', em.DNN, 'QDNN')):
+        np.random.seed(1300 + len(manifest))
+        rng = np.random.RandomState(77 + len(manifest))
+        keras_standin.ALL_WEIGHTS[:] = []
+        keras_standin.WEIGHT_HOOK[0] = _randomise_small_weights(rng)
+        keras_standin.feed_inputs([f32(x)])
+        model = builder(types.SimpleNamespace(model=params))
+        keras_standin.WEIGHT_HOOK[0] = None
+        p = model.outputs
+        dp = f32(torch.tensor(rng.randn(*p.shape)))
+        weights = list(keras_standin.ALL_WEIGHTS)
+        grads = torch.autograd.grad((p * dp).sum(), weights)
+        wrec, names = _capture(weights)
+        for k, v in wrec.items():
+            out['%s_%s' % (tag, k)] = v
+        for i, gt in enumerate(grads):
+            g = gt.numpy()
+            out['%s_g%03d' % (tag, i)] = g.astype(np.float32) if g.size > 100000 else g    # (keeps the file small)
+        out[tag + '_p'] = p.detach().numpy()
+        out[tag + '_dp'] = dp.numpy().astype(np.float32)
+        manifest[tag] = names
+    out['config'] = np.array(json.dumps(manifest))
+    return out
+
+
+def timit_goldens(aact):
+    """G17: the reference's OWN getTimitModel2D (models/interspeech_model.py:45-185, imported where it lies; it is
+    Python-2 code: `xrange` and `n/2` are served by an int-casting xrange) run eagerly on a small batch:
+    posteriors, CTC cost, and the gradient of sum(pred * dpred) w.r.t. the input and every weight."""
+    import builtins
+    import types
+    builtins.xrange = lambda a, b=None: range(int(a)) if b is None else range(int(a), int(b))
+    import models.interspeech_model as im
+    seed = 1700 + (1 if aact == 'prelu' else 0)
+    np.random.seed(seed)
+    rng = np.random.RandomState(seed + 50)
+    bsz, t = 2, 10
+    x = f32(torch.tensor(rng.randn(bsz, 4, 41, t))).requires_grad_(True)
+    labels = torch.tensor(rng.randint(0, 61, (bsz, 4)).astype(np.float32))
+    input_length = torch.tensor([[t], [t - 2]], dtype=torch.int64)
+    label_length = torch.tensor([[4], [3]], dtype=torch.int64)
+    d = types.SimpleNamespace(num_layers=4, start_filter=4, act='relu', aact=aact, dropout=0.0, l2=1e-4,
+                              model='quaternion', quat_init='quaternion')
+    keras_standin.ALL_WEIGHTS[:] = []
+    keras_standin.WEIGHT_HOOK[0] = _randomise_small_weights(rng)
+    keras_standin.feed_inputs([x, labels, input_length, label_length])     # order of the Input() calls (:81-90)
+    model, val_function = im.getTimitModel2D(d)
+    keras_standin.WEIGHT_HOOK[0] = None
+    pred = val_function([x])[0]
+    cost = model.outputs
+    dpred = f32(torch.tensor(rng.randn(*pred.shape)))
+    weights = list(keras_standin.ALL_WEIGHTS)
+    grads = torch.autograd.grad((pred * dpred).sum(), [x] + weights)
+    out, names = _capture(weights)
+    out.update(x=x.detach().numpy().astype(np.float32), labels=labels.numpy(), input_length=input_length.numpy(),
+               label_length=label_length.numpy(), pred=pred.detach().numpy(), dpred=dpred.numpy().astype(np.float32),
+               ctc_cost=cost.detach().numpy(), gx=grads[0].numpy())
+    for i, gt in enumerate(grads[1:]):
+        out['g%03d' % i] = gt.numpy()
+    out['config'] = np.array(json.dumps(dict(weights=names, d=dict(num_layers=4, start_filter=4, act='relu', aact=aact,
+                                                                  dropout=0.0, l2=1e-4), seed=seed)))
+    return out
+
+
 def main():
     cn = keras_standin.import_reference()
     os.makedirs(OUT, exist_ok=True)
@@ -212,6 +318,10 @@ def main():
     np.savez_compressed(os.path.join(OUT, 'g12_init.npz'), **init_goldens(cn))
     with open(os.path.join(OUT, 'g00_api.json'), 'w') as f:
         json.dump(api_goldens(cn), f, indent=1, sort_keys=True)
+    np.savez_compressed(os.path.join(OUT, 'g13_example_nets.npz'), **example_net_goldens())
+    for aact in ('none', 'prelu'):
+        np.savez_compressed(os.path.join(OUT, 'g17_timit_%s.npz' % ('relu' if aact == 'none' else 'prelu')),
+                            **timit_goldens(aact))
     print('wrote', OUT)
 
 

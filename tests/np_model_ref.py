@@ -172,3 +172,70 @@ def model_grads(model):
         for i, pl in enumerate(model.prelu):
             out['alpha%d' % i] = g(pl.alpha)
     return out
+
+
+# ---- fixtures captured from the reference's own model builders (oracle/make_golden.py: g17_*, g13_*) -----------
+def load_timit_fixture(path):
+    """tests/golden/g17_timit_*.npz -> dict(x, dpred, pred, ctc_cost, labels, input_length, label_length, d,
+    weights {name: array}, grads {name: array}) with this module's names (conv.kernel, conv0.bias, dense1.r,
+    alpha3, pred.kernel, ...).  The fixture lists the variables in the order getTimitModel2D created them."""
+    import json
+    z = np.load(path)
+    cfg = json.loads(str(z['config']))
+    names, n_conv, n_dense, n_alpha = [], 0, 0, 0
+    for layer, wname, _ in cfg['weights']:
+        if wname == 'alpha':
+            names.append('alpha%d' % n_alpha)
+            n_alpha += 1
+        elif layer == 'conv':
+            names.append('conv.' + wname)
+        elif layer.startswith('conv'):
+            names.append('conv%d.%s' % (n_conv, wname))
+            n_conv += wname == 'bias'
+        elif wname == 'r' or (layer.startswith('quaterniondense') and wname == 'bias'):
+            names.append('dense%d.%s' % (n_dense, wname))
+            n_dense += wname == 'bias'
+        else:
+            names.append('pred.' + wname)
+    out = {k: z[k] for k in ('x', 'dpred', 'pred', 'ctc_cost', 'labels', 'input_length', 'label_length')}
+    out['d'] = cfg['d']
+    out['weights'] = {n: z['w%03d' % i].astype(np.float64) for i, n in enumerate(names)}
+    out['grads'] = {n: z['g%03d' % i] for i, n in enumerate(names)}
+    out['grads']['x'] = z['gx']
+    return out
+
+
+class _NS(object):
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+def fake_model_from_weights(w):
+    """A TimitQCNN-shaped attribute bag over numpy weights (for TimitRef)."""
+    import torch
+    t = lambda a: torch.tensor(a, dtype=torch.float64)
+    n_conv = len([k for k in w if k.startswith('conv') and k.endswith('.kernel') and k != 'conv.kernel'])
+    alphas = sorted((k for k in w if k.startswith('alpha')), key=lambda s: int(s[5:]))
+    return _NS(conv=_NS(kernel=t(w['conv.kernel']), bias=t(w['conv.bias'])),
+               convs=[_NS(kernel=t(w['conv%d.kernel' % i]), bias=t(w['conv%d.bias' % i])) for i in range(n_conv)],
+               dense=[_NS(layer=_NS(r=t(w['dense%d.r' % i]), bias=t(w['dense%d.bias' % i]))) for i in range(3)],
+               pred=_NS(layer=_NS(kernel=t(w['pred.kernel']), bias=t(w['pred.bias']))),
+               prelu=[_NS(alpha=t(w[k])) for k in alphas] if alphas else None)
+
+
+def load_weights_into_model(model, w):
+    """Copy fixture weights into a built qcnn_amd.models.TimitQCNN."""
+    import torch
+    with torch.no_grad():
+        def put(p, a):
+            assert tuple(p.shape) == tuple(a.shape), (tuple(p.shape), a.shape)
+            p.copy_(torch.tensor(a, dtype=torch.float32))
+        put(model.conv.kernel, w['conv.kernel']); put(model.conv.bias, w['conv.bias'])
+        for i, c in enumerate(model.convs):
+            put(c.kernel, w['conv%d.kernel' % i]); put(c.bias, w['conv%d.bias' % i])
+        for i, d in enumerate(model.dense):
+            put(d.layer.r, w['dense%d.r' % i]); put(d.layer.bias, w['dense%d.bias' % i])
+        put(model.pred.layer.kernel, w['pred.kernel']); put(model.pred.layer.bias, w['pred.bias'])
+        if model.prelu is not None:
+            for i, pl in enumerate(model.prelu):
+                put(pl.alpha, w['alpha%d' % i])

@@ -609,10 +609,15 @@ def test_conv_chain_flags_match_oracle_composition(dtype):
     y.backward(torch.tensor(dy, device=dev).to(dtype))
     tol_y, tol_g = (1e-4, 1e-4) if dtype == torch.float32 else (1e-2, 3e-2)
     assert _rel_err(y.detach().float().cpu().numpy(), acts[-1]) <= tol_y
-    if dtype == torch.float32:                                # the backward on the GPU's own relu masks (see above)
-        acts = [x]
-        for w, b, (_, kw) in zip(ws, bs, specs):
-            acts.append(oracle.forward(acts[-1], w, b, 2, **kw))
+    # the backward is compared on the GPU's own activations (relu masks: outputs that are zero up to rounding land
+    # on either side of 0): the same kernels layer by layer give the chain's intermediate tensors bit for bit
+    acts = [x]
+    with torch.no_grad():
+        h = xt.detach()
+        for w, b, (_, kw) in zip(wt, bt, specs):
+            h = F.quaternion_conv(h, w, b, **kw)
+            acts.append(h.double().cpu().numpy())
+    assert np.array_equal(acts[-1], y.detach().double().cpu().numpy())
     g = dy
     for i in reversed(range(3)):
         g, dw, db = oracle.backward(acts[i], ws[i], bs[i], g, 2, y=acts[i + 1], **specs[i][1])
@@ -735,8 +740,17 @@ def test_cfg5_stack_small_matches_oracle(name, dtype):
     h = F.quaternion_conv(xt, wt[0], bt[0], **kws[0])                     # first layer: no input gradient -> folded
     y = F.quaternion_conv_chain(h, [(wt[i], bt[i], kws[i]) for i in (1, 2, 3)])
     y.backward(torch.tensor(dy, device=dev).to(dtype))
-    tol_y, tol_g = (4e-3, 1.5e-2) if dtype == torch.float16 else (2e-2, 6e-2)
+    tol_y, tol_g = (4e-3, 1e-2) if dtype == torch.float16 else (2e-2, 5e-2)
     assert _rel_err(y.detach().float().cpu().numpy(), acts[-1]) <= tol_y
+    # backward on the GPU's own activations (relu masks; with 8 - 32 rows per gradient element a single output that
+    # rounds across zero moves a kernel-gradient element by tens of percent)
+    acts = [x]
+    with torch.no_grad():
+        hh = xt
+        for i in range(4):
+            hh = F.quaternion_conv(hh, wt[i], bt[i], **kws[i])
+            acts.append(hh.double().cpu().numpy())
+    assert np.array_equal(acts[-1], y.detach().double().cpu().numpy())
     g = dy
     for i in reversed(range(4)):
         g, dw, db = oracle.backward(acts[i], ws[i], bs[i], g, 2, y=acts[i + 1], **kws[i])
@@ -779,8 +793,8 @@ def test_cfg5_stack_full_size_16bit_kernels_agree_with_exact_fp32_kernels():
     assert not torch.equal(fast[2], exact[2]), 'QK_NO_MFMA16 did not switch kernels: the check is vacuous'
     for i, (a, e) in enumerate(zip(fast, exact)):
         err = float((a - e).abs().max()) / float(e.abs().max())
-        # relu masks are decided by each path's own 16-bit y here (a whole stack): single near-zero flips move
-        # individual elements; the bound is the 16-bit output rounding plus that
-        assert err <= (1e-2 if i == 0 else 5e-3), 'tensor %d: rel err %.3g' % (i, err)
+        # relu masks are decided by each path's own 16-bit y here and the gradient passes through three 16-bit
+        # tensors before it reaches the first kernel: element-wise 3e-2, the checksums stay tight
+        assert err <= (1e-2 if i == 0 else 3e-2), 'tensor %d: rel err %.3g' % (i, err)
         ssum = abs(float(a.double().sum()) - float(e.double().sum())) / float(e.double().abs().sum())
         assert ssum <= 2e-4, 'tensor %d: checksum drift %.3g' % (i, ssum)

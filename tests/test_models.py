@@ -250,3 +250,57 @@ def test_conv_chain_node_equals_layer_by_layer(dtype, tol):
     for a, b in zip(*outs):
         assert a.shape == b.shape
         assert float((a - b).abs().max()) <= tol * max(float(a.abs().max()), 1e-6)
+
+
+# ---- G13: pinned to the reference's own example-model builders and DECODA reader -----------------------------------
+import json
+import os
+
+_G13 = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'g13_example_nets.npz')
+_DEV8 = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'decoda_dev_head8.data')
+
+
+def test_decoda_reader_reproduces_what_the_reference_reader_parsed():
+    """qcnn_amd.data on the first 8 lines of the bundled DEV file (tests/golden/decoda_dev_head8.data) against the
+    arrays working_example.py:dataPrepDecodaQuaternion (:19-66) produced for them (fixture g13)."""
+    z = np.load(_G13)
+    x, y = qcnn_amd.data.dataPrepDecodaQuaternion(_DEV8, isquat=True)
+    assert x.dtype == np.float64 and x.shape == (8, 250, 4) and y.shape == (8, 8)
+    assert np.array_equal(x.astype(np.float32), z['x']) and np.array_equal(y.astype(np.float32), z['labels'])
+    assert z['dev_shape'].tolist() == [174, 250, 4] and z['dev_label_counts'].tolist() == [4, 43, 9, 45, 33, 24, 7, 9]
+    x3, _ = qcnn_amd.data.dataPrepDecodaQuaternion(_DEV8, isquat=False)
+    assert np.array_equal(x3, x[:, :, 1:])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('tag', ['qcnn', 'qdnn'])
+def test_example_networks_match_the_reference_model_fixture(tag):
+    """models/example_model.py:CNN('QCNN') / DNN('QDNN') of the reference, executed through the keras stand-in on
+    the first 8 DEV documents (fixture g13): class posteriors and the gradient of sum(p * dp) w.r.t. every weight."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    dev = torch.device('cuda:0')
+    z = np.load(_G13)
+    names = json.loads(str(z['config']))[tag]
+    np.random.seed(0)
+    net = (qcnn_amd.models.CNN if tag == 'qcnn' else qcnn_amd.models.DNN)(types.SimpleNamespace(model=tag.upper()))
+    x = torch.tensor(z['x'], device=dev)
+    with torch.no_grad():
+        net(x)
+    if tag == 'qcnn':
+        L = net.layers
+        params = [L[0].kernel, L[0].bias, L[2].kernel, L[2].bias, L[5].r, L[5].bias, L[6].kernel, L[6].bias]
+    else:
+        params = [net.h0.r, net.h0.bias, net.h1.r, net.h1.bias, net.h2.r, net.h2.bias, net.out.kernel, net.out.bias]
+    assert len(params) == len(names)
+    with torch.no_grad():
+        for i, (p, (_, wname, shape)) in enumerate(zip(params, names)):
+            assert list(p.shape) == shape, (i, wname, tuple(p.shape), shape)
+            p.copy_(torch.tensor(z['%s_w%03d' % (tag, i)], device=dev))
+    p = net(x)
+    want = z[tag + '_p']
+    assert float(np.abs(p.detach().cpu().numpy() - want).max()) <= 1e-4 * float(np.abs(want).max())
+    (p.double() * torch.tensor(z[tag + '_dp'], device=dev).double()).sum().backward()
+    for i, prm in enumerate(params):
+        g, w = prm.grad.cpu().numpy().astype(np.float64), z['%s_g%03d' % (tag, i)].astype(np.float64)
+        assert float(np.abs(g - w).max()) <= 1e-4 * float(np.abs(w).max()), (i, names[i])
