@@ -105,6 +105,29 @@ typedef struct {
 int qk_version(void);
 const char *qk_last_error(void);
 
+/* Diagnostic switches (tests, profiling): a process-wide bit mask, read with one relaxed atomic load on
+ * every launch path.  Its initial value comes from the environment, read once (QK_NO_MFMA16, QK_NO_BAND16,
+ * QK_NO_BAND32, QK_WGRAD16_ONE_TAP set => the bit; QK_ABLATE=<n> => bits 8..15).  Every combination computes the
+ * same values (up to the rounding of the path selected); none is needed in production.
+ *   QK_DBG_NO_MFMA16        16-bit activations run on the general fp32-MFMA kernels (exact fp32 products)
+ *   QK_DBG_NO_BAND16/32     no band variants of the forward / backward-data kernels
+ *   QK_DBG_WGRAD16_ONE_TAP  16-bit backward-weight: one tap per block for 32-channel layers
+ *   QK_DBG_BAND16_8WAVES    16-bit band kernels in their 8-wave form (env QK_BAND16_8WAVES)
+ *   bits 8..15              kernel ablation for profiling (skip the MFMA loop / epilogue / atomics): WRONG RESULTS
+ * qk_set_debug_flags returns the previous mask. */
+#define QK_DBG_NO_MFMA16 1u
+#define QK_DBG_NO_BAND16 2u
+#define QK_DBG_NO_BAND32 4u
+#define QK_DBG_WGRAD16_ONE_TAP 8u
+#define QK_DBG_BAND16_8WAVES 16u   /* 16-bit band kernels: 8-wave workgroups (one per CU) instead of 4-wave (two per CU) */
+unsigned qk_set_debug_flags(unsigned flags);
+unsigned qk_get_debug_flags(void);
+
+/* Which kernel family served the most recent qk_* compute call of the calling thread (thread-local, like
+ * qk_last_error): lets a caller see when a shape fell off the 16-bit matrix-core fast path. */
+typedef enum { QK_PATH_NONE = 0, QK_PATH_MFMA16 = 1, QK_PATH_MFMA16_BAND = 2, QK_PATH_FP32_MFMA = 3 } qk_path_t;
+int qk_last_path(void);
+
 /* Bytes of caller-owned device workspace `op` needs for this descriptor (0 = none). */
 size_t qk_conv_workspace_bytes(const qk_conv_desc_t *desc, int op /* qk_op_t */);
 size_t qk_dense_workspace_bytes(const qk_dense_desc_t *desc, int op /* qk_op_t */);

@@ -7,13 +7,16 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.realpath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libqk_hip.so')
+# QK_LIB: diagnostic override (A/B runs of two builds of the library on one GPU box, tools/ab_layers.py)
+LIB_PATH = os.environ.get('QK_LIB') or os.path.join(_HERE, 'libqk_hip.so')
 
 QK_F32, QK_BF16, QK_F16 = 0, 1, 2
 QK_CH_LAST, QK_CH_FIRST = 0, 1
 QK_ACT_LINEAR, QK_ACT_RELU = 0, 1
 QK_OP_FWD, QK_OP_BWD_DATA, QK_OP_BWD_WEIGHT, QK_OP_BWD = 0, 1, 2, 3
 QK_BWD_MASK_DX, QK_BWD_DY_PREMASKED = 1, 2      # flags of qk_*_bwd_chain
+QK_DBG_NO_MFMA16, QK_DBG_NO_BAND16, QK_DBG_NO_BAND32, QK_DBG_WGRAD16_ONE_TAP, QK_DBG_BAND16_8WAVES = 1, 2, 4, 8, 16   # qk_set_debug_flags
+QK_PATH_NAMES = {0: 'none', 1: 'mfma16', 2: 'mfma16_band', 3: 'fp32_mfma'}               # qk_last_path
 
 I32 = ctypes.c_int32
 
@@ -45,6 +48,9 @@ _PD = ctypes.POINTER(PoolDesc)
 SYMBOLS = {
     'qk_version': (ctypes.c_int, []),
     'qk_last_error': (ctypes.c_char_p, []),
+    'qk_set_debug_flags': (ctypes.c_uint, [ctypes.c_uint]),
+    'qk_get_debug_flags': (ctypes.c_uint, []),
+    'qk_last_path': (ctypes.c_int, []),
     'qk_conv_workspace_bytes': (_SZ, [_CD, ctypes.c_int]),
     'qk_dense_workspace_bytes': (_SZ, [_DD, ctypes.c_int]),
     'qk_conv_fwd': (ctypes.c_int, [_CD, _VP, _FP, _FP, _VP, _VP, _SZ, _VP]),
@@ -91,3 +97,25 @@ def check(rc, what):
     if rc != 0:
         msg = lib().qk_last_error()
         raise RuntimeError('%s failed (status %d): %s' % (what, rc, msg.decode() if msg else ''))
+
+
+class debug_flags(object):
+    """`with debug_flags(QK_DBG_NO_MFMA16): ...` -- OR the given diagnostic bits into the library's process-wide
+    mask (qk_set_debug_flags) for the duration of the block.  Tests and profiling only."""
+
+    def __init__(self, bits, ablate=0):
+        self.bits = int(bits) | (int(ablate) << 8)
+
+    def __enter__(self):
+        self.prev = lib().qk_get_debug_flags()
+        lib().qk_set_debug_flags(self.prev | self.bits)
+        return self
+
+    def __exit__(self, *exc):
+        lib().qk_set_debug_flags(self.prev)
+        return False
+
+
+def last_path():
+    """Kernel family that served this thread's most recent compute call: 'mfma16', 'mfma16_band', 'fp32_mfma'."""
+    return QK_PATH_NAMES.get(lib().qk_last_path(), 'none')

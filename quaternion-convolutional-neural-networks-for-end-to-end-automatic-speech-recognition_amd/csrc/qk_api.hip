@@ -7,9 +7,57 @@
 
 #include "qk_common.h"
 
+#include <atomic>
+
 namespace qk {
 
 static thread_local char g_err[512] = "";
+static thread_local int g_path = QK_PATH_NONE;
+void note_path(int p) { g_path = p; }
+
+namespace {
+unsigned env_flags()
+{
+    unsigned f = 0;
+    if (getenv("QK_NO_MFMA16")) f |= kDbgNoMfma16;
+    if (getenv("QK_NO_BAND16")) f |= kDbgNoBand16;
+    if (getenv("QK_NO_BAND32")) f |= kDbgNoBand32;
+    if (getenv("QK_WGRAD16_ONE_TAP")) f |= kDbgWgradOneTap;
+    if (getenv("QK_BAND16_8WAVES")) f |= kDbgBand8Waves;
+    if (const char *ab = getenv("QK_ABLATE")) f |= ((unsigned)atoi(ab) << kDbgAblateShift) & kDbgAblateMask;
+    return f;
+}
+std::atomic<unsigned> &dbg_word()
+{
+    static std::atomic<unsigned> w{env_flags()};          // thread-safe one-time initialisation (C++11)
+    return w;
+}
+struct ForceCfg { bool set; int policy, bq; };
+const ForceCfg &force_cfg()
+{
+    static const ForceCfg fc = [] {
+        ForceCfg c = {false, -1, -1};
+        if (const char *f = getenv("QK_FORCE_CFG")) c.set = sscanf(f, "%d,%d", &c.policy, &c.bq) == 2;
+        return c;
+    }();
+    return fc;
+}
+}  // namespace
+
+unsigned debug_flags() { return dbg_word().load(std::memory_order_relaxed); }
+bool debug_force_cfg(int *policy, int *bq)
+{
+    const ForceCfg &c = force_cfg();
+    if (c.set) { *policy = c.policy; *bq = c.bq; }
+    return c.set;
+}
+int device_cu_count()
+{
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+        return 256;
+    return n;
+}
 
 void set_error(const char *fmt, ...)
 {
@@ -172,6 +220,7 @@ int conv_fwd_impl(const qk_conv_desc_t *d, const void *x, const float *w, const 
     }
     const bool vec = d->layout == QK_CH_LAST && d->cq % 4 == 0 && d->fq % 4 == 0 &&
                      vec_aligned(x, d->dtype) && aligned(w, 16);
+    note_path(QK_PATH_FP32_MFMA);
     return launch_hgemm(d->dtype, x, nullptr, w, bias, y, g, vec, stream);
 }
 
@@ -218,6 +267,7 @@ int conv_bwd_data_impl(const qk_conv_desc_t *d, const void *dy, const void *y, c
     g.w_swapped = 1;
     const bool vec = d->layout == QK_CH_LAST && d->cq % 4 == 0 && d->fq % 4 == 0 && aligned(w, 16) &&
                      vec_aligned(dy, d->dtype) && (!mask || vec_aligned(y, d->dtype));
+    note_path(QK_PATH_FP32_MFMA);
     if (int rc = launch_hgemm(d->dtype, dy, mask ? y : nullptr, w, nullptr, dx, g, vec, stream)) return rc;
     if (dx_mask) return launch_mask_gt0(d->dtype, dx, dx_mask, (size_t)g.M * 4 * d->cq, stream);
     return 0;
@@ -270,6 +320,7 @@ int conv_bwd_weight_impl(const qk_conv_desc_t *d, const void *x, const void *dy,
     }
     const bool vec = d->layout == QK_CH_LAST && d->cq % 4 == 0 && d->fq % 4 == 0 &&
                      vec_aligned(x, d->dtype) && vec_aligned(dy, d->dtype) && (!mask || vec_aligned(y, d->dtype));
+    note_path(QK_PATH_FP32_MFMA);
     return launch_wgrad(d->dtype, x, dy, mask ? y : nullptr, dw, dbias, g, vec, stream);
 }
 
@@ -331,6 +382,10 @@ extern "C" {
 int qk_version(void) { return QK_VERSION; }
 
 const char *qk_last_error(void) { return g_err; }
+
+unsigned qk_set_debug_flags(unsigned flags) { return dbg_word().exchange(flags, std::memory_order_relaxed); }
+unsigned qk_get_debug_flags(void) { return debug_flags(); }
+int qk_last_path(void) { return g_path; }
 
 size_t qk_conv_workspace_bytes(const qk_conv_desc_t *desc, int op)
 {

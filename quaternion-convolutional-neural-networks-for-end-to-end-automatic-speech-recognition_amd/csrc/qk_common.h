@@ -186,5 +186,21 @@ int launch_adam(float *p, float *g, float *m, float *v, size_t n, float lr, floa
                 float b2, float eps, int step, float gscale, bool zero_grad, hipStream_t stream);
 
 void set_error(const char *fmt, ...);
+void note_path(int qk_path);          // thread-local record behind qk_last_path()
+
+// Diagnostic switches: one process-wide bit mask, initialised ONCE from the environment (QK_NO_MFMA16,
+// QK_NO_BAND16, QK_NO_BAND32, QK_WGRAD16_ONE_TAP, QK_ABLATE=<bits>, QK_FORCE_CFG="policy,bq") and changeable at
+// run time through qk_set_debug_flags() (include/qk.h).  Launch paths read one relaxed atomic -- no getenv, no
+// other mutable global.  Not part of the compute contract: every combination computes the same values.
+enum : unsigned {
+    kDbgNoMfma16 = QK_DBG_NO_MFMA16, kDbgNoBand16 = QK_DBG_NO_BAND16, kDbgNoBand32 = QK_DBG_NO_BAND32,
+    kDbgWgradOneTap = QK_DBG_WGRAD16_ONE_TAP, kDbgBand8Waves = QK_DBG_BAND16_8WAVES, kDbgAblateShift = 8, kDbgAblateMask = 0xffu << 8
+};
+unsigned debug_flags();
+inline int debug_ablate() { return (int)((debug_flags() & kDbgAblateMask) >> kDbgAblateShift); }
+// QK_FORCE_CFG (fp32 tiling sweep, tools/gpu_cfgsweep.sh): parsed once; false when unset
+bool debug_force_cfg(int *policy, int *bq);
+// compute units x resident workgroups of a kernel, queried per call from the current device (no caching)
+int device_cu_count();
 
 }  // namespace qk

@@ -38,6 +38,23 @@ __device__ __forceinline__ floatx16 mfma16(f16, const uint4 &a, const uint4 &b, 
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
+// two floats -> one dword of two 16-bit values (lo = a, hi = b), round-to-nearest-even in hardware:
+// v_cvt_pk_bf16_f32 on gfx950 (the bit-twiddling from_f32<bf16> costs ~6 VALU per element; the epilogue
+// converts 64 elements per lane)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack2(bf16, float a, float b)
+{
+    const f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ unsigned pack2(f16, float a, float b)
+{
+    const f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
+}
+
 // zero the 16-bit halves whose mask half is <= 0 (as a signed integer == as a bf16/fp16 value):
 // v_pk_max_i16, v_pk_min_u16, v_pk_mul_lo_u16, v_and
 typedef short s2v __attribute__((ext_vector_type(2)));
@@ -81,6 +98,26 @@ k_prep_w16(const float *__restrict__ w, T *__restrict__ wq, int taps, int Cq, in
     if (blockIdx.x == 0 && threadIdx.x < 128) wq[total + threadIdx.x] = from_f32<T>(0.f);   // zero line for padding rows
 }
 
+// Workgroup-wide OR of a per-thread bit mask (bits [0, nbits)) over NW waves: one ballot per bit inside each
+// wave, one LDS word per wave, one barrier.  (512 atomicOr on one LDS word serialise: ~7 us per tile, measured.)
+template <int NW>
+__device__ __forceinline__ unsigned wg_or_mask(unsigned mine, int nbits, unsigned *slots, int wave, int lane)
+{
+    static_assert(NW == 4 || NW == 8, "one 16-byte read per four waves");
+    unsigned wmask = 0;
+    for (int b = 0; b < nbits; ++b)
+        if (__builtin_amdgcn_ballot_w64(((mine >> b) & 1u) != 0)) wmask |= 1u << b;
+    if (lane == 0) slots[wave] = wmask;
+    __syncthreads();
+    const uint4 lo = *reinterpret_cast<const uint4 *>(slots);
+    unsigned all = lo.x | lo.y | lo.z | lo.w;
+    if constexpr (NW == 8) {
+        const uint4 hi = *reinterpret_cast<const uint4 *>(slots + 4);
+        all |= hi.x | hi.y | hi.z | hi.w;
+    }
+    return __builtin_amdgcn_readfirstlane(all);
+}
+
 // ---------------------------------------------------------------------------------------
 template <typename T, int MT, int WM, int WN, bool CONJ, bool MASK>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))   // 256-register budget
@@ -95,7 +132,7 @@ k_hgemm16(const T *__restrict__ in, const T *__restrict__ mask, const uint4 *__r
     static_assert(BM % 64 == 0 && (16 * BF) % 512 == 0, "tile/threads");
     constexpr unsigned TBL = CONJ ? kSignConj : kSignConv;
     constexpr int TILE_U = BM * 16 + 16 * BF;       // 16-byte units of one (A, B) tile pair
-    __shared__ __attribute__((aligned(16))) uint4 lds[2 * TILE_U + 1];   // double buffered (+ one word: tile tap mask)
+    __shared__ __attribute__((aligned(16))) uint4 lds[2 * TILE_U + 2];   // double buffered (+ 8 words: per-wave tap masks)
     // A: [row][slot ^ (row & 15)] at lds + buf*TILE_U ; B: [slot][part][j] right behind it
 
     const int tid = threadIdx.x;
@@ -152,15 +189,10 @@ k_hgemm16(const T *__restrict__ in, const T *__restrict__ mask, const uint4 *__r
     // border image rows of every 'same' convolution.  The mask is the OR of the rows' masks, via one LDS word.
     unsigned tile_taps;
     {
-        unsigned *tw = reinterpret_cast<unsigned *>(lds + 2 * TILE_U);
-        if (tid == 0) *tw = 0u;
-        __syncthreads();
         unsigned mine = 0;
 #pragma unroll
         for (int r = 0; r < RPT2; ++r) mine |= tapmask[r];
-        if (mine) atomicOr(tw, mine);
-        __syncthreads();
-        tile_taps = __builtin_amdgcn_readfirstlane(*tw);
+        tile_taps = wg_or_mask<8>(mine, g.taps, reinterpret_cast<unsigned *>(lds + 2 * TILE_U), wave, lane);
     }
     const int iters = __builtin_popcount(tile_taps) * nkc;
     // slot s8 / s8+8 -> (component, 8-channel group) -> element offset inside the row
@@ -276,7 +308,7 @@ k_hgemm16(const T *__restrict__ in, const T *__restrict__ mask, const uint4 *__r
     if (iters > 1) load_tile();
     __syncthreads();
 
-    for (int it = 0; it < iters; ++it) {
+    for (int it = (g.ablate & 4) ? iters : 0; it < iters; ++it) {          // (ablate 4: profiling, no K loop)
         const int nb = (it + 1) & 1;
         const uint4 *a_rd = lds + (it & 1) * TILE_U + a_rd0;
         const uint4 *b_rd = lds + (it & 1) * TILE_U + b_rd0;
@@ -328,6 +360,7 @@ k_hgemm16(const T *__restrict__ in, const T *__restrict__ mask, const uint4 *__r
     // per lane (store-issue bound: 17 % of the kernel, measured).  Each wave instead transposes its
     // 32x32 tiles through a private 2.5 KB LDS patch (the tile buffers are free after the last
     // barrier; a wave's own LDS accesses execute in order) and writes 8 channels = 16 bytes per lane.
+    if ((g.ablate & 8) && acc[0][0][0] != 123.456f) return;          // (ablate 8: profiling, no epilogue)
     constexpr int EP_PITCH = 80;                                   // 64 B of data + 16 B pad per row
     char *ep = reinterpret_cast<char *>(lds) + wave * (32 * EP_PITCH);
     const int e_row = lane >> 2, e_chunk = lane & 3;
@@ -338,11 +371,14 @@ k_hgemm16(const T *__restrict__ in, const T *__restrict__ mask, const uint4 *__r
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v = acc[mt][b][r] + bia;
-                if constexpr (SPLIT) v -= accn[b][r];
-                if (g.relu) v = v > 0.f ? v : 0.f;
-                *reinterpret_cast<T *>(ep + mfma32_row(r, lane) * EP_PITCH + lr * 2) = from_f32<T>(v);
+            for (int r = 0; r < 16; r += 2) {               // registers r, r + 1 hold consecutive rows
+                float v0 = acc[mt][b][r] + bia, v1 = acc[mt][b][r + 1] + bia;
+                if constexpr (SPLIT) { v0 -= accn[b][r]; v1 -= accn[b][r + 1]; }
+                if (g.relu) { v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f; }
+                const unsigned pk = pack2(T(), v0, v1);
+                char *dst = ep + mfma32_row(r, lane) * EP_PITCH + lr * 2;
+                *reinterpret_cast<unsigned short *>(dst) = (unsigned short)pk;
+                *reinterpret_cast<unsigned short *>(dst + EP_PITCH) = (unsigned short)(pk >> 16);
             }
 #pragma unroll
             for (int pass = 0; pass < 2; ++pass) {
@@ -397,25 +433,39 @@ constexpr int band_op(int R, int K, int ti, int k)
 {
     if (R == 3 && K == 5) { const int t[5][5] = {{0, 1, -1, -1, -1}, {3, 2, -1, -1, -1}, {4, -1, -1, -1, -1}, {5, -1, -1, -1, -1}, {-1, -1, -1, -1, -1}}; return t[ti][k]; }
     if (R == 3 && K == 3) { const int t[3][5] = {{0, 1, -1, -1, -1}, {3, 4, 2, -1, -1}, {5, -1, -1, -1, -1}}; return t[ti][k]; }
+    if (R == 4 && K == 5) { const int t[5][5] = {{0, 1, -1, -1, -1}, {4, 2, -1, -1, -1}, {5, 3, -1, -1, -1}, {6, -1, -1, -1, -1}, {7, -1, -1, -1, -1}}; return t[ti][k]; }
+    if (R == 4 && K == 3) { const int t[3][5] = {{0, 1, 2, -1, -1}, {4, 5, 3, -1, -1}, {6, 7, -1, -1, -1}}; return t[ti][k]; }
     if (R == 5 && K == 5) { const int t[5][5] = {{0, 1, -1, -1, -1}, {5, 2, -1, -1, -1}, {6, 3, -1, -1, -1}, {7, 4, -1, -1, -1}, {8, 9, -1, -1, -1}}; return t[ti][k]; }
     if (R == 5 && K == 3) { const int t[3][5] = {{0, 1, 2, -1, -1}, {5, 6, 7, 3, 4}, {8, 9, -1, -1, -1}}; return t[ti][k]; }
     return -2;
 }
 
-template <typename T, int WM, int WN, int KIN, bool CONJ>
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+// Workgroup shapes (WM x WN waves of 32 rows x (4 components x 32 channels)):
+//   8 waves, one workgroup per CU (LDS 100 - 150 KB): the original form;
+//   4 waves, TWO workgroups per CU (LDS <= 80 KB each): a tile's prologue (row decode, first band: an HBM burst of
+//     ~64 KB per CU) and epilogue (64 KB of stores) are 21 % (N = 256) to 38 % (N = 128) of the 8-wave kernels'
+//     time (ablation), and with one workgroup per CU nothing overlaps them.  Two independent
+//     workgroups per CU let the hardware run one's K loop under the other's prologue / epilogue.
+//   TRIM (N = 128, 4 x 1 waves): the band buffer holds exactly BM = 128 rows, so a tile yields BM - (KIN - 1)
+//     output rows and the last KIN - 1 rows of the wave tiles are computed and dropped (3 %): 2 x 128 rows x 256 B
+//     + 2 B tiles = 80 KB is what lets two such workgroups share a CU.
+template <typename T, int WM, int WN, int KIN, bool CONJ, bool TRIM>
+__global__ void __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *__restrict__ zero_line,
                const float *__restrict__ bias, T *__restrict__ out, const GemmGeom g)
 {
-    static_assert(WM * WN == 8, "8 waves per workgroup");
+    constexpr int NW = WM * WN, NTHR = NW * 64;
+    static_assert(NW == 8 || NW == 4, "8 waves (one workgroup per CU) or 4 waves (two per CU)");
     static_assert(KIN >= 2 && KIN <= 9, "inner taps per band");
     constexpr int BM = WM * 32, BF = WN * 32;
-    constexpr int BU = (16 * BF) / 512;
+    constexpr int BMU = TRIM ? BM - (KIN - 1) : BM;    // output rows a tile yields
+    constexpr int BU = (16 * BF) / NTHR;               // 16-byte units of the B tile per thread
+    static_assert(BU >= 1 && BU <= 4 && (16 * BF) % NTHR == 0 && NTHR % BF == 0, "B tile / threads");
     constexpr unsigned TBL = CONJ ? kSignConj : kSignConv;
-    constexpr int BAND = BM + KIN - 1;             // rows of the A band
-    constexpr int A_U = (BM + 8) * 16;             // 16-byte units of one band buffer
+    constexpr int BAND = TRIM ? BM : BM + KIN - 1;     // rows of the A band
+    constexpr int A_U = (TRIM ? BM : BM + 8) * 16;     // 16-byte units of one band buffer
     constexpr int B_U = 16 * BF;
-    __shared__ __attribute__((aligned(16))) uint4 lds[2 * A_U + 2 * B_U + 1];   // (+ one word: tile tap mask)
+    __shared__ __attribute__((aligned(16))) uint4 lds[2 * A_U + 2 * B_U];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -424,22 +474,23 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
     const int lr = lane & 31, lh = lane >> 5;
     const int WP = g.b_wp;
     const int total_p = g.b_nlines * WP;           // padded rows (host checked < 2^31)
-    const int n_mt = (total_p + BM - 1) / BM;
+    const int n_mt = (total_p + BMU - 1) / BMU;
     const int per_xcd = (n_mt + 7) / 8;
     const int mtile = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
     if (mtile >= n_mt) return;
-    const int p0 = mtile * BM;
+    const int p0 = mtile * BMU;
     const int j0 = blockIdx.y * BF;
     const int nkc = g.Q / 32;
 
     // ---- band rows of this thread (decoded once) ------------------------------------------------
-    constexpr int RPT3 = (BAND + 63) / 64;
+    constexpr int RPP = NTHR / 8;                   // rows per staging pass (8 threads per row)
+    constexpr int RPT3 = (BAND + RPP - 1) / RPP;
     const int s_row = tid >> 3, s8 = tid & 7;
     int base_off[RPT3];
     unsigned omask[RPT3];                           // bit (t0 * ks1 + t1): outer tap inside the tensor
 #pragma unroll
     for (int r = 0; r < RPT3; ++r) {
-        const int j = s_row + r * 64;
+        const int j = s_row + r * RPP;
         base_off[r] = 0; omask[r] = 0;
         const int P = p0 + j;
         const int line = P / WP;
@@ -460,18 +511,14 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
                 }
         }
     }
-    // outer taps no row of this band can use are skipped altogether (see k_hgemm16): border image rows
+    // outer taps no row of this band can use are skipped altogether (see k_hgemm16): border image rows.
+    // (The per-wave words live at the start of B buffer 1, which is first written inside the K loop.)
     unsigned tile_ot;
     {
-        unsigned *tw = reinterpret_cast<unsigned *>(lds + 2 * A_U + 2 * B_U);
-        if (tid == 0) *tw = 0u;
-        __syncthreads();
         unsigned mine = 0;
 #pragma unroll
         for (int r = 0; r < RPT3; ++r) mine |= omask[r];
-        if (mine) atomicOr(tw, mine);
-        __syncthreads();
-        tile_ot = __builtin_amdgcn_readfirstlane(*tw);
+        tile_ot = wg_or_mask<NW>(mine, g.ks[0] * g.ks[1], reinterpret_cast<unsigned *>(lds + 2 * A_U + B_U), wave, lane);
     }
     const int groups = __builtin_popcount(tile_ot) * nkc;
     const int substeps = groups * KIN;
@@ -479,13 +526,15 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
     const __amdgpu_buffer_rsrc_t rin = make_rsrc16(in, g.b_in_bytes), rw = make_rsrc16(wq, g.b_w_bytes);
     const unsigned a_thr = (unsigned)(cmp_lo * g.Q + sub) * 2u;        // this thread's (component, 8 channels) of a row
     const unsigned a_hi = (unsigned)g.Q * 4u;                            // two components further (wave-uniform)
+    // B unit u = tid + k * NTHR lies (NTHR / BF) (slot, part) segments further per k: a wave-uniform offset
     const unsigned b_thr0 = (unsigned)((tid / BF) * g.J + j0 + tid % BF) * 16u;
-    const unsigned b_thr1 = (unsigned)(((tid + 512) / BF) * g.J + j0 + (tid + 512) % BF) * 16u;
+    const unsigned b_kstep = (unsigned)((NTHR / BF) * g.J) * 16u;
     // (named registers, not an array: hipcc leaves a 128-byte by-reference-captured array in scratch
     // here -- every staged unit then takes a scratch round trip)
-    constexpr int RPTF = RPT3 - 1;                  // full 64-row passes; pass RPTF is the KIN - 1 halo rows
-    static_assert(RPTF * 64 == BM && RPTF <= 4, "band = up to four full passes + one halo pass");
-    uint4 a0l, a0h, a1l, a1h, a2l, a2h, a3l, a3h, ah0, ah1, br0, br1;
+    constexpr bool HALO = !TRIM;                    // pass RPTF holds the KIN - 1 halo rows (none when trimmed)
+    constexpr int RPTF = HALO ? RPT3 - 1 : RPT3;    // full passes
+    static_assert(RPTF * RPP == BM && RPTF <= 4, "band = up to four full passes (+ one halo pass)");
+    uint4 a0l, a0h, a1l, a1h, a2l, a2h, a3l, a3h, ah0, ah1, br0, br1, br2, br3;
 
     // group the A loads fetch (outer tap at0/at1 = index aot, channel chunk akc); stops at the last
     int at0 = 0, at1 = 0, aot = 0, akc = 0, a_next = 0, adelta = 0;
@@ -514,7 +563,7 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
         if (r < RPTF || wave == 0) {                // the halo pass holds KIN - 1 <= 8 rows: wave 0 only
             const uint4 vl = buf_load16b(rin, voff, 0);
             const uint4 vh = buf_load16b(rin, voff, a_hi);
-            if (r == RPTF) { ah0 = vl; ah1 = vh; }
+            if (HALO && r == RPTF) { ah0 = vl; ah1 = vh; }
             else if (r == 0) { a0l = vl; a0h = vh; }
             else if (r == 1) { a1l = vl; a1h = vh; }
             else if (r == 2) { a2l = vl; a2h = vh; }
@@ -522,11 +571,12 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
         }
     };
     auto store_a = [&](int r, int buf) {
-        const int row = s_row + r * 64;
+        const int row = s_row + r * RPP;
         uint4 *As = lds + buf * A_U;
         if (r < RPTF || (wave == 0 && row < BAND)) {
-            const uint4 vl = r == RPTF ? ah0 : r == 0 ? a0l : r == 1 ? a1l : r == 2 ? a2l : a3l;
-            const uint4 vh = r == RPTF ? ah1 : r == 0 ? a0h : r == 1 ? a1h : r == 2 ? a2h : a3h;
+            const bool halo = HALO && r == RPTF;
+            const uint4 vl = halo ? ah0 : r == 0 ? a0l : r == 1 ? a1l : r == 2 ? a2l : a3l;
+            const uint4 vh = halo ? ah1 : r == 0 ? a0h : r == 1 ? a1h : r == 2 ? a2h : a3h;
             As[row * 16 + (s8 ^ (row & 15))] = vl;
             As[row * 16 + ((s8 + 8) ^ (row & 15))] = vh;
         }
@@ -545,14 +595,13 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
             if (++bti == KIN) { bti = 0; if (++bkc == nkc) { bkc = 0; bot = __builtin_ctz(tile_ot & (~1u << bot)); } }
         }
     };
-    auto load_b = [&]() {
-        br0 = buf_load16b(rw, b_thr0, bsoff);
-        if constexpr (BU == 2) br1 = buf_load16b(rw, b_thr1, bsoff);
+    auto load_b1 = [&](int k) {                     // one 16-byte unit of the B tile
+        const uint4 v = buf_load16b(rw, b_thr0, bsoff + (unsigned)k * b_kstep);
+        if (k == 0) br0 = v; else if (k == 1) br1 = v; else if (k == 2) br2 = v; else br3 = v;
     };
-    auto store_b = [&](int buf) {
+    auto store_b1 = [&](int k, int buf) {
         uint4 *Bs = lds + 2 * A_U + buf * B_U;
-        Bs[tid] = br0;
-        if constexpr (BU == 2) Bs[tid + 512] = br1;
+        Bs[tid + k * NTHR] = k == 0 ? br0 : k == 1 ? br1 : k == 2 ? br2 : br3;
     };
 
     floatx16 acc[4], accn[4];
@@ -568,17 +617,26 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
     a_prep();
 #pragma unroll
     for (int r = 0; r < RPT3; ++r) load_a(r);
+    b_prep();
+#pragma unroll
+    for (int k = 0; k < BU; ++k) load_b1(k);
 #pragma unroll
     for (int r = 0; r < RPT3; ++r) store_a(r, 0);
     a_advance_if_more();
-    b_prep(); load_b(); store_b(0); b_advance_if_more();
-    b_prep(); load_b(); b_advance_if_more();
+#pragma unroll
+    for (int k = 0; k < BU; ++k) store_b1(k, 0);
+    b_advance_if_more();
+    b_prep();
+#pragma unroll
+    for (int k = 0; k < BU; ++k) load_b1(k);
+    b_advance_if_more();
     __syncthreads();
 
     static_assert(band_op(RPT3, KIN, 0, 0) != -2, "no staging schedule for this (row passes, inner taps)");
+    static_assert(kBandOpsMax + 2 * BU <= 16, "one staging slot after every second MFMA");
 
     int s = 0;                                      // global sub-step
-    for (int gi = 0; gi < groups; ++gi) {
+    for (int gi = (g.ablate & 4) ? groups : 0; gi < groups; ++gi) {      // (ablate 4: profiling, no K loop)
         const uint4 *band = lds + (gi & 1) * A_U;
         const int nband = (gi + 1) & 1;
         a_prep();
@@ -613,8 +671,8 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
                                 const int q = band_op(RPT3, KIN, ti, op);
                                 if (q >= RPT3) store_a(q - RPT3, nband);
                                 else if (q >= 0) load_a(q);
-                            } else if (op == kBandOpsMax) store_b(nb);
-                            else if (op == kBandOpsMax + 1) load_b();
+                            } else if (op < kBandOpsMax + BU) store_b1(op - kBandOpsMax, nb);
+                            else if (op < kBandOpsMax + 2 * BU) load_b1(op - kBandOpsMax - BU);
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
@@ -626,6 +684,7 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
     }
 
     // ---- epilogue: bias + activation, per-wave LDS transpose, 16-byte stores (see k_hgemm16) --------
+    if ((g.ablate & 8) && acc[0][0] != 123.456f) return;              // (ablate 8: profiling, no epilogue)
     constexpr int EP_PITCH = 80;
     char *ep = reinterpret_cast<char *>(lds) + wave * (32 * EP_PITCH);
     const int e_row = lane >> 2, e_chunk = lane & 3;
@@ -636,10 +695,11 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
     bool o_ok[2];
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
-        const int P = p0 + wm * 32 + e_row + 16 * pass;
+        const int tr = wm * 32 + e_row + 16 * pass;                  // row inside the tile
+        const int P = p0 + tr;
         const int line = P / WP;
         const int u = P - line * WP;
-        o_ok[pass] = line < g.b_nlines && u < g.osp[2];
+        o_ok[pass] = line < g.b_nlines && u < g.osp[2] && (!TRIM || tr < BMU);
         o_row[pass] = (long long)(line * g.osp[2] + u) * (int)g.out_ss + j0 + wn * 32 + e_chunk * 8;
     }
     uint4 em[4][2];
@@ -655,10 +715,13 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
     for (int b = 0; b < 4; ++b) {
         const float bia = g.has_bias ? bias[b * g.J + j0 + wn * 32 + lr] : 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float v = acc[b][r] - accn[b][r] + bia;
-            if (g.relu) v = v > 0.f ? v : 0.f;
-            *reinterpret_cast<T *>(ep + mfma32_row(r, lane) * EP_PITCH + lr * 2) = from_f32<T>(v);
+        for (int r = 0; r < 16; r += 2) {                   // registers r, r + 1 hold consecutive rows
+            float v0 = acc[b][r] - accn[b][r] + bia, v1 = acc[b][r + 1] - accn[b][r + 1] + bia;
+            if (g.relu) { v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f; }
+            const unsigned pk = pack2(T(), v0, v1);
+            char *dst = ep + mfma32_row(r, lane) * EP_PITCH + lr * 2;
+            *reinterpret_cast<unsigned short *>(dst) = (unsigned short)pk;
+            *reinterpret_cast<unsigned short *>(dst + EP_PITCH) = (unsigned short)(pk >> 16);
         }
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
@@ -672,17 +735,17 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
     }
 }
 
-template <typename T, int WM, int WN, int KIN>
+template <typename T, int WM, int WN, int KIN, bool TRIM>
 int run16_band(const T *in, const uint4 *wq, const T *zero_line, const float *bias, T *out, const GemmGeom &g,
                hipStream_t stream)
 {
-    constexpr int BM = WM * 32, BF = WN * 32;
-    const int n_mt = (int)(((long long)g.b_nlines * g.b_wp + BM - 1) / BM);
+    constexpr int BM = WM * 32, BF = WN * 32, BMU = TRIM ? BM - (KIN - 1) : BM, NTHR = WM * WN * 64;
+    const int n_mt = (int)(((long long)g.b_nlines * g.b_wp + BMU - 1) / BMU);
     dim3 grid((n_mt + 7) / 8 * 8, g.J / BF, 1);
     if (g.sign_tbl == kSignConj)
-        hipLaunchKernelGGL((k_hgemm16_band<T, WM, WN, KIN, true>), grid, dim3(512), 0, stream, in, wq, zero_line, bias, out, g);
+        hipLaunchKernelGGL((k_hgemm16_band<T, WM, WN, KIN, true, TRIM>), grid, dim3(NTHR), 0, stream, in, wq, zero_line, bias, out, g);
     else
-        hipLaunchKernelGGL((k_hgemm16_band<T, WM, WN, KIN, false>), grid, dim3(512), 0, stream, in, wq, zero_line, bias, out, g);
+        hipLaunchKernelGGL((k_hgemm16_band<T, WM, WN, KIN, false, TRIM>), grid, dim3(NTHR), 0, stream, in, wq, zero_line, bias, out, g);
     return hipGetLastError() == hipSuccess ? 1 : QK_ERR_LAUNCH;
 }
 
@@ -704,9 +767,11 @@ int run16(const T *in, const T *mask, const uint4 *wq, const T *zero_line, const
 }
 
 template <typename T>
-int go16(const void *in, const void *mask, const float *w, const float *bias, void *out, const GemmGeom &g,
+int go16(const void *in, const void *mask, const float *w, const float *bias, void *out, const GemmGeom &g_in,
          bool transposed, void *ws, hipStream_t stream)
 {
+    GemmGeom g = g_in;
+    g.ablate = debug_ablate();
     T *wq = static_cast<T *>(ws);
     const int Cq = transposed ? g.J : g.Q, F = transposed ? g.Q : g.J;
     const long long total = (long long)g.taps * Cq * 4 * F;
@@ -717,16 +782,30 @@ int go16(const void *in, const void *mask, const float *w, const float *bias, vo
     const uint4 *wq4 = reinterpret_cast<const uint4 *>(wq);
     const T *zero_line = wq + total;                 // 256 zeroed bytes behind the re-laid-out kernel
     GemmGeom bg;
-    if (!getenv("QK_NO_BAND16") && band_geom(g, 2, &bg)) {
+    if (!(debug_flags() & kDbgNoBand16) && band_geom(g, 2, &bg)) {
         const T *ip = (const T *)in;
         T *op = (T *)out;
+        note_path(QK_PATH_MFMA16_BAND);
+        // Workgroup shape, by measurement on MI355X (tools/gpu_ab.sh, B = 256 TIMIT layers, us per launch):
+        //   N = 128 (J = 32):  8 waves 384 / 376 (fwd / bwd-data)  ->  4 waves x 2 per CU, trimmed band  327 / 319
+        //   N = 256 (J = 64):  8 waves 1166 / 1158                ->  4 waves (64-row tiles)           1166 / 1113
+        // The 64-row tiles stage twice the B units per MFMA and their conv-table instantiation spills inside the
+        // K loop, so N = 256 takes the 4-wave form only with the transposed table (the backward-data of a plain
+        // convolution); QK_DBG_BAND16_8WAVES forces the 8-wave tilings everywhere (A/B switch).
+        const bool w8 = (debug_flags() & kDbgBand8Waves) != 0;
+        const bool w8_wide = w8 || bg.sign_tbl != kSignConj;
         if (bg.ks[2] == 5) {
-            if (g.J % 64 == 0) return run16_band<T, 4, 2, 5>(ip, wq4, zero_line, bias, op, bg, stream);
-            return run16_band<T, 8, 1, 5>(ip, wq4, zero_line, bias, op, bg, stream);
+            if (g.J % 64 == 0) return w8_wide ? run16_band<T, 4, 2, 5, false>(ip, wq4, zero_line, bias, op, bg, stream)
+                                              : run16_band<T, 2, 2, 5, false>(ip, wq4, zero_line, bias, op, bg, stream);
+            return w8 ? run16_band<T, 8, 1, 5, false>(ip, wq4, zero_line, bias, op, bg, stream)
+                      : run16_band<T, 4, 1, 5, true>(ip, wq4, zero_line, bias, op, bg, stream);
         }
-        if (g.J % 64 == 0) return run16_band<T, 4, 2, 3>(ip, wq4, zero_line, bias, op, bg, stream);
-        return run16_band<T, 8, 1, 3>(ip, wq4, zero_line, bias, op, bg, stream);
+        if (g.J % 64 == 0) return w8_wide ? run16_band<T, 4, 2, 3, false>(ip, wq4, zero_line, bias, op, bg, stream)
+                                          : run16_band<T, 2, 2, 3, false>(ip, wq4, zero_line, bias, op, bg, stream);
+        return w8 ? run16_band<T, 8, 1, 3, false>(ip, wq4, zero_line, bias, op, bg, stream)
+                  : run16_band<T, 4, 1, 3, true>(ip, wq4, zero_line, bias, op, bg, stream);
     }
+    note_path(QK_PATH_MFMA16);
     if (g.J % 64 == 0) {
         // (256-row tiles, MT = 2, were measured: no gain over 128 rows, and they spill)
         return run16<T, 1, 4, 2>((const T *)in, (const T *)mask, wq4, zero_line, bias, (T *)out, g, stream);
@@ -751,7 +830,7 @@ int try_hgemm_16(int dtype, const void *in, const void *mask, const float *w_f32
     const size_t need = (size_t)g.taps * g.Q * 4 * g.J * 2 + 256;
     if (!ws || ws_bytes < need) return 0;
     if ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(ws) | reinterpret_cast<uintptr_t>(mask)) & 15) return 0;
-    if (getenv("QK_NO_MFMA16")) return 0;                              // diagnostic switch
+    if (debug_flags() & kDbgNoMfma16) return 0;                        // diagnostic switch
     if (dtype == QK_BF16) return go16<bf16>(in, mask, w_f32, bias, out, g, w_is_transposed, ws, stream);
     return go16<f16>(in, mask, w_f32, bias, out, g, w_is_transposed, ws, stream);
 }

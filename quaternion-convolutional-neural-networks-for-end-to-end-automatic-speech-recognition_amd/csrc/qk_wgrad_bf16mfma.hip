@@ -341,6 +341,7 @@ k_wgrad16(const T *__restrict__ x, const T *__restrict__ dy, const T *__restrict
     // Phase ph deposits the rows of gathered component a = ph onto part p = ph ^ b.  Waves that hold
     // the same a differ in their output components b (disjoint p), or in their channels cc, so the
     // plain LDS read-modify-write is race free; phase 0 (p = b) initialises every slab entry.
+    if ((g.ablate & 1) && acc[0][0][0] != 123.456f) return;          // (ablate 1: profiling, no fold / atomics)
     float *slab = reinterpret_cast<float *>(lds);
     const int lr = lane & 31;
 #pragma unroll
@@ -372,7 +373,7 @@ k_wgrad16(const T *__restrict__ x, const T *__restrict__ dy, const T *__restrict
         const int p = (e / BF) & 3;
         const int cv = e / (4 * BF);                                    // virtual channel: member * BCQ + cc
         const int tm = t * TG + cv / BCQ;
-        if (tm < g.taps)
+        if (tm < g.taps && !(g.ablate & 2))
             atomicAdd(dw + ((tm * g.Cq + c0 + cv % BCQ) * 4 + p) * g.F + f0 + ff, slab[e]);
     }
     if (bias_blk && tid < 4 * BF) {
@@ -391,15 +392,11 @@ int run_wgrad16(const T *x, const T *dy, const T *ymask, float *dw, float *dbias
     const long long max_splits = ((long long)g.M + KM - 1) / KM;
     // Split M so that the grid fills a whole number of residency rounds: with 144 KB of LDS there is
     // one workgroup per CU, and e.g. 780 equal tiles on 256 CUs take four rounds, the last 5 % full.
-    static int slots = 0;
-    if (!slots) {
-        int dev = 0, n_cu = 0, per_cu = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_wgrad16<T, WR, WC, TN, TG, true>, WR * WC * 64, 0) != hipSuccess)
-            return QK_ERR_LAUNCH;
-        slots = (n_cu > 0 ? n_cu : 256) * (per_cu > 0 ? per_cu : 1);
-    }
+    // resident workgroups per CU follow from the kernel's static LDS (160 KB per CU); the CU count is asked of
+    // the current device on every call (multi-GPU processes, no cached state)
+    constexpr int kLdsBytes = 2 * KM * ((4 * WR * 16 * 2 + 64) + (4 * WC * TN * 8 * 2 + 64));
+    constexpr int per_cu = (160 * 1024) / kLdsBytes > 0 ? (160 * 1024) / kLdsBytes : 1;
+    const int slots = device_cu_count() * (per_cu > 2 ? 2 : per_cu);        // 8-wave blocks, 2 waves per SIMD: <= 2
     const long long kEpilogueSteps = 16;                   // fold + atomics, in K-step equivalents
     long long splits = 1, best_cost = -1;
     for (int r = 1; r <= 4; ++r) {
@@ -419,7 +416,7 @@ int run_wgrad16(const T *x, const T *dy, const T *ymask, float *dw, float *dbias
     g.n_splits = (int)splits;
     g.x_bytes = (unsigned)((long long)g.batch * g.x_sn * 2);
     g.dy_bytes = (unsigned)((long long)g.M * g.dy_ss * 2);
-    g.ablate = 0;
+    g.ablate = debug_ablate();
     const long long n_tiles = splits * other;
     dim3 grid((unsigned)((n_tiles + 7) / 8 * 8), 1, 1);      // padded to the 8 XCDs (see the tile remap)
     if (g.has_mask)
@@ -434,7 +431,7 @@ int go_wgrad16(const void *x, const void *dy, const void *ymask, float *dw, floa
                hipStream_t stream)
 {
     const T *xp = (const T *)x, *dp = (const T *)dy, *yp = (const T *)ymask;
-    const bool one_tap = getenv("QK_WGRAD16_ONE_TAP") != nullptr;     // tuning aid: the TG = 1 tilings only
+    const bool one_tap = (debug_flags() & kDbgWgradOneTap) != 0;      // tuning aid: the TG = 1 tilings only
     if (g.Cq % 64 == 0) {
         if (g.F % 64 == 0) return run_wgrad16<T, 4, 2, 4, 1>(xp, dp, yp, dw, dbias, g, stream);
         return run_wgrad16<T, 4, 2, 2, 1>(xp, dp, yp, dw, dbias, g, stream);
@@ -462,7 +459,8 @@ int try_wgrad_16(int dtype, const void *x, const void *dy, const void *ymask, fl
     // buffer-resource addressing: 32-bit byte offsets, kOutOfRange must stay beyond every extent
     if ((long long)g.batch * g.x_sn * 2 >= 0xF0000000ll || (long long)g.M * g.dy_ss * 2 >= 0xF0000000ll) return 0;
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(ymask)) & 15) return 0;
-    if (getenv("QK_NO_MFMA16")) return 0;
+    if (debug_flags() & kDbgNoMfma16) return 0;
+    note_path(QK_PATH_MFMA16);
     if (dtype == QK_BF16) return go_wgrad16<bf16>(x, dy, ymask, dw, dbias, g, stream);
     return go_wgrad16<f16>(x, dy, ymask, dw, dbias, g, stream);
 }

@@ -254,3 +254,19 @@ def test_component_getters_follow_reference_axis_rule():
     assert getpart_quaternion_output_shape_first((None, 8, 3, 5)) == (None, 2, 3, 5)
     assert getpart_quaternion_output_shape_first((None, 5, 8)) == (None, 5, 2)
     assert GetRFirst().compute_output_shape((None, 8)) == (None, 2)
+
+
+def test_debug_flags_are_a_process_wide_mask_set_through_the_c_abi():
+    """qk_set_debug_flags / qk_get_debug_flags (include/qk.h): the diagnostic switches are one atomic word, not
+    getenv calls on the launch path; the Python context manager restores the previous mask."""
+    lib = _lib.lib()
+    prev = lib.qk_get_debug_flags()
+    try:
+        assert lib.qk_set_debug_flags(_lib.QK_DBG_NO_MFMA16 | _lib.QK_DBG_NO_BAND16) == prev
+        assert lib.qk_get_debug_flags() == 3
+        with _lib.debug_flags(_lib.QK_DBG_WGRAD16_ONE_TAP, ablate=5):
+            assert lib.qk_get_debug_flags() == (3 | 8 | (5 << 8))
+        assert lib.qk_get_debug_flags() == 3
+    finally:
+        lib.qk_set_debug_flags(prev)
+    assert _lib.last_path() in _lib.QK_PATH_NAMES.values()

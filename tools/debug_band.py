@@ -16,12 +16,13 @@ for xs, ws in cases:
     call = F.conv_call(tuple(xs), tuple(ws), dtype, rank, 1, 'same', 'channels_last', 1, 'linear', True)
     outs = []
     for nb in (False, True):
-        if nb: os.environ['QK_NO_BAND16'] = '1'
+        from qcnn_amd import _lib
+        prev = _lib.lib().qk_set_debug_flags(_lib.QK_DBG_NO_BAND16 if nb else 0)
         y = call.fwd(x, w, b)
         dy = torch.randn(y.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(5)).to(dtype)
         dx = call.bwd_data(dy, None, w)
         torch.cuda.synchronize()
-        if nb: del os.environ['QK_NO_BAND16']
+        _lib.lib().qk_set_debug_flags(prev)
         outs.append((y.float(), dx.float()))
     ey = float((outs[0][0] - outs[1][0]).abs().max() / outs[1][0].abs().max())
     ex = float((outs[0][1] - outs[1][1]).abs().max() / outs[1][1].abs().max())

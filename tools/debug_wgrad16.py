@@ -16,9 +16,9 @@ for dtype in (torch.bfloat16, torch.float16):
         y = call.fwd(x, w, b)
         dy = torch.randn(y.shape, device=dev, generator=g).to(dtype)
         want = torch.where(y > 0, dy, torch.zeros_like(dy))
-        os.environ['QK_NO_MFMA16'] = '1'
-        dw_ref, db_ref = call.bwd_weight(x, dy, y, True)
-        del os.environ['QK_NO_MFMA16']
+        from qcnn_amd import _lib
+        with _lib.debug_flags(_lib.QK_DBG_NO_MFMA16):
+            dw_ref, db_ref = call.bwd_weight(x, dy, y, True)
         bad_dym = bad_dw = 0
         worst = 0.0
         for rep in range(20):
