@@ -3,18 +3,24 @@
 
     python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
 
-Default workload = BASELINE.json configs[1]: ONE QuaternionConv1D(64, 3, padding='same',
-activation='relu') layer, forward + backward (d input, d kernel, d bias) + the Keras-Adam update
-of the compact kernel, on a synthetic TIMIT-shape batch x (64, 200, 160) channels_last fp32
-(40 mel x 4 quaternion components, 200 frames), batch 64 PER GPU (weak scaling).  A "step" is one
-such pass over one batch already resident in HBM.  Data-parallel: every rank holds a replica, the
-only exchange is one RCCL sum all-reduce of the flat fp32 gradient buffer per step, issued right
-after backward-weight so it overlaps backward-data.
+Default workload (every N) = BASELINE.json configs[2] / [3]: the FULL TIMIT quaternion CNN of
+models/interspeech_model.py (n=10, sf=32: conv 1->32, pool, 5 x conv 32, 5 x conv 64, 3 x TimeDistributed
+QuaternionDense(256), Dense(62) softmax), bf16, 256 samples PER GPU (weak scaling: global batch 256 N, 2048 on
+8 GPUs), forward + backward of every layer + the Keras-Adam update of all 1.68 M parameters.  A "step" is one such
+pass over one synthetic batch already resident in HBM.  Data-parallel: every rank holds a replica; gradients are
+summed with bucketed RCCL all-reduces launched from autograd hooks while the backward is still running
+(qcnn_amd/dp.py), 1/N folded into the fused Adam kernel.
 
-Prints ONE JSON line on rank 0 (see the contract in the task description): value = whole-job
-samples/s; `roofline` = the dominant kernel's algorithmic FLOPs / its average duration measured
-with HIP events on the launch stream, against the fp32-MFMA peak; `cpu_baseline` = the
-reference's CPU op sequence (oracle/ref_port.py, torch-CPU) timed on this host (N=1 only).
+Prints ONE JSON line on rank 0.  `value` = whole-job samples/s of that step.  At N = 1 the line also carries
+  roofline       the kernel that takes the largest share of the step (one of the Hamilton GEMM kernels of the
+                 64 -> 64 body convolution, M = 716 800, N = 256, K = 3840): 2MNK / its MEAN launch duration measured
+                 live with HIP events on the launch stream, against the 2.5 PF dense bf16 MFMA peak; traffic = HBM bytes
+                 per launch from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json)
+  hamilton_gemm  all three kernels of that layer (the "% of MFMA peak at batch 256" half of BASELINE's metric)
+  layer_kernels  the other two conv shapes of the model (32 -> 32, 32 -> 64)
+  cfg2_layer     BASELINE configs[1]: one QuaternionConv1D(64, 3, 'same', relu) on x (64, 200, 160) fp32, step + kernels
+  cpu_baseline   the reference's CPU op sequence for the same model (oracle/ref_model.py on torch-CPU), bounded sample
+`--workload` selects any single-layer workload instead (then `roofline` is that layer's dominant kernel).
 """
 import argparse
 import json
@@ -41,6 +47,11 @@ WORKLOADS = {
                                         kernel=(3, 5), dtype='bf16'),
     'cfg3_body_qconv2d_b256_fp32': dict(kind='conv', rank=2, batch=256, spatial=(14, 200), cq=64, filters=64,
                                         kernel=(3, 5), dtype='fp32'),
+    # the other two conv shapes of the TIMIT model (stage 1: 32 -> 32; the 32 -> 64 transition)
+    'cfg3_stage1_qconv2d_b256_bf16': dict(kind='conv', rank=2, batch=256, spatial=(14, 200), cq=32, filters=32,
+                                          kernel=(3, 5), dtype='bf16'),
+    'cfg3_32to64_qconv2d_b256_bf16': dict(kind='conv', rank=2, batch=256, spatial=(14, 200), cq=32, filters=64,
+                                          kernel=(3, 5), dtype='bf16'),
     # BASELINE.json configs[4] body layer: Cq = F = 256, fp16, 32 samples per GPU
     'cfg5_body_qconv2d_b32_fp16': dict(kind='conv', rank=2, batch=32, spatial=(14, 200), cq=256, filters=256,
                                        kernel=(3, 5), dtype='fp16'),
@@ -68,7 +79,7 @@ def qcnn_flops(sf, n, batch, frames):
 
 
 class ModelTrainStep(object):
-    """Full TIMIT QCNN: forward + backward (autograd through the C-ABI kernels) + all-reduce + Adam."""
+    """Full TIMIT QCNN: forward + backward (autograd through the C-ABI kernels) + bucketed all-reduce + Adam."""
 
     def __init__(self, cfg, dev, rank, world):
         import qcnn_amd
@@ -82,32 +93,34 @@ class ModelTrainStep(object):
         self.x = torch.randn(B, 41, T, 4, device=dev, generator=gen).to(dt).permute(0, 3, 1, 2)
         np.random.seed(0)
         torch.manual_seed(0)
-        self.model = TimitQCNN(num_layers=cfg['layers'], start_filter=cfg['sf'], act='relu', aact='none', dropout=0.0)
+        self.model = TimitQCNN(num_layers=cfg['layers'], start_filter=cfg['sf'], act='relu',
+                               aact=cfg.get('aact', 'none'), dropout=cfg.get('dropout', 0.0))
+        self.model.train()
         with torch.no_grad():
             self.model(self.x[:2])
         self.model.to(dev)
         params = [p for p in self.model.parameters() if p.requires_grad]
         self.flat = dp.FlatParams(params)
         dp.broadcast_params(self.flat)
+        # one message per >= 1 MB of gradients, launched from autograd hooks as the backward produces them
+        self.reducer = dp.BucketedAllReduce(self.flat, bucket_bytes=cfg.get('bucket_bytes', 1 << 20))
         self.m = torch.zeros_like(self.flat.param)
         self.v = torch.zeros_like(self.flat.param)
         self.target = torch.randn(B, T, 62, device=dev, generator=gen)
         self.t = 0
         self.flops_per_kernel = qcnn_flops(cfg['sf'], cfg['layers'], B, T)      # forward; step = 3x
-        self.gemm = dict(layers='conv 1->%d, %dx conv, 3x TD-dense' % (cfg['sf'], cfg['layers']))
+        self.gemm = dict(layers='conv 1->%d, %dx conv, 3x TD-dense' % (cfg['sf'], cfg['layers']),
+                         parameters=int(sum(p.numel() for p in params)), allreduce_buckets=len(self.reducer.buckets))
         self.y = self.x
 
     def step(self):
         self.t += 1
         pred = self.model(self.x)
-        loss = (pred.float() * self.target).sum()
-        self.flat.zero_grad()
-        loss.backward()
-        work = self.dp.allreduce_sum_(self.flat.grad, async_op=True)
-        if work is not None:
-            work.wait()
+        loss = (pred.float() * self.target).sum()       # (CTC is a "next" row: SURVEY.md 8d asks for a sum loss here)
+        loss.backward()                                 # gradients accumulate into the zeroed flat buffer; the
+        self.reducer.finish()                           # buckets go out while the backward is still running
         self.F.adam_step(self.flat.param, self.flat.grad, self.m, self.v, self.t, lr=5e-4,
-                         grad_scale=1.0 / self.world)
+                         grad_scale=1.0 / self.world, zero_grad=True)
 
     def capture(self):
         raise RuntimeError('model workloads run eagerly (launch overhead is negligible at this size)')
@@ -165,6 +178,14 @@ class LayerTrainStep(object):
         # backward adds into it -- no 5 us fill per step
         self.call.bwd_weight(self.x, self.dy, self.y, True, out=(self.dw, self.db), masked_dy_out=self.dym,
                              accumulate=self.acc_grads)
+
+    def k_bwd_weight_chain(self):
+        """backward-weight as it runs INSIDE a chain of relu layers (functional.quaternion_conv_chain): dy arrives
+        with the relu derivative already applied by the next layer's backward-data epilogue, so no mask, no y."""
+        self.call_lin.bwd_weight(self.x, self.dy, None, True, out=(self.dw, self.db), accumulate=self.acc_grads)
+
+    def k_bwd_data_chain(self):
+        self.call_lin.bwd_data(self.dy, None, self.kernel.data, out=self.dx)
 
     def k_bwd_data(self):
         if self.relu and not self.diag_mask_in_bwd_data:
@@ -243,9 +264,10 @@ def pmc_traffic(workload, kernel):
 
 
 def event_time_ms(fn, stream, reps=20, rounds=5):
-    """Average duration of `fn`'s launches: `reps` back-to-back launches between two HIP events
-    recorded on the launch stream; best of `rounds`."""
-    best = None
+    """Duration of `fn`'s launches: `reps` back-to-back launches between two HIP events recorded on the launch
+    stream, `rounds` times.  Returns (mean over all rounds, best round) in ms per launch; the MEAN is what the
+    roofline fractions use."""
+    per = []
     for _ in range(rounds):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(stream)
@@ -253,12 +275,31 @@ def event_time_ms(fn, stream, reps=20, rounds=5):
             fn()
         e1.record(stream)
         e1.synchronize()
-        ms = e0.elapsed_time(e1) / reps
-        best = ms if best is None else min(best, ms)
-    return best
+        per.append(e0.elapsed_time(e1) / reps)
+    return sum(per) / len(per), min(per)
 
 
-def _cpu_pass_time(cfg, threads, seconds):
+def layer_kernel_times(workload, dev, reps=5, rounds=4):
+    """fwd / bwd_weight / bwd_data of one layer workload: {name: {ms (mean), ms_min, tflops, frac_of_peak, hbm_bytes}}."""
+    cfg = dict(WORKLOADS[workload], activation='relu')
+    job = LayerTrainStep(cfg, dev, 0, 1)
+    job.k_fwd(); job.k_bwd_weight(); job.k_bwd_data()
+    torch.cuda.synchronize()
+    stream = torch.cuda.current_stream(dev)
+    peak = PEAK_TFLOPS[cfg['dtype']]
+    out = {}
+    # fwd / bwd_weight / bwd_data: the layer on its own (relu mask applied in backward-weight, which also leaves the
+    # masked dy for backward-data); *_chain: the same kernels as they run inside the QCNN's conv chain
+    for name, fn in (('fwd', job.k_fwd), ('bwd_weight', job.k_bwd_weight), ('bwd_data', job.k_bwd_data),
+                     ('bwd_weight_chain', job.k_bwd_weight_chain), ('bwd_data_chain', job.k_bwd_data_chain)):
+        ms, ms_min = event_time_ms(fn, stream, reps=reps, rounds=rounds)
+        tf = job.flops_per_kernel / (ms * 1e-3) / 1e12
+        out[name] = {'ms': ms, 'ms_min': ms_min, 'tflops': tf, 'frac_of_peak': tf / peak,
+                     'hbm_bytes': pmc_traffic(workload, name)}
+    return out, job
+
+
+def _cpu_layer_pass_time(cfg, threads, seconds):
     from oracle import ref_port
     from qcnn_amd.complexnn.init import qconv_init
     torch.set_num_threads(threads)
@@ -285,84 +326,69 @@ def _cpu_pass_time(cfg, threads, seconds):
     return 1e3 * t_total / n, n
 
 
+def _cpu_model_pass_time(cfg, threads, seconds, batch):
+    from oracle import ref_model
+    torch.set_num_threads(threads)
+    torch.manual_seed(0)
+    p = ref_model.init_params(cfg['layers'], cfg['sf'], seed=0, dtype=torch.float32, prelu=cfg.get('aact') == 'prelu')
+    x = torch.randn(batch, 4, 41, cfg['frames'])
+    target = torch.randn(batch, cfg['frames'], 62)
+    leaves = ref_model.leaves(p)
+    n, t_total = 0, 0.0
+    for it in range(100):
+        t0 = time.perf_counter()
+        pred = ref_model.timit_forward(x, p, 'relu')
+        torch.autograd.grad((pred * target).sum(), leaves)
+        dt = time.perf_counter() - t0
+        if it >= 1:            # one warm-up pass
+            n += 1
+            t_total += dt
+            if t_total >= seconds or n >= 50:
+                break
+    return 1e3 * t_total / n, n
+
+
 def cpu_baseline(cfg, seconds):
-    """The reference's per-step CPU op sequence (expand kernel by concat -> one real conv ->
-    bias -> relu; autograd backward) on this host's cores, fp32, bounded to ~`seconds` in total.
-    oneDNN does not scale this small problem to hundreds of threads, so a few thread counts are
-    tried and the best is reported (`cores` = the thread count that produced `value`)."""
+    """The reference's per-step CPU op sequence (expand kernel by concat -> one real conv / matmul -> bias ->
+    activation; autograd backward) on this host's cores, fp32, bounded to ~`seconds` in total, for the SAME workload:
+    the single layer (oracle/ref_port.py) or the full TIMIT model on a small batch (oracle/ref_model.py).  oneDNN
+    does not scale these problems to hundreds of threads, so a few thread counts are tried and the best is reported
+    (`cores` = the thread count that produced `value`).  No optimizer step (negligible on the CPU side)."""
     ncpu = os.cpu_count() or 1
-    tries = sorted({min(ncpu, t) for t in (8, 32, 64, ncpu)})
+    is_model = cfg.get('kind') == 'model'
+    tries = sorted({min(ncpu, t) for t in ((16, 64) if is_model else (8, 32, 64, ncpu))})
+    sample_b = 4 if is_model else cfg['batch']
     best = None
     for th in tries:
-        ms, n = _cpu_pass_time(cfg, th, seconds / len(tries))
+        if is_model:
+            ms, n = _cpu_model_pass_time(cfg, th, seconds / len(tries), sample_b)
+        else:
+            ms, n = _cpu_layer_pass_time(cfg, th, seconds / len(tries))
         if best is None or ms < best[0]:
             best = (ms, n, th)
     ms, n, th = best
-    B = cfg['batch']
-    return {'value': B / (ms * 1e-3), 'unit': 'samples/s', 'cores': th, 'kind': 'port',
-            'ms_per_step': ms, 'host_cpus': ncpu, 'threads_tried': tries,
-            'sample': '%d timed fwd+bwd passes of the same workload (batch %d) through the reference op '
-                      'sequence (oracle/ref_port.py) on torch-CPU/oneDNN, fp32, no optimizer step' % (n, B)}
+    what = ('the full TIMIT QCNN (n=%d, sf=%d, %d frames) through oracle/ref_model.py' % (cfg['layers'], cfg['sf'], cfg['frames'])
+            if is_model else 'the same layer through oracle/ref_port.py')
+    return {'value': sample_b / (ms * 1e-3), 'unit': 'samples/s', 'cores': th, 'kind': 'port',
+            'ms_per_step': ms, 'host_cpus': ncpu, 'threads_tried': tries, 'sample_batch': sample_b,
+            'sample': '%d timed fwd+bwd passes of %s (reference op sequence, torch-CPU/oneDNN, fp32, batch %d, '
+                      'no optimizer step)' % (n, what, sample_b)}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=300)
-    ap.add_argument('--warmup', type=int, default=30)
-    ap.add_argument('--workload', default='cfg2_qconv1d_timit_b64_fp32', choices=sorted(WORKLOADS))
-    ap.add_argument('--cpu-seconds', type=float, default=12.0)
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-kernel-timing', action='store_true')
-    ap.add_argument('--graph', action='store_true',
-                    help='replay the step as a hipGraph (measured 3 %% SLOWER than eager back-to-back launches here: '
-                         '0.159 vs 0.154 ms -- the GPU is never starved and a replay has a fixed cost)')
-    ap.add_argument('--no-graph', action='store_true', help=argparse.SUPPRESS)
-    ap.add_argument('--graph-multi', action='store_true',
-                    help='with --graph and N > 1: hipGraph segments around the RCCL all-reduce')
-    ap.add_argument('--no-hamilton-gemm', action='store_true',
-                    help='skip the extra kernel timing of the batch-256 bf16 Hamilton GEMM (config-3 body conv)')
-    ap.add_argument('--activation', default='relu', choices=['relu', 'linear'], help='diagnostic: linear drops the relu mask')
-    args = ap.parse_args()
+DEFAULT_WORKLOAD = 'cfg3_qcnn_timit_b256_bf16'
+# (kernel, launches per QCNN step) of the three conv shapes: used to name the kernel with the largest share of a step
+QCNN_LAYER_COUNTS = {'cfg3_body_qconv2d_b256_bf16': 4, 'cfg3_stage1_qconv2d_b256_bf16': 5, 'cfg3_32to64_qconv2d_b256_bf16': 1}
 
-    import qcnn_amd  # noqa: F401  (fails loudly if libqk_hip.so is missing)
-    from qcnn_amd import dp
-    import torch.distributed as dist
 
-    rank, world, local = dp.init_from_env()
-    if world != args.gpus:
-        if rank == 0:
-            sys.stderr.write('warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE\n' % (args.gpus, world))
-    assert torch.cuda.is_available(), 'bench.py needs a GPU'
-    dev = torch.device('cuda', local)
-    torch.cuda.set_device(dev)
-    cfg = dict(WORKLOADS[args.workload], activation=args.activation)
-    is_model = cfg.get('kind') == 'model'
-    job = ModelTrainStep(cfg, dev, rank, world) if is_model else LayerTrainStep(cfg, dev, rank, world)
-
-    def barrier():
-        if world > 1 or dist.is_initialized():
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    use_graph = args.graph and not args.no_graph and (world == 1 or args.graph_multi) and not is_model
-    if use_graph:
-        try:
-            job.step()
-            job.capture()
-        except Exception as e:          # keep the bench alive; the JSON says which mode ran
-            sys.stderr.write('hipGraph capture failed (%s); running eager\n' % (e,))
-            use_graph = False
-    # one-off initialisation outside the contract's W warm-up steps: first launches load the code objects,
-    # size the workspaces and settle the allocator (not part of any step)
-    for _ in range(8 if not is_model else 1):
+def timed_steps(job, steps, warmup, pre, barrier, world, dev, dist):
+    for _ in range(pre):
         job.step()
     torch.cuda.synchronize()
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         job.step()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         job.step()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -370,13 +396,68 @@ def main():
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    ms_per_step = 1e3 * elapsed / args.steps
-    samples_per_s = world * cfg['batch'] * args.steps / elapsed
+    return elapsed
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=None, help='timed steps (default: 100 for the QCNN, 300 for a layer)')
+    ap.add_argument('--warmup', type=int, default=None, help='untimed warm-up steps (default: 10 / 30)')
+    ap.add_argument('--workload', default=DEFAULT_WORKLOAD, choices=sorted(WORKLOADS))
+    ap.add_argument('--cpu-seconds', type=float, default=16.0)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-timing', action='store_true')
+    ap.add_argument('--no-extras', action='store_true', help='skip the cfg2_layer / layer_kernels blocks of the default line')
+    ap.add_argument('--graph', action='store_true',
+                    help='layer workloads: replay the step as a hipGraph (measured 3 %% SLOWER than eager back-to-back '
+                         'launches: 0.159 vs 0.154 ms -- the GPU is never starved and a replay has a fixed cost)')
+    ap.add_argument('--graph-multi', action='store_true',
+                    help='with --graph and N > 1: hipGraph segments around the RCCL all-reduce')
+    ap.add_argument('--no-hamilton-gemm', action='store_true', help='skip the batch-256 bf16 Hamilton GEMM kernel timing')
+    ap.add_argument('--activation', default='relu', choices=['relu', 'linear'], help='layer workloads, diagnostic: linear drops the relu mask')
+    args = ap.parse_args()
+
+    import qcnn_amd  # noqa: F401  (fails loudly if libqk_hip.so is missing)
+    from qcnn_amd import dp
+    import torch.distributed as dist
+
+    rank, world, local = dp.init_from_env()
+    if world != args.gpus and rank == 0:
+        sys.stderr.write('warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE\n' % (args.gpus, world))
+    assert torch.cuda.is_available(), 'bench.py needs a GPU'
+    dev = torch.device('cuda', local)
+    torch.cuda.set_device(dev)
+    cfg = dict(WORKLOADS[args.workload], activation=args.activation)
+    is_model = cfg.get('kind') == 'model'
+    steps = args.steps if args.steps is not None else (100 if is_model else 300)
+    warmup = args.warmup if args.warmup is not None else (10 if is_model else 30)
+    job = ModelTrainStep(cfg, dev, rank, world) if is_model else LayerTrainStep(cfg, dev, rank, world)
+
+    def barrier():
+        if world > 1 or dist.is_initialized():
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    use_graph = args.graph and (world == 1 or args.graph_multi) and not is_model
+    if use_graph:
+        try:
+            job.step()
+            job.capture()
+        except Exception as e:          # keep the bench alive; the JSON says which mode ran
+            sys.stderr.write('hipGraph capture failed (%s); running eager\n' % (e,))
+            use_graph = False
+    # `pre_warmup_steps`: one-off initialisation in front of the contract's W warm-up steps -- the first launches load
+    # the code objects, size the workspaces and settle the allocator.  Reported in the JSON; never timed.
+    pre = 2 if is_model else 8
+    elapsed = timed_steps(job, steps, warmup, pre, barrier, world, dev, dist)
+    ms_per_step = 1e3 * elapsed / steps
+    samples_per_s = world * cfg['batch'] * steps / elapsed
 
     out = {
-        'metric': 'quaternion-conv samples/sec (fwd+bwd+Adam of %s)' % ('the full TIMIT QCNN' if is_model else 'one QuaternionConv layer'),
-        'value': samples_per_s, 'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps,
-        'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True,
+        'metric': 'quaternion-conv samples/sec (fwd+bwd+Adam of %s)' % ('the full TIMIT QCNN, per-GPU batch %d' % cfg['batch'] if is_model else 'one QuaternionConv layer'),
+        'value': samples_per_s, 'unit': 'samples/s', 'n_gpus': world, 'steps': steps,
+        'warmup': warmup, 'pre_warmup_steps': pre, 'ms_per_step': ms_per_step, 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': cfg['dtype'], 'data': 'synthetic',
         'config': {'workload': args.workload, 'per_gpu_batch': cfg['batch'],
                    'global_batch': cfg['batch'] * world, 'input': list(job.x.shape),
@@ -384,59 +465,92 @@ def main():
                    'activation': cfg['activation'], 'gemm_view': job.gemm, 'parallelism': 'dp%d' % world,
                    'optimizer': 'adam(5e-4)', 'launch': 'hipgraph' if use_graph else 'eager'},
     }
+    peak = PEAK_TFLOPS[cfg['dtype']]
+    stream = torch.cuda.current_stream(dev)
+    timing = rank == 0 and world == 1 and not args.no_kernel_timing
 
     if rank == 0 and is_model:
-        peak = PEAK_TFLOPS[cfg['dtype']]
         tf = 3 * job.flops_per_kernel / (ms_per_step * 1e-3) / 1e12
-        out['roofline'] = {'bound': 'mfma', 'kernel': 'whole step: quaternion layers, 2MNK fwd + 4MNK bwd', 'achieved': tf,
-                           'peak': peak, 'unit': 'TFLOP/s', 'frac': tf / peak, 'traffic': None,
-                           'flops_per_launch': 3 * job.flops_per_kernel, 'avg_launch_ms': ms_per_step}
+        out['qcnn_step'] = {'ms_per_step': ms_per_step, 'tflops': tf, 'frac_of_peak': tf / peak,
+                            'flops_per_step': 3 * job.flops_per_kernel,
+                            'note': 'algorithmic 2MNK fwd + 4MNK bwd of the quaternion layers / whole-step wall time'}
         out['step_tflops'] = tf
-    if rank == 0 and not args.no_kernel_timing and not is_model:
-        stream = torch.cuda.current_stream(dev)
+    if timing and is_model:
+        # free the model's activations before the layer-level timing runs
+        model_job, job = job, None
+        del model_job
+        torch.cuda.empty_cache()
+        try:
+            hk, hjob = layer_kernel_times('cfg3_body_qconv2d_b256_bf16', dev)
+            out['hamilton_gemm'] = {'workload': 'cfg3_body_qconv2d_b256_bf16', 'gemm_view': hjob.gemm, 'dtype': 'bf16',
+                                    'peak_tflops': PEAK_TFLOPS['bf16'], 'kernels': hk,
+                                    'timing': 'mean of 4 rounds x 5 back-to-back launches (HIP events on the launch stream)'}
+            flops = hjob.flops_per_kernel
+            del hjob
+            in_step = ('fwd', 'bwd_weight_chain', 'bwd_data_chain')      # the forms the QCNN step launches
+            share = {('cfg3_body_qconv2d_b256_bf16', k): hk[k]['ms'] * QCNN_LAYER_COUNTS['cfg3_body_qconv2d_b256_bf16'] for k in in_step}
+            if not args.no_extras:
+                out['layer_kernels'] = {}
+                for wl in ('cfg3_stage1_qconv2d_b256_bf16', 'cfg3_32to64_qconv2d_b256_bf16'):
+                    lk, ljob = layer_kernel_times(wl, dev)
+                    out['layer_kernels'][wl] = {'gemm_view': ljob.gemm, 'kernels': lk}
+                    del ljob
+                    share.update({(wl, k): lk[k]['ms'] * QCNN_LAYER_COUNTS[wl] for k in in_step})
+            (dwl, dom) = max(share, key=share.get)
+            kern = hk[dom] if dwl == 'cfg3_body_qconv2d_b256_bf16' else out['layer_kernels'][dwl]['kernels'][dom]
+            dflops = flops if dwl == 'cfg3_body_qconv2d_b256_bf16' else LayerFlops(dwl)
+            out['roofline'] = {'bound': 'mfma', 'kernel': '%s of %s (largest share of the step: %d launches x %.3f ms)'
+                                                       % (dom, dwl, QCNN_LAYER_COUNTS[dwl], kern['ms']),
+                               'achieved': kern['tflops'], 'peak': PEAK_TFLOPS['bf16'], 'unit': 'TFLOP/s',
+                               'frac': kern['tflops'] / PEAK_TFLOPS['bf16'], 'traffic': kern['hbm_bytes'],
+                               'flops_per_launch': dflops, 'avg_launch_ms': kern['ms']}
+        except Exception as e:
+            out['hamilton_gemm'] = {'error': repr(e)}
+        if not args.no_extras:
+            try:        # BASELINE configs[1]: the single QuaternionConv1D layer, step + kernels
+                c2 = dict(WORKLOADS['cfg2_qconv1d_timit_b64_fp32'], activation='relu')
+                j2 = LayerTrainStep(c2, dev, 0, 1)
+                el = timed_steps(j2, 300, 30, 8, barrier, 1, dev, dist)
+                k2 = {}
+                for name, fn in (('fwd', j2.k_fwd), ('bwd_weight', j2.k_bwd_weight), ('bwd_data', j2.k_bwd_data)):
+                    ms, ms_min = event_time_ms(fn, stream)
+                    tf = j2.flops_per_kernel / (ms * 1e-3) / 1e12
+                    k2[name] = {'ms': ms, 'ms_min': ms_min, 'tflops': tf, 'frac_of_peak': tf / PEAK_TFLOPS['fp32'],
+                                'hbm_bytes': pmc_traffic('cfg2_qconv1d_timit_b64_fp32', name)}
+                out['cfg2_layer'] = {'workload': 'cfg2_qconv1d_timit_b64_fp32', 'dtype': 'fp32', 'gemm_view': j2.gemm,
+                                     'steps': 300, 'warmup': 30, 'pre_warmup_steps': 8, 'ms_per_step': 1e3 * el / 300,
+                                     'samples_per_s': c2['batch'] * 300 / el, 'peak_tflops': PEAK_TFLOPS['fp32'], 'kernels': k2}
+                del j2
+            except Exception as e:
+                out['cfg2_layer'] = {'error': repr(e)}
+    if timing and not is_model:
         kernels = {}
         for name, fn in (('fwd', job.k_fwd), ('bwd_weight', job.k_bwd_weight), ('bwd_data', job.k_bwd_data)):
-            ms = event_time_ms(fn, stream)
-            kernels[name] = {'ms': ms, 'tflops': job.flops_per_kernel / (ms * 1e-3) / 1e12}
+            ms, ms_min = event_time_ms(fn, stream)
+            tf = job.flops_per_kernel / (ms * 1e-3) / 1e12
+            kernels[name] = {'ms': ms, 'ms_min': ms_min, 'tflops': tf, 'frac_of_peak': tf / peak,
+                             'hbm_bytes': pmc_traffic(args.workload, name)}
         dom = max(kernels, key=lambda k: kernels[k]['ms'])
-        peak = PEAK_TFLOPS[cfg['dtype']]
         out['roofline'] = {'bound': 'mfma', 'kernel': dom, 'achieved': kernels[dom]['tflops'], 'peak': peak,
                            'unit': 'TFLOP/s', 'frac': kernels[dom]['tflops'] / peak,
-                           'traffic': pmc_traffic(args.workload, dom),
+                           'traffic': kernels[dom]['hbm_bytes'],
                            'flops_per_launch': job.flops_per_kernel, 'avg_launch_ms': kernels[dom]['ms']}
         out['kernels'] = kernels
-        step_flops = 3 * job.flops_per_kernel
-        out['step_tflops'] = step_flops / (ms_per_step * 1e-3) / 1e12
-    # The "% of MFMA peak on the Hamilton GEMM at batch 256" half of BASELINE.json's metric: the
-    # config-3 stage-2 body conv (M=716800, N=256, K=3840, bf16), kernels timed with HIP events.
-    if rank == 0 and world == 1 and not is_model and not args.no_hamilton_gemm and not args.no_kernel_timing \
-            and args.workload == 'cfg2_qconv1d_timit_b64_fp32':
-        try:
-            hcfg = dict(WORKLOADS['cfg3_body_qconv2d_b256_bf16'], activation='relu')
-            hjob = LayerTrainStep(hcfg, dev, 0, 1)
-            hjob.k_fwd(); hjob.k_bwd_weight(); hjob.k_bwd_data()
-            torch.cuda.synchronize()
-            stream = torch.cuda.current_stream(dev)
-            hk = {}
-            for name, fn in (('fwd', hjob.k_fwd), ('bwd_weight', hjob.k_bwd_weight), ('bwd_data', hjob.k_bwd_data)):
-                ms = event_time_ms(fn, stream, reps=5, rounds=3)
-                tf = hjob.flops_per_kernel / (ms * 1e-3) / 1e12
-                hk[name] = {'ms': ms, 'tflops': tf, 'frac_of_peak': tf / PEAK_TFLOPS['bf16'],
-                            'hbm_bytes': pmc_traffic('cfg3_body_qconv2d_b256_bf16', name)}
-            out['hamilton_gemm'] = {'workload': 'cfg3_body_qconv2d_b256_bf16', 'gemm_view': hjob.gemm, 'dtype': 'bf16',
-                                    'peak_tflops': PEAK_TFLOPS['bf16'], 'kernels': hk}
-            del hjob
-        except Exception as e:
-            out['hamilton_gemm'] = {'error': str(e)}
+        out['step_tflops'] = 3 * job.flops_per_kernel / (ms_per_step * 1e-3) / 1e12
     if world > 1:
         dist.barrier()
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and not is_model:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(cfg, args.cpu_seconds)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def LayerFlops(workload):
+    c = WORKLOADS[workload]
+    return 2.0 * c['batch'] * int(np.prod(c['spatial'])) * 4 * c['filters'] * int(np.prod(c['kernel'])) * 4 * c['cq']
 
 
 if __name__ == '__main__':

@@ -96,6 +96,80 @@ def allreduce_sum_(tensor, group=None, async_op=False):
     return dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
 
 
+class BucketedAllReduce(object):
+    """Gradient all-reduce in buckets, launched WHILE the backward pass is still running.
+
+    The flat gradient buffer of `FlatParams` is cut into contiguous buckets of at least `bucket_bytes`
+    (parameters in creation order; the backward produces their gradients roughly in reverse).  A
+    post-accumulate hook on every parameter counts its bucket down; the moment a bucket is complete its
+    slice of the flat buffer goes out as one asynchronous sum all-reduce (RCCL on the process group's own
+    stream, overlapping the remaining backward kernels).  `finish()` waits for every bucket -- call it before
+    the optimiser step.  For the 6.7 MB TIMIT model this is 4-7 messages; for the 145 MB config-5 stack one
+    message per 15.7 MB layer, each hidden behind the next layer's 100+ ms of backward.
+    Single-process runs (no process group) do nothing unless QK_DP_FORCE_COLLECTIVES is set."""
+
+    def __init__(self, flat, bucket_bytes=1 << 20, group=None):
+        self.flat, self.group = flat, group
+        self.active = dist.is_initialized() and (dist.get_world_size(group) > 1 or _FORCE)
+        self.buckets = []                 # [lo, hi) element ranges of the flat buffer
+        self.bucket_of = {}               # id(param) -> bucket index
+        self.sizes = []                   # parameters per bucket
+        lo, cur = 0, []
+        for p, off in zip(flat.params, flat.offsets):
+            cur.append(p)
+            hi = off + (p.numel() + 63) // 64 * 64
+            if (hi - lo) * 4 >= bucket_bytes:
+                self._close(lo, hi, cur)
+                lo, cur = hi, []
+        if cur:
+            self._close(lo, flat.numel, cur)
+        self.pending = list(self.sizes)
+        self.works = []
+        self.launch_order = []
+        self.handles = []
+        if self.active:
+            for p in flat.params:
+                if p.requires_grad:
+                    self.handles.append(p.register_post_accumulate_grad_hook(self._hook))
+
+    def _close(self, lo, hi, params):
+        b = len(self.buckets)
+        self.buckets.append((lo, hi))
+        n = 0
+        for p in params:
+            self.bucket_of[id(p)] = b
+            n += bool(p.requires_grad)
+        self.sizes.append(n)
+
+    def _hook(self, p):
+        b = self.bucket_of[id(p)]
+        self.pending[b] -= 1
+        if self.pending[b] == 0:
+            self._launch(b)
+
+    def _launch(self, b):
+        lo, hi = self.buckets[b]
+        self.launch_order.append(b)
+        self.works.append(dist.all_reduce(self.flat.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self):
+        """Launch whatever never fired (parameters without a gradient this step), wait for all buckets."""
+        if not self.active:
+            return
+        for b, left in enumerate(self.pending):
+            if left > 0 or (self.sizes[b] == 0 and b not in self.launch_order):
+                self._launch(b)
+        for w in self.works:
+            w.wait()
+        self.works, self.launch_order = [], []
+        self.pending = list(self.sizes)
+
+    def remove(self):
+        for h in self.handles:
+            h.remove()
+        self.handles = []
+
+
 def world_size(group=None):
     return dist.get_world_size(group) if dist.is_initialized() else 1
 

@@ -88,7 +88,8 @@ def test_bench_step_through_one_rank_rccl_group():
     """The 1-GPU test box cannot form a 2-rank RCCL group (one device), so the exact calls of the
     multi-GPU bench -- torchrun env, nccl process group with device_id, async all-reduce overlapping
     backward-data, barrier, MAX-reduce of the elapsed time -- run here with a one-rank communicator
-    (QK_DP_FORCE_COLLECTIVES, qcnn_amd/dp.py)."""
+    (QK_DP_FORCE_COLLECTIVES, qcnn_amd/dp.py).  The default workload is the full TIMIT QCNN step: its gradients go
+    out as bucketed all-reduces launched from autograd hooks during the backward."""
     import json
     import subprocess
     import sys
@@ -102,10 +103,64 @@ def test_bench_step_through_one_rank_rccl_group():
     env = dict(os.environ, QK_DP_FORCE_COLLECTIVES='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1',
            '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.join(root, 'bench.py'),
-           '--gpus', '1', '--steps', '20', '--warmup', '3', '--no-cpu-baseline', '--no-hamilton-gemm',
-           '--no-kernel-timing']
+           '--gpus', '1', '--steps', '10', '--warmup', '2', '--no-cpu-baseline', '--no-kernel-timing']
     out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1]
     rec = json.loads(line)
     assert rec['n_gpus'] == 1 and rec['value'] > 0 and rec['config']['launch'] == 'eager'
+    assert rec['config']['workload'] == 'cfg3_qcnn_timit_b256_bf16' and rec['config']['gemm_view']['allreduce_buckets'] >= 3
+    assert rec['pre_warmup_steps'] == 2 and rec['steps'] == 10
+
+
+def _bucket_worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    from qcnn_amd import dp
+    dp.init_from_env(backend='gloo')
+    torch.manual_seed(0)                                   # identical replicas
+    net = torch.nn.Sequential(torch.nn.Linear(20, 300), torch.nn.ReLU(), torch.nn.Linear(300, 300), torch.nn.ReLU(),
+                              torch.nn.Linear(300, 7))
+    frozen = net[2].bias
+    frozen.requires_grad_(False)                           # a parameter that never gets a gradient
+    flat = dp.FlatParams(list(net.parameters()))
+    dp.broadcast_params(flat)
+    red = dp.BucketedAllReduce(flat, bucket_bytes=16 * 1024)
+    assert red.active and len(red.buckets) >= 3 and red.buckets[0][0] == 0 and red.buckets[-1][1] == flat.numel
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(12, 20, generator=g)
+    y = torch.randn(12, 7, generator=g)
+    lo, hi = dp.shard_rows(12, rank, world)
+    for step in range(2):                                  # twice: the counters must re-arm
+        flat.zero_grad()
+        loss = ((net(x[lo:hi]) - y[lo:hi]) ** 2).sum()
+        loss.backward()                                    # hooks launch the buckets as their gradients complete
+        order = list(red.launch_order)
+        red.finish()
+        assert sorted(order) == order[::-1] or len(order) <= 1 or order[0] > order[-1], order   # last layers first
+    np.save(os.path.join(out_dir, 'bgrad_%d.npy' % rank), flat.grad.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_overlapping_backward_equals_full_batch_gradient(tmp_path):
+    """dp.BucketedAllReduce: per-bucket asynchronous all-reduces fired from autograd hooks while the backward is
+    still running; the reduced flat gradient must equal the single-process gradient of the whole batch."""
+    world, port = 2, _free_port()
+    mp.spawn(_bucket_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    from qcnn_amd import dp
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(20, 300), torch.nn.ReLU(), torch.nn.Linear(300, 300), torch.nn.ReLU(),
+                              torch.nn.Linear(300, 7))
+    net[2].bias.requires_grad_(False)
+    flat = dp.FlatParams(list(net.parameters()))
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(12, 20, generator=g)
+    y = torch.randn(12, 7, generator=g)
+    ((net(x) - y) ** 2).sum().backward()
+    want = flat.grad.numpy()
+    g0, g1 = np.load(tmp_path / 'bgrad_0.npy'), np.load(tmp_path / 'bgrad_1.npy')
+    assert np.array_equal(g0, g1)
+    assert np.abs(g0 - want).max() <= 1e-5 * np.abs(want).max()
+    red = dp.BucketedAllReduce(flat)                       # no process group here: inert
+    assert not red.active and red.finish() is None

@@ -131,55 +131,33 @@ def test_prelu_shapes_on_cpu():
 
 def test_numpy_model_composition_agrees_with_torch_autograd_on_cpu():
     """The float64 composition the GPU tests compare against, checked here against torch autograd through the
-    reference op sequence (oracle/ref_port.py): two independent restatements of the same model."""
+    reference op sequence (oracle/ref_model.py on oracle/ref_port.py): two independent restatements of the model."""
     import types
-    from oracle import ref_port
+    from oracle import ref_model
     rng = np.random.RandomState(0)
     n, sf, bsz, t = 2, 2, 2, 7
-    widths = [sf] * (n // 2) + [2 * sf] * (n // 2)
-    P = lambda *s: torch.tensor(rng.randn(*s) / np.sqrt(max(np.prod(s[:-1]), 1)), dtype=torch.float64, requires_grad=True)
-    conv = (P(3, 5, 1, 4 * sf), P(4 * sf))
-    convs, cin = [], sf
-    for w in widths:
-        convs.append((P(3, 5, cin, 4 * w), P(4 * w)))
-        cin = w
-    dense = [(P(14 * cin, 16), P(16)), (P(4, 16), P(16)), (P(4, 16), P(16))]
-    pred = (P(16, 5), P(5))
-    a_shapes = [(1, 41, 1)] + [(1, 14, 1)] * n + [(1, 1)] * 3
-    alphas = [torch.tensor(0.05 + 0.3 * rng.rand(*s), dtype=torch.float64, requires_grad=True) for s in a_shapes]
     x = torch.tensor(rng.randn(bsz, 4, 41, t), dtype=torch.float64, requires_grad=True)
-    dpred = rng.randn(bsz, t, 5)
+    dpred = rng.randn(bsz, t, 62)
     for use_prelu in (False, True):
-        act = None if use_prelu else 'relu'
-        pl = (lambda h, k: torch.relu(h) - alphas[k] * torch.relu(-h)) if use_prelu else (lambda h, k: h)
-        kw = dict(padding='same', data_format='channels_first', activation=act)
-        h = pl(ref_port.conv_forward(x, conv[0], conv[1], 2, **kw), 0)
-        h = torch.nn.functional.max_pool2d(h, (3, 1), (3, 1), ceil_mode=True)
-        for i, (w, b) in enumerate(convs):
-            h = pl(ref_port.conv_forward(h, w, b, 2, **kw), 1 + i)
-        h = h.permute(0, 3, 1, 2).reshape(bsz, t, -1)
-        for i, (w, b) in enumerate(dense):
-            h = pl(ref_port.dense_forward(h.reshape(bsz * t, -1), w, b, activation=act).reshape(bsz, t, -1), 1 + n + i)
-        p = torch.softmax(h @ pred[0] + pred[1], dim=-1)
-        leaves = [x, conv[0], conv[1]] + [t_ for wb in convs for t_ in wb] + [t_ for wb in dense for t_ in wb] + list(pred)
-        if use_prelu:
-            leaves += alphas
-        grads = torch.autograd.grad((p * torch.tensor(dpred)).sum(), leaves)
-        # the same model through the numpy composition
+        p = ref_model.init_params(n, sf, seed=1, dtype=torch.float64, prelu=use_prelu)
+        pred = ref_model.timit_forward(x, p, 'relu')
+        lv = [x] + ref_model.leaves(p)
+        grads = torch.autograd.grad((pred * torch.tensor(dpred)).sum(), lv)
         fake = types.SimpleNamespace(
-            conv=types.SimpleNamespace(kernel=conv[0], bias=conv[1]),
-            convs=[types.SimpleNamespace(kernel=w, bias=b) for w, b in convs],
-            dense=[types.SimpleNamespace(layer=types.SimpleNamespace(r=w, bias=b)) for w, b in dense],
-            pred=types.SimpleNamespace(layer=types.SimpleNamespace(kernel=pred[0], bias=pred[1])),
-            prelu=[types.SimpleNamespace(alpha=a) for a in alphas] if use_prelu else None)
+            conv=types.SimpleNamespace(kernel=p['conv'][0], bias=p['conv'][1]),
+            convs=[types.SimpleNamespace(kernel=w, bias=b) for w, b in p['convs']],
+            dense=[types.SimpleNamespace(layer=types.SimpleNamespace(r=w, bias=b)) for w, b in p['dense']],
+            pred=types.SimpleNamespace(layer=types.SimpleNamespace(kernel=p['pred'][0], bias=p['pred'][1])),
+            prelu=[types.SimpleNamespace(alpha=a) for a in p['alphas']] if use_prelu else None)
         ref = TimitRef(fake, act='relu')
         want = ref.forward(x.detach().numpy())
-        assert np.abs(want - p.detach().numpy()).max() <= 1e-12
+        assert np.abs(want - pred.detach().numpy()).max() <= 1e-12
         g = ref.backward(dpred)
-        names = ['x', 'conv.kernel', 'conv.bias'] + [s % i for i in range(n) for s in ('conv%d.kernel', 'conv%d.bias')] \
-            + [s % i for i in range(3) for s in ('dense%d.r', 'dense%d.bias')] + ['pred.kernel', 'pred.bias']
+        names = ['x', 'conv.kernel', 'conv.bias'] + [s_ % i for i in range(n) for s_ in ('conv%d.kernel', 'conv%d.bias')] \
+            + [s_ % i for i in range(3) for s_ in ('dense%d.r', 'dense%d.bias')] + ['pred.kernel', 'pred.bias']
         if use_prelu:
-            names += ['alpha%d' % i for i in range(len(alphas))]
+            names += ['alpha%d' % i for i in range(len(p['alphas']))]
+        assert len(names) == len(grads)
         for name, tg in zip(names, grads):
             assert np.abs(g[name] - tg.numpy()).max() <= 1e-10 * max(1.0, float(tg.abs().max())), name
 
