@@ -113,12 +113,14 @@ const char *qk_last_error(void);
  *   QK_DBG_NO_BAND16/32     no band variants of the forward / backward-data kernels
  *   QK_DBG_WGRAD16_ONE_TAP  16-bit backward-weight: one tap per block for 32-channel layers
  *   QK_DBG_BAND16_8WAVES    16-bit band kernels in their 8-wave form (env QK_BAND16_8WAVES)
+ *   QK_DBG_NO_WGRAD_BAND    16-bit backward-weight without the band kernel (env QK_NO_WGRAD_BAND)
  *   bits 8..15              kernel ablation for profiling (skip the MFMA loop / epilogue / atomics): WRONG RESULTS
  * qk_set_debug_flags returns the previous mask. */
 #define QK_DBG_NO_MFMA16 1u
 #define QK_DBG_NO_BAND16 2u
 #define QK_DBG_NO_BAND32 4u
 #define QK_DBG_WGRAD16_ONE_TAP 8u
+#define QK_DBG_NO_WGRAD_BAND 32u   /* 16-bit backward-weight: one block per tap (k_wgrad16) instead of the band kernel */
 #define QK_DBG_BAND16_8WAVES 16u   /* 16-bit band kernels: 8-wave workgroups (one per CU) instead of 4-wave (two per CU) */
 unsigned qk_set_debug_flags(unsigned flags);
 unsigned qk_get_debug_flags(void);

@@ -24,6 +24,7 @@ unsigned env_flags()
     if (getenv("QK_NO_BAND32")) f |= kDbgNoBand32;
     if (getenv("QK_WGRAD16_ONE_TAP")) f |= kDbgWgradOneTap;
     if (getenv("QK_BAND16_8WAVES")) f |= kDbgBand8Waves;
+    if (getenv("QK_NO_WGRAD_BAND")) f |= kDbgNoWgradBand;
     if (const char *ab = getenv("QK_ABLATE")) f |= ((unsigned)atoi(ab) << kDbgAblateShift) & kDbgAblateMask;
     return f;
 }
@@ -82,6 +83,9 @@ int try_hgemm_16(int dtype, const void *in, const void *mask, const float *w_f32
                  void *out, const GemmGeom &g, bool w_is_transposed, void *ws, size_t ws_bytes,
                  hipStream_t stream);
 
+// 16-bit-input MFMA backward-weight, band form (qk_wgrad_band_bf16mfma.hip); returns 1 when it took the call
+int try_wgrad_band_16(int dtype, const void *x, const void *dy, const void *ymask, float *dw, float *dbias,
+                      const WgradGeom &g, hipStream_t stream);
 // 16-bit-input MFMA backward-weight (qk_wgrad_bf16mfma.hip); returns 1 when it took the call
 int try_wgrad_16(int dtype, const void *x, const void *dy, const void *ymask, float *dw, float *dbias,
                  const WgradGeom &g, hipStream_t stream);
@@ -315,7 +319,8 @@ int conv_bwd_weight_impl(const qk_conv_desc_t *d, const void *x, const void *dy,
         if (g.want_dbias && hipMemsetAsync(dbias, 0, dbb, stream) != hipSuccess) { set_error("memset dbias failed"); return QK_ERR_LAUNCH; }
     }
     if (d->dtype != QK_F32) {
-        const int r = try_wgrad_16(d->dtype, x, dy, mask ? y : nullptr, dw, dbias, g, stream);
+        int r = try_wgrad_band_16(d->dtype, x, dy, mask ? y : nullptr, dw, dbias, g, stream);
+        if (r == 0) r = try_wgrad_16(d->dtype, x, dy, mask ? y : nullptr, dw, dbias, g, stream);
         if (r != 0) return r < 0 ? r : 0;
     }
     const bool vec = d->layout == QK_CH_LAST && d->cq % 4 == 0 && d->fq % 4 == 0 &&

@@ -116,6 +116,9 @@ struct WgradGeom {
     int n_splits;
     int ablate;         // profiling only (env QK_ABLATE): 1 = skip fold + atomics, 2 = skip HBM atomics
     unsigned x_bytes, dy_bytes;   // extents of x and of dy / y / dym (buffer-resource bounds of the 16-bit kernel)
+    // band variant (qk_wgrad_band_bf16mfma.hip): positions run over padded lines of the innermost axis (b_wp per
+    // line, b_nlines lines); band row j of a tile holds input column (padded position + b_cshift)
+    int b_wp, b_nlines, b_cshift;
     void *dym;          // optional output: dy with the relu mask applied (same layout/dtype as dy), or NULL;
                         // written by the blocks of tap 0 / channel chunk 0, which see every (row, filter) once
 };
@@ -194,7 +197,7 @@ void note_path(int qk_path);          // thread-local record behind qk_last_path
 // other mutable global.  Not part of the compute contract: every combination computes the same values.
 enum : unsigned {
     kDbgNoMfma16 = QK_DBG_NO_MFMA16, kDbgNoBand16 = QK_DBG_NO_BAND16, kDbgNoBand32 = QK_DBG_NO_BAND32,
-    kDbgWgradOneTap = QK_DBG_WGRAD16_ONE_TAP, kDbgBand8Waves = QK_DBG_BAND16_8WAVES, kDbgAblateShift = 8, kDbgAblateMask = 0xffu << 8
+    kDbgWgradOneTap = QK_DBG_WGRAD16_ONE_TAP, kDbgBand8Waves = QK_DBG_BAND16_8WAVES, kDbgNoWgradBand = QK_DBG_NO_WGRAD_BAND, kDbgAblateShift = 8, kDbgAblateMask = 0xffu << 8
 };
 unsigned debug_flags();
 inline int debug_ablate() { return (int)((debug_flags() & kDbgAblateMask) >> kDbgAblateShift); }

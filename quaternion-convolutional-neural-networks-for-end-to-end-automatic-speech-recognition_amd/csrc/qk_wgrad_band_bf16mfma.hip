@@ -1,0 +1,417 @@
+// Backward-weight on the 16-bit-input matrix cores, BAND form: one block computes the kernel gradient of ALL
+// taps along the innermost spatial axis (KIN = 3 or 5) for one (outer tap, channel chunk, filter chunk).
+//
+//   dW[t0, t1, t, c, p, f] = sum_{a^b=p} sgn(a,b) * sum_P x_a[P + t, c] * dy_b[P, f]        t = 0 .. KIN-1
+//
+// k_wgrad16 (qk_wgrad_bf16mfma.hip) gives every tap its own block, so the X and dY tiles of a row range are staged
+// once PER TAP: 15 x (|x| + |dy|) through L2 and LDS for a (3,5) kernel -- its 32-channel instantiations are
+// LDS-bound (33 % of the MFMA peak) and the 64-channel one moves 1.3x the algorithmic HBM bytes.  Here the
+// reduction index P runs over PADDED lines of the innermost axis (out extent + KIN - 1 positions per line,
+// exactly as in k_hgemm16_band): then "input position of (P, inner tap t)" is simply "band row P + t", one staged
+// X band of KM + KIN - 1 rows serves all KIN taps, and the dY tile is staged once for them.  Padded positions
+// carry a zero dY row (buffer loads past the extent return zeros), so they contribute nothing.
+//
+// Block tile = KIN taps x (4 components x CQB channels) rows x (4 components x BF filters) columns of the EXPANDED
+// gradient = KIN x RTT x CT tiles of 32 x 32, ten per wave (160 accumulator registers):
+//   RTT = 2 (F % 64 == 0): CQB = 16 channels, BF = 64 filters;  wave = (row tile rt, component b = cg), 2 col tiles
+//   RTT = 4 (F % 32 == 0): CQB = 32 channels, BF = 32 filters;  wave = (component a = rt, column half),  2 col tiles
+// Per 16-deep step a wave reads KIN A fragments (one per tap: the same band, shifted by one row) and 2 B fragments
+// with ds_read_b64_tr_b16 and issues 2 KIN MFMAs.  Fold of the 16 (a,b) blocks onto the 4 compact parts, bias
+// gradient, masked-dY side output and the XCD-aware block order are those of k_wgrad16.
+#include "qk_common.h"
+
+namespace qk {
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef short v4s __attribute__((ext_vector_type(4)));
+typedef short v8s __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ floatx16 mfma16b(bf16, const v8s &a, const v8s &b, const floatx16 &c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ floatx16 mfma16b(f16, const v8s &a, const v8s &b, const floatx16 &c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+typedef __attribute__((address_space(3))) v4s lds_v4s;
+__device__ __forceinline__ v8s tr_frag8(const char *base, int pitch)
+{
+    const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s *)(base));
+    const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s *)(base + 4 * pitch));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned kOOR = 0xF0000000u;                  // > every extent try_wgrad_band_16 admits
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_of(const void *p, unsigned bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ uint4 bload16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void bstore16(const uint4 &d, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+    u32x4 v; v.x = d.x; v.y = d.y; v.z = d.z; v.w = d.w;
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)voff, (int)soff, 0);
+}
+typedef unsigned short u2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned keep2(unsigned v, unsigned m)       // see relu_keep2 in qk_wgrad_bf16mfma.hip
+{
+    const u2v one = __builtin_elementwise_min(__builtin_bit_cast(u2v, m), (u2v)(1));
+    return v & __builtin_bit_cast(unsigned, (u2v)(one * (u2v)(0xffff)));
+}
+
+template <typename T, int RTT, int KIN, bool MASK>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_wgrad16_band(const T *__restrict__ x, const T *__restrict__ dy, const T *__restrict__ ymask,
+               float *__restrict__ dw, float *__restrict__ dbias, const WgradGeom g)
+{
+    static_assert(RTT == 2 || RTT == 4, "row tiles per tap");
+    static_assert(KIN == 3 || KIN == 5, "inner taps");
+    constexpr int NTHR = 512, WCG = 8 / RTT, CTW = 2;
+    constexpr int CQB = RTT * 8, BF = WCG * CTW * 8;          // channels / filters per block
+    constexpr int KM = 64;                                     // positions per K step
+    constexpr int XROW = 4 * CQB * 2 + 64, DROW = 4 * BF * 2 + 64;   // (+64 B: transpose reads stay conflict free)
+    constexpr int XBUF = (KM + KIN - 1) * XROW, DBUF = KM * DROW, BUF = XBUF + DBUF;
+    constexpr int FOLD = KIN * CQB * 4 * BF * 4;
+    static_assert(2 * BUF >= FOLD, "fold slab reuses the tile buffers");
+    __shared__ __attribute__((aligned(16))) char lds[2 * BUF];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rt = wave / WCG, cg = wave % WCG;
+    // ---- which block (XCD-aware: the blocks of one split of the positions sit on one XCD and share x / dy in its L2)
+    const int n_ot = g.ks[0] * g.ks[1];
+    const int ncc = g.Cq / CQB, nfc = g.F / BF;
+    const int n_inner = n_ot * ncc * nfc;
+    const int n_tiles = n_inner * g.n_splits;
+    const int per_xcd = (n_tiles + 7) / 8;
+    const int tile = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+    if (tile >= n_tiles) return;
+    const int split = tile / n_inner;
+    const int inner = tile - split * n_inner;
+    const int ot = inner % n_ot;                    // outer tap (t0 * ks1 + t1)
+    const int chunk = inner / n_ot;
+    const int cchunk = chunk / nfc, fchunk = chunk - cchunk * nfc;
+    const int c0 = cchunk * CQB, f0 = fchunk * BF;
+    const int t0 = ot / g.ks[1], t1 = ot - t0 * g.ks[1];
+    const int WP = g.b_wp, W = g.osp[2];
+    const int p_begin = split * g.m_per_split;
+    const int p_end = min(g.b_nlines * WP, p_begin + g.m_per_split);
+    // the blocks that stage the same dY tiles -- (outer tap, channel chunk) of one (split, filter chunk) -- take turns
+    // at the bias gradient and at the masked-dY side output (one owner would set the kernel time)
+    const int n_share = n_ot * ncc;
+    const bool bias_blk = g.want_dbias != 0, dym_blk = MASK && g.dym != nullptr;
+    int turn = ot * ncc + cchunk;                   // 0 => this K step is ours
+
+    // ---- staging: 8 threads per position, 16-byte units -------------------------------------------------------
+    constexpr int UC = CQB / 8, UF = BF / 8;        // units per component block of an X / dY row
+    constexpr int UX = (4 * UC) / 8, UD = (4 * UF) / 8;       // units per thread
+    static_assert(UX >= 1 && UD >= 1, "units per thread");
+    const int s_row = tid >> 3, s_sub = tid & 7;
+    const __amdgpu_buffer_rsrc_t rx = rsrc_of(x, g.x_bytes), rdy = rsrc_of(dy, g.dy_bytes);
+    const __amdgpu_buffer_rsrc_t ry = rsrc_of(MASK ? ymask : dy, g.dy_bytes);
+    const __amdgpu_buffer_rsrc_t rdym = rsrc_of(g.dym ? g.dym : dy, g.dym ? g.dy_bytes : 0u);
+    // unit q = s_sub + 8 u of a row: component q / UC (UF), channel group q % UC (UF)
+    const unsigned x_thr = (unsigned)((s_sub / UC) * g.Cq + c0 + (s_sub % UC) * 8) * 2u;
+    const unsigned d_thr = (unsigned)((s_sub / UF) * g.F + f0 + (s_sub % UF) * 8) * 2u;
+    const unsigned x_ustep = (unsigned)((8 / UC) * g.Cq) * 2u, d_ustep = (unsigned)((8 / UF) * g.F) * 2u;
+    uint4 xr[UX], xh[UX], dr[UD], mr[MASK ? UD : 1];
+    // position of this thread's row: (line, u) with line = (n * osp0 + o0) * osp1 + o1; advanced by KM per decode
+    int r_line, r_u, r_n, r_o0, r_o1;
+    {
+        const int P = p_begin + s_row;
+        r_line = P / WP; r_u = P - r_line * WP;
+        int l = r_line;
+        r_o1 = l % g.osp[1]; l /= g.osp[1];
+        r_o0 = l % g.osp[0];
+        r_n = l / g.osp[0];
+    }
+    // offsets of the row this thread loads next (vx: band row of the tile, vd: its dY row) and of the one after
+    // (vx_n: also the HALO row of the tile, band row KM + s_row, for the threads with s_row < KIN - 1)
+    unsigned vx = kOOR, vd = kOOR, vx_n = kOOR, vd_n = kOOR, vd_cur = kOOR;
+    int p_next = p_begin;                            // position base of the next decode
+    auto decode = [&]() {
+        const bool in_img = r_line < g.b_nlines;
+        const int col = r_u + g.b_cshift;
+        const int i0 = r_o0 * g.pa[0] + t0 * g.pb[0] + g.pc[0], i1 = r_o1 * g.pa[1] + t1 * g.pb[1] + g.pc[1];
+        const bool x_in = in_img && col >= 0 && col < g.isp[2] && i0 >= 0 && i0 < g.isp[0] && i1 >= 0 && i1 < g.isp[1];
+        const int xo = r_n * (int)g.x_sn + i0 * (int)g.x_ss[0] + i1 * (int)g.x_ss[1] + col * (int)g.x_ss[2];
+        vx_n = x_in ? (unsigned)xo * 2u + x_thr : kOOR;
+        const bool d_in = in_img && r_u < W && p_next + s_row < p_end;
+        vd_n = d_in ? (unsigned)((r_line * W + r_u) * (int)g.dy_ss) * 2u + d_thr : kOOR;
+        p_next += KM;
+        if (WP >= KM) {                                 // carry-propagate (no divisions in the loop)
+            r_u += KM;
+            const bool c = r_u >= WP;
+            r_u -= c ? WP : 0; r_line += c ? 1 : 0;
+            r_o1 += c ? 1 : 0;
+            const bool c1 = r_o1 == g.osp[1];
+            r_o1 = c1 ? 0 : r_o1; r_o0 += c1 ? 1 : 0;
+            const bool c0_ = r_o0 == g.osp[0];
+            r_o0 = c0_ ? 0 : r_o0; r_n += c0_ ? 1 : 0;
+        } else {                                        // short lines: decode again
+            const int P = p_next + s_row;
+            r_line = P / WP; r_u = P - r_line * WP;
+            int l = r_line;
+            r_o1 = l % g.osp[1]; l /= g.osp[1];
+            r_o0 = l % g.osp[0];
+            r_n = l / g.osp[0];
+        }
+    };
+    auto shift = [&]() { vx = vx_n; vd = vd_n; };
+    const bool halo_thr = s_row < KIN - 1;
+    constexpr int NU = 2 * UX + UD;                  // staged units per thread and K step: X, X halo, dY
+    auto load_unit = [&](int u) {
+        if (u < UX) xr[u] = bload16(rx, vx, u * x_ustep);
+        else if (u < 2 * UX) { if (wave == 0) xh[u - UX] = bload16(rx, halo_thr ? vx_n : kOOR, (u - UX) * x_ustep); }
+        else {
+            const int i = u - 2 * UX;
+            dr[i] = bload16(rdy, vd, i * d_ustep);
+            if constexpr (MASK) mr[i] = bload16(ry, vd, i * d_ustep);
+        }
+    };
+    auto store_unit = [&](int u, int buf, bool write_dym) {
+        char *b = lds + buf * BUF;
+        if (u < UX) *reinterpret_cast<uint4 *>(b + s_row * XROW + (s_sub + u * 8) * 16) = xr[u];
+        else if (u < 2 * UX) {
+            if (wave == 0 && halo_thr) *reinterpret_cast<uint4 *>(b + (KM + s_row) * XROW + (s_sub + (u - UX) * 8) * 16) = xh[u - UX];
+        } else {
+            const int i = u - 2 * UX;
+            uint4 v = dr[i];
+            if constexpr (MASK) v = make_uint4(keep2(v.x, mr[i].x), keep2(v.y, mr[i].y), keep2(v.z, mr[i].z), keep2(v.w, mr[i].w));
+            *reinterpret_cast<uint4 *>(b + XBUF + s_row * DROW + (s_sub + i * 8) * 16) = v;
+            if constexpr (MASK) {
+                if (write_dym) {
+                    bstore16(v, rdym, vd_cur, i * d_ustep);
+                    asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");      // store-data hazard, see k_wgrad16
+                }
+            }
+        }
+    };
+
+    floatx16 acc[KIN][CTW];
+#pragma unroll
+    for (int t = 0; t < KIN; ++t)
+#pragma unroll
+        for (int ct = 0; ct < CTW; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][ct][r] = 0.f;
+    float dbacc = 0.f;
+
+    const int Lg = lane & 15, g16 = (lane >> 4) & 1, kh = lane >> 5;
+    const int fr_row = 8 * kh + (Lg >> 2);
+    const int fr_ch = 16 * g16 + 4 * (Lg & 3);
+    const int a_off = fr_row * XROW + (rt * 32 + fr_ch) * 2;                          // + (ks*16 + t) rows
+    const int b_off = XBUF + fr_row * DROW + ((cg * CTW) * 32 + fr_ch) * 2;           // + ks*16 rows, + ct*64 bytes
+
+    constexpr int KS = KM / 16, NMF = KIN * CTW;
+    static_assert((NU + KS - 1) / KS * 2 <= NMF, "two issue slots per staged unit");
+    const int iters = (p_end - p_begin + KM - 1) / KM;
+    if (iters > 0) {
+        decode(); shift(); decode();                 // vx/vd: tile 0, vx_n: tile 1 (= halo rows of tile 0)
+#pragma unroll
+        for (int u = 0; u < NU; ++u) load_unit(u);
+        vd_cur = vd;
+        {
+            const bool mine = turn == 0;
+#pragma unroll
+            for (int u = 0; u < NU; ++u) store_unit(u, 0, dym_blk && mine);
+        }
+        shift(); decode();
+#pragma unroll
+        for (int u = 0; u < NU; ++u) load_unit(u);
+        vd_cur = vd;
+        __syncthreads();
+        for (int it = 0; it < iters; ++it) {
+            const char *tb = lds + (it & 1) * BUF;
+            const int nb = (it + 1) & 1;
+            const bool mine = turn == 0;              // this tile's dY rows are ours (bias / masked dY): tile `it`
+            turn = turn == 0 ? n_share - 1 : turn - 1;
+            const bool mine_next = turn == 0;         // ... and the one moving into LDS now: tile it + 1
+            if (bias_blk && mine && tid < 4 * BF) {
+                const T *col = reinterpret_cast<const T *>(tb + XBUF) + tid;
+#pragma unroll 8
+                for (int mm = 0; mm < KM; ++mm) dbacc += to_f32(col[mm * (DROW / 2)]);
+            }
+            shift(); decode();
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                v8s A[KIN], B[CTW];
+#pragma unroll
+                for (int t = 0; t < KIN; ++t) A[t] = tr_frag8(tb + a_off + (ks * 16 + t) * XROW, XROW);
+#pragma unroll
+                for (int ct = 0; ct < CTW; ++ct) B[ct] = tr_frag8(tb + b_off + ks * 16 * DROW + ct * 64, DROW);
+                __builtin_amdgcn_sched_barrier(0);
+                const int u_lo = ks * NU / KS, u_hi = (ks + 1) * NU / KS;
+#pragma unroll
+                for (int j = 0; j < NMF; ++j) {
+                    const int t = j / CTW, ct = j % CTW;
+                    acc[t][ct] = mfma16b(T(), A[t], B[ct], acc[t][ct]);
+                    const int u = u_lo + j / 2;
+                    if (u < u_hi) {
+                        if (j % 2 == 0) store_unit(u, nb, dym_blk && mine_next);
+                        else load_unit(u);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            vd_cur = vd;
+            __syncthreads();
+        }
+    }
+
+    // ---- fold the 16 expanded blocks onto the 4 compact parts, then one atomic pass ---------------------------
+    if ((g.ablate & 1) && acc[0][0][0] != 123.456f) return;
+    float *slab = reinterpret_cast<float *>(lds);     // [tap][channel][part][filter]
+    const int lr = lane & 31;
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph) {                  // phase = gathered component a
+        const bool active = RTT == 2 ? rt == (ph >> 1) : rt == ph;
+        if (active) {
+#pragma unroll
+            for (int ct = 0; ct < CTW; ++ct) {
+                const int col = (cg * CTW + ct) * 32 + lr;
+                const int b = col / BF, ff = col % BF;
+                const int p = ph ^ b;
+                const bool neg = (g.sign_tbl >> (ph * 4 + b)) & 1u;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    if (RTT == 2 && (r >> 3) != (ph & 1)) continue;      // this register's rows belong to the other component
+                    const int row = mfma32_row(r, lane);
+                    const int cc = RTT == 2 ? (row & 15) : row;
+#pragma unroll
+                    for (int t = 0; t < KIN; ++t) {
+                        const float v = neg ? -acc[t][ct][r] : acc[t][ct][r];
+                        float *dst = &slab[((t * CQB + cc) * 4 + p) * BF + ff];
+                        *dst = ph == 0 ? v : *dst + v;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    const int tap0 = ot * KIN;                        // compact tap index of inner tap 0
+    for (int e = tid; e < KIN * CQB * 4 * BF; e += NTHR) {
+        const int ff = e % BF;
+        const int p = (e / BF) & 3;
+        const int cv = e / (4 * BF);                  // tap * CQB + channel
+        const int t = cv / CQB, cc = cv - t * CQB;
+        if (!(g.ablate & 2))
+            atomicAdd(dw + (((tap0 + t) * g.Cq + c0 + cc) * 4 + p) * g.F + f0 + ff, slab[e]);
+    }
+    if (bias_blk && tid < 4 * BF) {
+        const int b = tid / BF, ff = tid % BF;
+        atomicAdd(dbias + b * g.F + f0 + ff, dbacc);
+    }
+}
+
+template <typename T, int RTT, int KIN>
+int run_wgrad16_band(const T *x, const T *dy, const T *ymask, float *dw, float *dbias, WgradGeom g, hipStream_t stream)
+{
+    constexpr int CQB = RTT * 8, BF = (8 / RTT) * 2 * 8, KM = 64;
+    const long long other = (long long)g.ks[0] * g.ks[1] * (g.Cq / CQB) * (g.F / BF);
+    const long long total_p = (long long)g.b_nlines * g.b_wp;
+    const long long max_splits = (total_p + KM - 1) / KM;
+    const int slots = device_cu_count();              // 84 - 100 KB of LDS: one workgroup per CU
+    const long long kEpilogueSteps = 24;              // fold + atomics, in K-step equivalents
+    long long splits = 1, best_cost = -1;
+    for (int r = 1; r <= 4; ++r) {
+        long long sp = (long long)r * slots / other;
+        sp = sp < 1 ? 1 : (sp > max_splits ? max_splits : sp);
+        long long mps_r = (total_p + sp - 1) / sp;
+        mps_r = (mps_r + KM - 1) / KM * KM;
+        sp = (total_p + mps_r - 1) / mps_r;
+        const long long rounds = (sp * other + slots - 1) / slots;
+        const long long cost = rounds * (mps_r / KM + kEpilogueSteps);
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; splits = sp; }
+    }
+    long long mps = (total_p + splits - 1) / splits;
+    mps = (mps + KM - 1) / KM * KM;
+    splits = (total_p + mps - 1) / mps;
+    g.m_per_split = (int)mps;
+    g.n_splits = (int)splits;
+    g.x_bytes = (unsigned)((long long)g.batch * g.x_sn * 2);
+    g.dy_bytes = (unsigned)((long long)g.M * g.dy_ss * 2);
+    g.ablate = debug_ablate();
+    const long long n_tiles = splits * other;
+    dim3 grid((unsigned)((n_tiles + 7) / 8 * 8), 1, 1);
+    if (g.has_mask)
+        hipLaunchKernelGGL((k_wgrad16_band<T, RTT, KIN, true>), grid, dim3(512), 0, stream, x, dy, ymask, dw, dbias, g);
+    else
+        hipLaunchKernelGGL((k_wgrad16_band<T, RTT, KIN, false>), grid, dim3(512), 0, stream, x, dy, ymask, dw, dbias, g);
+    return hipGetLastError() == hipSuccess ? 1 : QK_ERR_LAUNCH;
+}
+
+// Band geometry of a backward-weight call, or false: the innermost used axis must have 3 or 5 taps with unit stride
+// and dilation; axes are rotated so that it is index 2 (unit axes move to the front: neither the position order nor
+// the tap order changes).
+bool wgrad_band_geom(const WgradGeom &g, WgradGeom *o)
+{
+    int ax = 2;
+    while (ax > 0 && g.osp[ax] == 1 && g.isp[ax] == 1 && g.ks[ax] == 1) --ax;
+    if (g.ks[ax] != 3 && g.ks[ax] != 5) return false;
+    if (g.pa[ax] != 1 || g.pb[ax] != 1) return false;
+    *o = g;
+    const int sh = 2 - ax;
+    for (int i = 0; i < 3; ++i) {
+        const int src = i - sh;
+        o->osp[i] = src >= 0 ? g.osp[src] : 1; o->isp[i] = src >= 0 ? g.isp[src] : 1; o->ks[i] = src >= 0 ? g.ks[src] : 1;
+        o->pa[i] = src >= 0 ? g.pa[src] : 1; o->pb[i] = src >= 0 ? g.pb[src] : 1; o->pc[i] = src >= 0 ? g.pc[src] : 0;
+        o->x_ss[i] = src >= 0 ? g.x_ss[src] : 0;
+    }
+    const int k = o->ks[2];
+    o->b_wp = o->osp[2] + k - 1;
+    if ((k - 1) * 12 > o->b_wp) return false;                // > 8 % of the positions would be padding
+    const long long lines = (long long)g.batch * o->osp[0] * o->osp[1];
+    if (lines * o->b_wp >= (1ll << 31) - 512) return false;
+    o->b_nlines = (int)lines;
+    o->b_cshift = o->pc[2];
+    return true;
+}
+
+template <typename T>
+int go_wgrad16_band(const void *x, const void *dy, const void *ymask, float *dw, float *dbias, const WgradGeom &g,
+                    hipStream_t stream)
+{
+    const T *xp = (const T *)x, *dp = (const T *)dy, *yp = (const T *)ymask;
+    const bool k5 = g.ks[2] == 5;
+    // F % 64 == 0: 16 channels x 64 filters per block -- except with the relu mask, where the narrower dY tile of the
+    // 32 x 32 form halves the mask work per block (B = 256 body layer: 1117 vs 1135 us linear, 1350 vs 1221 us masked)
+    if (g.F % 64 == 0 && !(g.has_mask && g.Cq % 32 == 0))
+        return k5 ? run_wgrad16_band<T, 2, 5>(xp, dp, yp, dw, dbias, g, stream) : run_wgrad16_band<T, 2, 3>(xp, dp, yp, dw, dbias, g, stream);
+    return k5 ? run_wgrad16_band<T, 4, 5>(xp, dp, yp, dw, dbias, g, stream) : run_wgrad16_band<T, 4, 3>(xp, dp, yp, dw, dbias, g, stream);
+}
+
+}  // namespace
+
+// Returns 1 when the band kernel took the call, 0 when the shape is outside it (the caller goes on to k_wgrad16),
+// < 0 on error.  dw / dbias must already be zeroed (atomic accumulation).
+int try_wgrad_band_16(int dtype, const void *x, const void *dy, const void *ymask, float *dw, float *dbias,
+                      const WgradGeom &g, hipStream_t stream)
+{
+    if (dtype != QK_BF16 && dtype != QK_F16) return 0;
+    if (debug_flags() & (kDbgNoMfma16 | kDbgNoWgradBand)) return 0;
+    if (g.x_sc != 1 || g.dy_sc != 1) return 0;                         // channels_last buffers only
+    const long long S = (long long)g.osp[0] * g.osp[1] * g.osp[2];
+    if (g.dy_sn != S * g.dy_ss) return 0;                              // dy rows are addressed by flat position
+    if (g.F % 32 != 0 || g.Cq % (g.F % 64 == 0 ? 16 : 32) != 0) return 0;
+    if ((long long)g.batch * g.x_sn * 2 >= 0xF0000000ll || (long long)g.M * g.dy_ss * 2 >= 0xF0000000ll) return 0;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(ymask)) & 15) return 0;
+    WgradGeom bg;
+    if (!wgrad_band_geom(g, &bg)) return 0;
+    if ((long long)bg.taps * bg.Cq * 4 * bg.F >= (1ll << 31)) return 0;
+    note_path(QK_PATH_MFMA16_BAND);
+    if (dtype == QK_BF16) return go_wgrad16_band<bf16>(x, dy, ymask, dw, dbias, bg, stream);
+    return go_wgrad16_band<f16>(x, dy, ymask, dw, dbias, bg, stream);
+}
+
+}  // namespace qk
