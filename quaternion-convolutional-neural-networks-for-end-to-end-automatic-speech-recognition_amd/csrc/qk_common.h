@@ -54,6 +54,9 @@ struct GemmGeom {
     // band variant of the 16-bit kernel (qk_hgemm_bf16mfma.hip): rows of M run over PADDED lines of the
     // innermost axis (b_wp = out extent + k - 1 positions per line, b_nlines lines), band row j of a tile
     // holds input position (padded position + b_cshift); b_rev: taps walk the band backwards (bwd-data)
+    // division by the row-decode divisors through precomputed multipliers (set_fastdiv below): an integer
+    // division is ~40 VALU instructions, a tile's prologue decodes 3 - 5 rows with 3 of them each
+    unsigned dv_mul[3], dv_shr[3];       // k_hgemm16: by osp[2], osp[1], osp[0];  band: by b_wp, osp[1], osp[0]
     const void *ep_mask;                 // optional epilogue mask: out *= (ep_mask > 0), same layout as out (16-bit kernels)
     int b_wp, b_nlines, b_cshift, b_rev;
     unsigned b_in_bytes, b_w_bytes;      // extents of the input tensor and of the re-laid-out kernel (buffer resources)
@@ -96,6 +99,21 @@ inline bool band_geom(const GemmGeom &g, int esize, GemmGeom *o)
     o->b_rev = o->pb[2] < 0;
     o->b_cshift = o->b_rev ? o->pc[2] - (k - 1) : o->pc[2];
     return true;
+}
+
+// n / d for 0 <= n < 2^31 with (mul, shr) from fastdiv_of(d): umulhi(n, mul) >> shr  (d == 1: mul == 0 marks identity)
+inline void fastdiv_of(unsigned d, unsigned *mul, unsigned *shr)
+{
+    if (d <= 1) { *mul = 0; *shr = 0; return; }
+    unsigned lg = 0;
+    while ((1ull << lg) < d) ++lg;                         // ceil(log2 d)
+    const unsigned p = 31 + lg;
+    *mul = (unsigned)(((1ull << p) + d - 1) / d);
+    *shr = p - 32;
+}
+__device__ __forceinline__ int fastdiv(int n, unsigned mul, unsigned shr)
+{
+    return mul ? (int)(__umulhi((unsigned)n, mul) >> shr) : n;
 }
 
 struct WgradGeom {

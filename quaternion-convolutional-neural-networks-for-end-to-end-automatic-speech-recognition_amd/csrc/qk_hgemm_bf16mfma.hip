@@ -167,10 +167,9 @@ k_hgemm16(const T *__restrict__ in, const T *__restrict__ mask, const uint4 *__r
         int m = m0 + s_row + r * 64;
         base_off[r] = 0; tapmask[r] = 0;
         if (m < g.M) {
-            const int o2 = m % g.osp[2]; m /= g.osp[2];
-            const int o1 = m % g.osp[1]; m /= g.osp[1];
-            const int o0 = m % g.osp[0];
-            const int n = m / g.osp[0];
+            const int q2 = fastdiv(m, g.dv_mul[0], g.dv_shr[0]), o2 = m - q2 * g.osp[2];
+            const int q1 = fastdiv(q2, g.dv_mul[1], g.dv_shr[1]), o1 = q2 - q1 * g.osp[1];
+            const int n = fastdiv(q1, g.dv_mul[2], g.dv_shr[2]), o0 = q1 - n * g.osp[0];
             const int p0 = o0 * g.pa[0] + g.pc[0], p1 = o1 * g.pa[1] + g.pc[1], p2 = o2 * g.pa[2] + g.pc[2];
             base_off[r] = n * (int)g.in_sn + p0 * (int)g.in_ss[0] + p1 * (int)g.in_ss[1] + p2 * (int)g.in_ss[2];
             int t = 0;
@@ -364,10 +363,13 @@ k_hgemm16(const T *__restrict__ in, const T *__restrict__ mask, const uint4 *__r
     constexpr int EP_PITCH = 80;                                   // 64 B of data + 16 B pad per row
     char *ep = reinterpret_cast<char *>(lds) + wave * (32 * EP_PITCH);
     const int e_row = lane >> 2, e_chunk = lane & 3;
+    float bia4[4];                                                 // up front: see k_hgemm16_band
+#pragma unroll
+    for (int b = 0; b < 4; ++b) bia4[b] = g.has_bias ? bias[b * g.J + j0 + wn * 32 + lr] : 0.f;
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
         const int ch0 = b * g.J + j0 + wn * 32;
-        const float bia = g.has_bias ? bias[ch0 + lr] : 0.f;
+        const float bia = bia4[b];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -449,7 +451,7 @@ constexpr int band_op(int R, int K, int ti, int k)
 //   TRIM (N = 128, 4 x 1 waves): the band buffer holds exactly BM = 128 rows, so a tile yields BM - (KIN - 1)
 //     output rows and the last KIN - 1 rows of the wave tiles are computed and dropped (3 %): 2 x 128 rows x 256 B
 //     + 2 B tiles = 80 KB is what lets two such workgroups share a CU.
-template <typename T, int WM, int WN, int KIN, bool CONJ, bool TRIM>
+template <typename T, int WM, int WN, int KIN, bool CONJ, bool TRIM, bool EPM>
 __global__ void __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *__restrict__ zero_line,
                const float *__restrict__ bias, T *__restrict__ out, const GemmGeom g)
@@ -493,13 +495,11 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
         const int j = s_row + r * RPP;
         base_off[r] = 0; omask[r] = 0;
         const int P = p0 + j;
-        const int line = P / WP;
+        const int line = fastdiv(P, g.dv_mul[0], g.dv_shr[0]);
         const int col = P - line * WP + g.b_cshift;
         if (j < BAND && line < g.b_nlines && col >= 0 && col < g.isp[2]) {
-            const int o1 = line % g.osp[1];
-            const int l2 = line / g.osp[1];
-            const int o0 = l2 % g.osp[0];
-            const int n = l2 / g.osp[0];
+            const int l2 = fastdiv(line, g.dv_mul[1], g.dv_shr[1]), o1 = line - l2 * g.osp[1];
+            const int n = fastdiv(l2, g.dv_mul[2], g.dv_shr[2]), o0 = l2 - n * g.osp[0];
             const int q0 = o0 * g.pa[0] + g.pc[0], q1 = o1 * g.pa[1] + g.pc[1];
             base_off[r] = n * (int)g.in_sn + q0 * (int)g.in_ss[0] + q1 * (int)g.in_ss[1] + col * (int)g.in_ss[2];
             int t = 0;
@@ -697,13 +697,13 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
     for (int pass = 0; pass < 2; ++pass) {
         const int tr = wm * 32 + e_row + 16 * pass;                  // row inside the tile
         const int P = p0 + tr;
-        const int line = P / WP;
+        const int line = fastdiv(P, g.dv_mul[0], g.dv_shr[0]);
         const int u = P - line * WP;
         o_ok[pass] = line < g.b_nlines && u < g.osp[2] && (!TRIM || tr < BMU);
         o_row[pass] = (long long)(line * g.osp[2] + u) * (int)g.out_ss + j0 + wn * 32 + e_chunk * 8;
     }
-    uint4 em[4][2];
-    if (g.ep_mask) {
+    uint4 em[EPM ? 4 : 1][2];
+    if (EPM && g.ep_mask) {
 #pragma unroll
         for (int b = 0; b < 4; ++b)
 #pragma unroll
@@ -711,9 +711,14 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
                 em[b][pass] = o_ok[pass] ? *reinterpret_cast<const uint4 *>(static_cast<const T *>(g.ep_mask) + o_row[pass] + b * g.J)
                                          : make_uint4(0u, 0u, 0u, 0u);
     }
+    // all four bias values up front: a load inside the component loop makes every iteration wait for vmcnt(0), i.e.
+    // for the previous iteration's global STORES to be acknowledged as well (~6 us per tile, measured by ablation)
+    float bia4[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) bia4[b] = g.has_bias ? bias[b * g.J + j0 + wn * 32 + lr] : 0.f;
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-        const float bia = g.has_bias ? bias[b * g.J + j0 + wn * 32 + lr] : 0.f;
+        const float bia = bia4[b];
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {                   // registers r, r + 1 hold consecutive rows
             float v0 = acc[b][r] - accn[b][r] + bia, v1 = acc[b][r + 1] - accn[b][r + 1] + bia;
@@ -728,7 +733,7 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
             const int row = e_row + 16 * pass;
             uint4 v = *reinterpret_cast<const uint4 *>(ep + row * EP_PITCH + e_chunk * 16);
             if (o_ok[pass]) {
-                if (g.ep_mask) v = mask8(v, em[b][pass]);
+                if constexpr (EPM) { if (g.ep_mask) v = mask8(v, em[b][pass]); }
                 *reinterpret_cast<uint4 *>(out + o_row[pass] + b * g.J) = v;
             }
         }
@@ -742,10 +747,12 @@ int run16_band(const T *in, const uint4 *wq, const T *zero_line, const float *bi
     constexpr int BM = WM * 32, BF = WN * 32, BMU = TRIM ? BM - (KIN - 1) : BM, NTHR = WM * WN * 64;
     const int n_mt = (int)(((long long)g.b_nlines * g.b_wp + BMU - 1) / BMU);
     dim3 grid((n_mt + 7) / 8 * 8, g.J / BF, 1);
-    if (g.sign_tbl == kSignConj)
-        hipLaunchKernelGGL((k_hgemm16_band<T, WM, WN, KIN, true, TRIM>), grid, dim3(NTHR), 0, stream, in, wq, zero_line, bias, out, g);
-    else
-        hipLaunchKernelGGL((k_hgemm16_band<T, WM, WN, KIN, false, TRIM>), grid, dim3(NTHR), 0, stream, in, wq, zero_line, bias, out, g);
+    // EPM (epilogue mask, QK_BWD_MASK_DX) is its own instantiation: its eight prefetched mask pieces cost 32 VGPRs
+#define QK_GO(C, E) hipLaunchKernelGGL((k_hgemm16_band<T, WM, WN, KIN, C, TRIM, E>), grid, dim3(NTHR), 0, stream, in, wq, zero_line, bias, out, g)
+    const bool conj = g.sign_tbl == kSignConj, epm = g.ep_mask != nullptr;
+    if (conj) { if (epm) QK_GO(true, true); else QK_GO(true, false); }
+    else      { if (epm) QK_GO(false, true); else QK_GO(false, false); }
+#undef QK_GO
     return hipGetLastError() == hipSuccess ? 1 : QK_ERR_LAUNCH;
 }
 
@@ -772,6 +779,7 @@ int go16(const void *in, const void *mask, const float *w, const float *bias, vo
 {
     GemmGeom g = g_in;
     g.ablate = debug_ablate();
+    for (int i = 0; i < 3; ++i) fastdiv_of((unsigned)g.osp[2 - i], &g.dv_mul[i], &g.dv_shr[i]);
     T *wq = static_cast<T *>(ws);
     const int Cq = transposed ? g.J : g.Q, F = transposed ? g.Q : g.J;
     const long long total = (long long)g.taps * Cq * 4 * F;
@@ -783,6 +791,9 @@ int go16(const void *in, const void *mask, const float *w, const float *bias, vo
     const T *zero_line = wq + total;                 // 256 zeroed bytes behind the re-laid-out kernel
     GemmGeom bg;
     if (!(debug_flags() & kDbgNoBand16) && band_geom(g, 2, &bg)) {
+        fastdiv_of((unsigned)bg.b_wp, &bg.dv_mul[0], &bg.dv_shr[0]);
+        fastdiv_of((unsigned)bg.osp[1], &bg.dv_mul[1], &bg.dv_shr[1]);
+        fastdiv_of((unsigned)bg.osp[0], &bg.dv_mul[2], &bg.dv_shr[2]);
         const T *ip = (const T *)in;
         T *op = (T *)out;
         note_path(QK_PATH_MFMA16_BAND);
