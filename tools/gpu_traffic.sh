@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; cd $R; mkdir -p gpurun_out/traffic
 for WL in "$@"; do
-for K in fwd bwd_weight bwd_data; do
+for K in fwd bwd_weight bwd_data bwd_weight_chain bwd_data_chain; do
   for C in FETCH_SIZE WRITE_SIZE; do
     timeout 600 rocprofv3 --pmc $C -d gpurun_out/traffic -o ${WL}_${K}_${C} --output-format csv -- python tools/run_kernel.py $WL $K 3 > gpurun_out/traffic/log.txt 2>&1 || echo "fail $WL $K $C"
   done
@@ -13,7 +13,7 @@ python - <<'PY'
 import csv, glob, json, os, re, collections
 out = collections.defaultdict(dict)
 for f in sorted(glob.glob('gpurun_out/traffic/*_counter_collection.csv')):
-    m = re.match(r'(.*)_(fwd|bwd_weight|bwd_data)_(FETCH_SIZE|WRITE_SIZE)_counter_collection.csv', os.path.basename(f))
+    m = re.match(r'(.*?)_(fwd|bwd_weight_chain|bwd_data_chain|bwd_weight|bwd_data)_(FETCH_SIZE|WRITE_SIZE)_counter_collection.csv', os.path.basename(f))
     if not m: continue
     wl, k, c = m.groups()
     vals = collections.defaultdict(list)
@@ -22,7 +22,7 @@ for f in sorted(glob.glob('gpurun_out/traffic/*_counter_collection.csv')):
         if any(s in name for s in ('k_hgemm', 'k_wgrad')):
             vals[name].append(float(r['Counter_Value']))
     # the kernel under test is the one launched most often in this run (run_kernel.py: 3 reps + 1 fwd warm-up)
-    want = {'fwd': 'k_hgemm', 'bwd_data': 'k_hgemm', 'bwd_weight': 'k_wgrad'}[k]
+    want = 'k_wgrad' if 'weight' in k else 'k_hgemm'
     cands = {n: v for n, v in vals.items() if want in n}
     if k == 'bwd_data' and len(cands) > 1:      # the warm-up fwd is also a k_hgemm: take the most frequent
         pass
