@@ -58,6 +58,10 @@ WORKLOADS = {
     # BASELINE.json configs[2]: the full TIMIT QCNN (models/interspeech_model.py:45-185), n=10, sf=32
     'cfg3_qcnn_timit_b256_bf16': dict(kind='model', batch=256, frames=200, sf=32, layers=10, dtype='bf16'),
     'cfg3_qcnn_timit_b64_fp32': dict(kind='model', batch=64, frames=200, sf=32, layers=10, dtype='fp32'),
+    # the reference's own activation / regularisation setting (interspeech_model.py:55-56,99-137: aact='prelu' makes
+    # every layer linear + PReLU(shared_axes=[1,0]) + Dropout): PReLU and dropout fused into the kernel epilogues
+    'cfg3_qcnn_prelu_dropout_b256_bf16': dict(kind='model', batch=256, frames=200, sf=32, layers=10, dtype='bf16',
+                                              aact='prelu', dropout=0.3),
 }
 
 

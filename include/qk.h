@@ -194,6 +194,41 @@ int qk_dense_bwd_chain(const qk_dense_desc_t *desc, const void *x, const void *d
                        void *dx, float *dw, float *dbias, int32_t flags, void *workspace, size_t workspace_bytes,
                        void *stream);
 
+/* PReLU + Dropout behind a layer, as the reference's TIMIT model applies them after every convolution
+ * (models/interspeech_model.py:99-101,117-121: `PReLU(shared_axes=[1,0])`, `Dropout(d.dropout)`):
+ *     y = drop(prelu(pre)),  prelu(v) = v > 0 ? v : alpha * v,  drop(v) = keep ? v / (1 - rate) : 0.
+ * alpha: float32 on the device, ONE scalar (alpha_axis = -1) or one slope per position along spatial axis
+ * `alpha_axis` (0 .. rank-1) of the tensor -- what Keras builds for shared_axes=[1,0] on a channels_first (C, F, T)
+ * activation is (1, F, 1): alpha_axis = 0, alpha_len = F.  The dropout mask is never stored: keep(e) is a hash of
+ * (drop_seed, flat element index of y in its channels_last buffer), identical in forward and backward; pass a new
+ * seed every step.  drop_rate = 0 disables dropout. */
+typedef struct {
+    int32_t alpha_axis;      /* -1: scalar; 0..2: spatial axis of the activation that indexes alpha       */
+    int32_t alpha_len;       /* 1 for a scalar, else the extent of that axis                                */
+    const float *alpha;      /* device pointer, float32                                                     */
+    float drop_rate;         /* in [0, 1)                                                                   */
+    uint32_t drop_seed;
+} qk_postop_t;
+
+/* y = post(W (x) x + b): the convolution must be LINEAR (desc->activation); `pre` receives W (x) x + b (same
+ * shape / dtype as y; needed by the backward of the post-op), `y` the activated / dropped tensor. */
+int qk_conv_fwd_post(const qk_conv_desc_t *desc, const qk_postop_t *post, const void *x, const float *w,
+                     const float *bias, void *pre, void *y, void *workspace, size_t workspace_bytes, void *stream);
+
+/* Fused backward of a LINEAR layer (dy = d loss / d pre of THIS layer) whose input x = post_x(x_pre) was produced by
+ * a post-op: dw, dbias as qk_conv_bwd; dx receives d loss / d x_pre (the post-op's derivative is applied in the
+ * epilogue of backward-data), dalpha_x[alpha_len] (float32) is ACCUMULATED into (zero it once per step). */
+int qk_conv_bwd_post(const qk_conv_desc_t *desc, const void *x, const void *dy, const float *w, void *dx, float *dw,
+                     float *dbias, const qk_postop_t *post_x, const void *x_pre, float *dalpha_x, void *workspace,
+                     size_t workspace_bytes, void *stream);
+
+/* The post-op on its own (any dtype / shape, HBM-bound): `t` describes the channels_last activation
+ * (batch, spatial[0..rank-1], channels) -- only batch, rank, out_spatial, fq (channels = 4 * fq) and dtype of a
+ * qk_conv_desc_t are read.  bwd: dpre = d loss / d pre, dalpha accumulated. */
+int qk_postop_fwd(const qk_conv_desc_t *t, const qk_postop_t *post, const void *pre, void *y, void *stream);
+int qk_postop_bwd(const qk_conv_desc_t *t, const qk_postop_t *post, const void *pre, const void *dy, void *dpre,
+                  float *dalpha, void *stream);
+
 /* Tap folding for layers with very few input channels (the first TIMIT layer has cq = 1: K = 4*taps).
  *   xcol[m, a*cq2 + t*cq + c] = x[pos(m, t), a*cq + c]      (0 in the padding and for t*cq + c >= taps*cq)
  * xcol is channels_last (N, *out_spatial, 4*cq2), cq2 a multiple of 8 with cq2 >= taps*cq.  The layer

@@ -46,6 +46,15 @@ class PoolDesc(ctypes.Structure):
 
 _PD = ctypes.POINTER(PoolDesc)
 
+
+class PostOp(ctypes.Structure):
+    """qk_postop_t (include/qk.h): PReLU (+ Dropout) behind a layer."""
+    _fields_ = [('alpha_axis', ctypes.c_int32), ('alpha_len', ctypes.c_int32), ('alpha', ctypes.c_void_p),
+                ('drop_rate', ctypes.c_float), ('drop_seed', ctypes.c_uint32)]
+
+
+_PO = ctypes.POINTER(PostOp)
+
 SYMBOLS = {
     'qk_version': (ctypes.c_int, []),
     'qk_last_error': (ctypes.c_char_p, []),
@@ -56,6 +65,10 @@ SYMBOLS = {
     'qk_dense_workspace_bytes': (_SZ, [_DD, ctypes.c_int]),
     'qk_conv_fwd': (ctypes.c_int, [_CD, _VP, _FP, _FP, _VP, _VP, _SZ, _VP]),
     'qk_conv_bwd_data': (ctypes.c_int, [_CD, _VP, _VP, _FP, _VP, _VP, _SZ, _VP]),
+    'qk_conv_fwd_post': (ctypes.c_int, [_CD, _PO, _VP, _FP, _FP, _VP, _VP, _VP, _SZ, _VP]),
+    'qk_conv_bwd_post': (ctypes.c_int, [_CD, _VP, _VP, _FP, _VP, _FP, _FP, _PO, _VP, _FP, _VP, _SZ, _VP]),
+    'qk_postop_fwd': (ctypes.c_int, [_CD, _PO, _VP, _VP, _VP]),
+    'qk_postop_bwd': (ctypes.c_int, [_CD, _PO, _VP, _VP, _VP, _FP, _VP]),
     'qk_conv_bwd_weight': (ctypes.c_int, [_CD, _VP, _VP, _VP, _FP, _FP, _VP, _SZ, _VP]),
     'qk_conv_bwd_chain': (ctypes.c_int, [_CD, _VP, _VP, _VP, _FP, _VP, _FP, _FP, I32, _VP, _SZ, _VP]),
     'qk_dense_bwd_chain': (ctypes.c_int, [_DD, _VP, _VP, _VP, _FP, _VP, _FP, _FP, I32, _VP, _SZ, _VP]),

@@ -175,6 +175,41 @@ Strides act_strides(const int32_t *sp, int ch, int layout)
 
 int taps_of(const qk_conv_desc_t *d) { return d->kernel[0] * d->kernel[1] * d->kernel[2]; }
 
+// qk_postop_t -> kernel form; `rank` / `sp` describe the tensor the post-op acts on
+int to_postop(const qk_postop_t *q, int rank, const int32_t *sp, PostOp *p)
+{
+    memset(p, 0, sizeof(*p));
+    if (!q) return 0;
+    if (!q->alpha) { set_error("post-op: alpha is NULL"); return QK_ERR_INVALID_ARG; }
+    if (q->alpha_axis < -1 || q->alpha_axis >= (rank > 0 ? rank : 1) || !(q->drop_rate >= 0.f && q->drop_rate < 1.f)) {
+        set_error("post-op: alpha_axis %d / drop_rate %g out of range", q->alpha_axis, (double)q->drop_rate); return QK_ERR_INVALID_ARG;
+    }
+    const int want = q->alpha_axis < 0 ? 1 : sp[q->alpha_axis];
+    if (q->alpha_len != want) { set_error("post-op: alpha_len %d, expected %d", q->alpha_len, want); return QK_ERR_INVALID_ARG; }
+    p->kind = 1; p->alpha_sel = q->alpha_axis; p->alpha_len = q->alpha_len; p->alpha = q->alpha;
+    p->drop_scale = 1.f / (1.f - q->drop_rate);
+    unsigned thr = (unsigned)(q->drop_rate * 65536.f + 0.5f);
+    p->drop_thr = thr > 65535u ? 65535u : thr;
+    p->drop_seed = q->drop_seed;
+    return 0;
+}
+
+// the post-op as its own elementwise pass over a channels_last (batch, sp, ch) tensor
+int postop_pass(int dtype, bool backward, const PostOp &p, int batch, const int32_t *sp, int ch, const void *pre,
+                const void *dy, void *out, float *dalpha, hipStream_t stream)
+{
+    const long long rows = (long long)batch * sp[0] * sp[1] * sp[2];
+    int key_div = 1, key_mod = 1;
+    if (p.alpha_sel >= 0) { for (int i = p.alpha_sel + 1; i < 3; ++i) key_div *= sp[i]; key_mod = sp[p.alpha_sel]; }
+    const int vec = dtype == QK_F32 ? 4 : 8;
+    if (ch % vec != 0 || !aligned(pre, 16) || !aligned(out, 16) || (dy && !aligned(dy, 16))) {
+        set_error("post-op: channels must be a multiple of %d and buffers 16-byte aligned", vec); return QK_ERR_UNSUPPORTED;
+    }
+    if (backward && p.alpha_len > 256) { set_error("post-op: alpha_len %d > 256", p.alpha_len); return QK_ERR_UNSUPPORTED; }
+    if (rows * ch >= (1ll << 32)) { set_error("post-op: tensor has >= 2^32 elements"); return QK_ERR_UNSUPPORTED; }
+    return launch_postop(dtype, backward, pre, dy, out, dalpha, p, rows, ch, key_div, key_mod, stream);
+}
+
 size_t w_floats(const qk_conv_desc_t *d) { return (size_t)taps_of(d) * d->cq * 4 * d->fq; }
 
 size_t dy_bytes(const qk_conv_desc_t *d)
@@ -196,7 +231,7 @@ size_t ws_bytes_impl(const qk_conv_desc_t *d, int op)
 }
 
 int conv_fwd_impl(const qk_conv_desc_t *d, const void *x, const float *w, const float *bias, void *y,
-                  void *ws, size_t wsb, hipStream_t stream)
+                  void *ws, size_t wsb, hipStream_t stream, const PostOp *post = nullptr, void *pre = nullptr)
 {
     if (!x || !w || !y) { set_error("x/w/y must not be NULL"); return QK_ERR_INVALID_ARG; }
     if (d->has_bias && !bias) { set_error("has_bias set but bias is NULL"); return QK_ERR_INVALID_ARG; }
@@ -218,19 +253,29 @@ int conv_fwd_impl(const qk_conv_desc_t *d, const void *x, const float *w, const 
     g.relu = d->activation == QK_ACT_RELU;
     g.has_bias = d->has_bias ? 1 : 0;
     g.has_mask = 0;
+    const bool with_post = post && post->kind;
     if (d->dtype != QK_F32) {
+        if (with_post && d->layout == QK_CH_LAST && aligned(pre, 16) && aligned(y, 16)) { g.post = *post; g.pre_out = pre; }
         const int r = try_hgemm_16(d->dtype, x, nullptr, w, bias, y, g, false, ws, wsb, stream);
         if (r != 0) return r < 0 ? r : 0;
+        g.post.kind = 0; g.pre_out = nullptr;
     }
     const bool vec = d->layout == QK_CH_LAST && d->cq % 4 == 0 && d->fq % 4 == 0 &&
                      vec_aligned(x, d->dtype) && aligned(w, 16);
     note_path(QK_PATH_FP32_MFMA);
-    return launch_hgemm(d->dtype, x, nullptr, w, bias, y, g, vec, stream);
+    if (!with_post) return launch_hgemm(d->dtype, x, nullptr, w, bias, y, g, vec, stream);
+    // general path: the convolution writes pre, the post-op runs as its own pass
+    if (d->layout != QK_CH_LAST) { set_error("post-op needs channels_last buffers"); return QK_ERR_UNSUPPORTED; }
+    if (int rc = launch_hgemm(d->dtype, x, nullptr, w, bias, pre, g, vec, stream)) return rc;
+    return postop_pass(d->dtype, false, *post, d->batch, d->out_spatial, 4 * d->fq, pre, nullptr, y, nullptr, stream);
 }
 
 int conv_bwd_data_impl(const qk_conv_desc_t *d, const void *dy, const void *y, const float *w, void *dx,
-                       void *ws, size_t wsb, hipStream_t stream, const void *dx_mask = nullptr)
+                       void *ws, size_t wsb, hipStream_t stream, const void *dx_mask = nullptr,
+                       const PostOp *post = nullptr, float *dalpha = nullptr)
 {
+    // post != NULL: dx_mask holds the PRE-activation of x (x = post(x_pre)); dx returns d loss / d x_pre
+    const bool with_post = post && post->kind;
     if (!dy || !w || !dx) { set_error("dy/w/dx must not be NULL"); return QK_ERR_INVALID_ARG; }
     const bool mask = d->activation == QK_ACT_RELU;
     if (mask && !y) { set_error("activation is RELU: the forward output y is required"); return QK_ERR_INVALID_ARG; }
@@ -259,13 +304,18 @@ int conv_bwd_data_impl(const qk_conv_desc_t *d, const void *dy, const void *y, c
     if (d->dtype != QK_F32) {
         // the 16-bit kernels apply an epilogue mask themselves (needs 16-byte aligned rows of dx_mask)
         g.ep_mask = (dx_mask && aligned(dx_mask, 16)) ? dx_mask : nullptr;
+        const bool fuse_post = with_post && g.ep_mask && post->alpha_len <= 256 && d->layout == QK_CH_LAST;
+        if (fuse_post) { g.post = *post; g.dalpha = dalpha; }
+        else if (with_post) g.ep_mask = nullptr;
         const int r = try_hgemm_16(d->dtype, dy, mask ? y : nullptr, w, nullptr, dx, g, true, ws, wsb, stream);
         if (r < 0) return r;
         if (r > 0) {
+            if (with_post && !fuse_post)
+                return postop_pass(d->dtype, true, *post, d->batch, d->in_spatial, 4 * d->cq, dx_mask, dx, dx, dalpha, stream);
             if (dx_mask && !g.ep_mask) return launch_mask_gt0(d->dtype, dx, dx_mask, (size_t)g.M * 4 * d->cq, stream);
             return 0;
         }
-        g.ep_mask = nullptr;
+        g.ep_mask = nullptr; g.post.kind = 0; g.dalpha = nullptr;
     }
     // the fp32-MFMA kernel stages the compact kernel in place with the channel/filter roles swapped
     g.w_swapped = 1;
@@ -273,6 +323,10 @@ int conv_bwd_data_impl(const qk_conv_desc_t *d, const void *dy, const void *y, c
                      vec_aligned(dy, d->dtype) && (!mask || vec_aligned(y, d->dtype));
     note_path(QK_PATH_FP32_MFMA);
     if (int rc = launch_hgemm(d->dtype, dy, mask ? y : nullptr, w, nullptr, dx, g, vec, stream)) return rc;
+    if (with_post) {
+        if (d->layout != QK_CH_LAST) { set_error("post-op needs channels_last buffers"); return QK_ERR_UNSUPPORTED; }
+        return postop_pass(d->dtype, true, *post, d->batch, d->in_spatial, 4 * d->cq, dx_mask, dx, dx, dalpha, stream);
+    }
     if (dx_mask) return launch_mask_gt0(d->dtype, dx, dx_mask, (size_t)g.M * 4 * d->cq, stream);
     return 0;
 }
@@ -411,6 +465,55 @@ int qk_conv_fwd(const qk_conv_desc_t *desc, const void *x, const float *w, const
 {
     if (int rc = validate(desc, false)) return rc;
     return check_launch(conv_fwd_impl(desc, x, w, bias, y, workspace, workspace_bytes, (hipStream_t)stream), "qk_conv_fwd");
+}
+
+int qk_conv_fwd_post(const qk_conv_desc_t *desc, const qk_postop_t *post, const void *x, const float *w,
+                     const float *bias, void *pre, void *y, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (int rc = validate(desc, false)) return rc;
+    if (!post || !pre) { set_error("qk_conv_fwd_post: post / pre must not be NULL"); return QK_ERR_INVALID_ARG; }
+    if (desc->activation != QK_ACT_LINEAR) { set_error("qk_conv_fwd_post: the convolution must be LINEAR (the post-op is the activation)"); return QK_ERR_INVALID_ARG; }
+    PostOp p;
+    if (int rc = to_postop(post, desc->rank, desc->out_spatial, &p)) return rc;
+    return check_launch(conv_fwd_impl(desc, x, w, bias, y, workspace, workspace_bytes, (hipStream_t)stream, &p, pre), "qk_conv_fwd_post");
+}
+
+int qk_conv_bwd_post(const qk_conv_desc_t *desc, const void *x, const void *dy, const float *w, void *dx, float *dw,
+                     float *dbias, const qk_postop_t *post_x, const void *x_pre, float *dalpha_x, void *workspace,
+                     size_t workspace_bytes, void *stream)
+{
+    if (int rc = validate(desc, false)) return rc;
+    if (!dx || !post_x || !x_pre || !dalpha_x) { set_error("qk_conv_bwd_post: dx / post_x / x_pre / dalpha_x must not be NULL"); return QK_ERR_INVALID_ARG; }
+    if (desc->activation != QK_ACT_LINEAR) { set_error("qk_conv_bwd_post: the layer must be LINEAR"); return QK_ERR_INVALID_ARG; }
+    PostOp p;
+    if (int rc = to_postop(post_x, desc->rank, desc->in_spatial, &p)) return rc;
+    const size_t bd = ws_bytes_impl(desc, QK_OP_BWD_DATA);
+    if (bd && (!workspace || workspace_bytes < bd)) { set_error("bwd needs %zu workspace bytes, got %zu", bd, workspace_bytes); return QK_ERR_WORKSPACE; }
+    if (int rc = conv_bwd_weight_impl(desc, x, dy, nullptr, dw, dbias, nullptr, (hipStream_t)stream)) return check_launch(rc, "qk_conv_bwd_post");
+    return check_launch(conv_bwd_data_impl(desc, dy, nullptr, w, dx, workspace, bd, (hipStream_t)stream, x_pre, &p, dalpha_x), "qk_conv_bwd_post");
+}
+
+static int postop_entry(const qk_conv_desc_t *t, const qk_postop_t *post, bool backward, const void *pre, const void *dy,
+                        void *out, float *dalpha, void *stream)
+{
+    if (!t || !post || !pre || !out || (backward && (!dy || !dalpha))) { set_error("post-op: NULL argument"); return QK_ERR_INVALID_ARG; }
+    if (t->rank < 0 || t->rank > 3 || t->batch <= 0 || t->fq <= 0) { set_error("post-op: bad tensor description"); return QK_ERR_INVALID_ARG; }
+    int32_t sp[3] = {1, 1, 1};
+    for (int i = 0; i < t->rank; ++i) { if (t->out_spatial[i] <= 0) { set_error("post-op: bad extent"); return QK_ERR_INVALID_ARG; } sp[i] = t->out_spatial[i]; }
+    PostOp p;
+    if (int rc = to_postop(post, t->rank, sp, &p)) return rc;
+    return check_launch(postop_pass(t->dtype, backward, p, t->batch, sp, 4 * t->fq, pre, dy, out, dalpha, (hipStream_t)stream), "qk_postop");
+}
+
+int qk_postop_fwd(const qk_conv_desc_t *t, const qk_postop_t *post, const void *pre, void *y, void *stream)
+{
+    return postop_entry(t, post, false, pre, nullptr, y, nullptr, stream);
+}
+
+int qk_postop_bwd(const qk_conv_desc_t *t, const qk_postop_t *post, const void *pre, const void *dy, void *dpre,
+                  float *dalpha, void *stream)
+{
+    return postop_entry(t, post, true, pre, dy, dpre, dalpha, stream);
 }
 
 int qk_conv_bwd_data(const qk_conv_desc_t *desc, const void *dy, const void *y, const float *w, void *dx,

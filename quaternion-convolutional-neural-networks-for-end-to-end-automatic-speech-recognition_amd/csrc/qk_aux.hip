@@ -1,5 +1,6 @@
 // Small HBM-bound helpers: the fused Adam step and the tap-folding gather.
 #include "qk_common.h"
+#include "qk_postop.h"
 
 namespace qk {
 namespace {
@@ -160,6 +161,65 @@ int run_maxpool(bool backward, const void *x, const void *dy, void *out, const P
     return hipGetLastError() == hipSuccess ? 0 : QK_ERR_LAUNCH;
 }
 
+
+// ---------------------------------------------------------------------------------------
+// PReLU + Dropout on their own (qk_postop_fwd / qk_postop_bwd): any dtype, HBM-bound.  One thread handles VEC
+// consecutive channels of one row; rows -> alpha index through (stride, extent) of the alpha axis.
+// ---------------------------------------------------------------------------------------
+struct PostDims { long long units; int upr; int key_div; int key_mod; };   // units = rows * upr, upr = units per row
+
+template <typename T, bool BWD>
+__global__ void __launch_bounds__(256)
+k_postop(const T *__restrict__ pre, const T *__restrict__ dy, T *__restrict__ out, float *__restrict__ dalpha,
+         const PostOp p, const PostDims d)
+{
+    constexpr int VEC = sizeof(T) == 2 ? 8 : 4;
+    __shared__ float slab[256];
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (BWD) { slab[tid] = 0.f; __syncthreads(); }
+    for (long long base = (long long)blockIdx.x * 256; base < d.units; base += (long long)gridDim.x * 256) {
+        const long long u = base + tid;
+        const bool ok = u < d.units;
+        int key = 0;
+        float dal = 0.f;
+        if (ok) {
+            const long long row = u / d.upr;
+            if (p.alpha_sel >= 0) key = (int)((row / d.key_div) % d.key_mod);
+            const float alpha = p.alpha[key];
+            const long long e0 = u * VEC;
+            if constexpr (sizeof(T) == 2) {
+                const uint4 q = *reinterpret_cast<const uint4 *>(pre + e0);
+                uint4 r;
+                if constexpr (BWD) r = post_bwd8<T>(*reinterpret_cast<const uint4 *>(dy + e0), q, alpha, (unsigned)e0, p, dal);
+                else r = post_fwd8<T>(q, alpha, (unsigned)e0, p);
+                *reinterpret_cast<uint4 *>(out + e0) = r;
+            } else {
+                const float4 q = *reinterpret_cast<const float4 *>(pre + e0);
+                float v[4] = {q.x, q.y, q.z, q.w}, g[4] = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (BWD) { const float4 t = *reinterpret_cast<const float4 *>(dy + e0); g[0] = t.x; g[1] = t.y; g[2] = t.z; g[3] = t.w; }
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    float ka = 1.f, kb = 1.f;
+                    if (p.drop_thr) { const unsigned h = drop_hash((unsigned)(e0 >> 1) + k, p.drop_seed); ka = drop_factor(h, 0, p); kb = drop_factor(h, 1, p); }
+                    if constexpr (BWD) {
+                        v[2 * k] = post_bwd1(g[2 * k] * ka, v[2 * k], alpha, dal);
+                        v[2 * k + 1] = post_bwd1(g[2 * k + 1] * kb, v[2 * k + 1], alpha, dal);
+                    } else {
+                        v[2 * k] = post_fwd1(v[2 * k], alpha, ka);
+                        v[2 * k + 1] = post_fwd1(v[2 * k + 1], alpha, kb);
+                    }
+                }
+                *reinterpret_cast<float4 *>(out + e0) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+        if constexpr (BWD) wave_add_by_key(dal, key, slab, lane);
+    }
+    if constexpr (BWD) {
+        __syncthreads();
+        if (tid < p.alpha_len && slab[tid] != 0.f) atomicAdd(dalpha + tid, slab[tid]);
+    }
+}
+
 }  // namespace
 
 int launch_mask_gt0(int dtype, void *data, const void *mask, size_t n, hipStream_t stream)
@@ -212,6 +272,24 @@ int launch_adam(float *p, float *g, float *m, float *v, size_t n, float lr, floa
         hipLaunchKernelGGL(k_adam<true>, dim3((unsigned)blocks), dim3(256), 0, stream, p, g, m, v, n, lr_t, b1, b2, eps, gscale);
     else
         hipLaunchKernelGGL(k_adam<false>, dim3((unsigned)blocks), dim3(256), 0, stream, p, g, m, v, n, lr_t, b1, b2, eps, gscale);
+    return hipGetLastError() == hipSuccess ? 0 : QK_ERR_LAUNCH;
+}
+
+
+int launch_postop(int dtype, bool backward, const void *pre, const void *dy, void *out, float *dalpha, const PostOp &p,
+                  long long rows, int channels, int key_div, int key_mod, hipStream_t stream)
+{
+    const int vec = dtype == QK_F32 ? 4 : 8;
+    PostDims d;
+    d.upr = channels / vec; d.units = rows * d.upr; d.key_div = key_div; d.key_mod = key_mod;
+    long long blocks = (d.units + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    if (blocks < 1) blocks = 1;
+#define QK_PO(T, B) hipLaunchKernelGGL((k_postop<T, B>), dim3((unsigned)blocks), dim3(256), 0, stream, (const T *)pre, (const T *)dy, (T *)out, dalpha, p, d)
+    if (dtype == QK_F32) { if (backward) QK_PO(float, true); else QK_PO(float, false); }
+    else if (dtype == QK_BF16) { if (backward) QK_PO(bf16, true); else QK_PO(bf16, false); }
+    else { if (backward) QK_PO(f16, true); else QK_PO(f16, false); }
+#undef QK_PO
     return hipGetLastError() == hipSuccess ? 0 : QK_ERR_LAUNCH;
 }
 

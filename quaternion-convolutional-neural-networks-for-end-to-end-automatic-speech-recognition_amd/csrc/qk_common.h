@@ -33,6 +33,17 @@ constexpr unsigned kSignConj = 0x284Eu;   // transpose: (0,1) (0,2) (0,3) (1,2) 
 // pos(m, t): m -> (n, o0, o1, o2); per axis num = o*pa + t*pb + pc; the tap contributes iff
 // num >= 0, num % pd == 0 and num/pd < isp (zero padding otherwise).
 // ---------------------------------------------------------------------------------------
+// PReLU (+ Dropout) attached to a layer output, see qk_postop.h and qk_postop_t (include/qk.h)
+struct PostOp {
+    int kind;               // 0: none, 1: y = drop(prelu(pre))
+    int alpha_sel;          // -1: scalar alpha[0]; 0 / 1 / 2: alpha indexed by the row's o0 / o1 / o2 (the kernel's axes)
+    int alpha_len;          // entries of alpha (<= 256 on the fused paths)
+    const float *alpha;     // device, float32
+    float drop_scale;       // 1 / (1 - rate); 1 without dropout
+    unsigned drop_thr;      // keep iff hash16 >= drop_thr; 0 = no dropout
+    unsigned drop_seed;
+};
+
 struct GemmGeom {
     int M;              // batch * prod(osp)
     int batch;
@@ -58,6 +69,12 @@ struct GemmGeom {
     // division is ~40 VALU instructions, a tile's prologue decodes 3 - 5 rows with 3 of them each
     unsigned dv_mul[3], dv_shr[3];       // k_hgemm16: by osp[2], osp[1], osp[0];  band: by b_wp, osp[1], osp[0]
     const void *ep_mask;                 // optional epilogue mask: out *= (ep_mask > 0), same layout as out (16-bit kernels)
+    // post-op (16-bit kernels).  forward: out = post(pre), pre = bias + conv is ALSO written to pre_out;
+    // backward-data: ep_mask holds the pre-activation of the tensor whose gradient is produced, out = d pre,
+    // d alpha is accumulated into dalpha
+    PostOp post;
+    void *pre_out;
+    float *dalpha;
     int b_wp, b_nlines, b_cshift, b_rev;
     unsigned b_in_bytes, b_w_bytes;      // extents of the input tensor and of the re-laid-out kernel (buffer resources)
 };
@@ -98,6 +115,7 @@ inline bool band_geom(const GemmGeom &g, int esize, GemmGeom *o)
     o->b_w_bytes = (unsigned)w_bytes;
     o->b_rev = o->pb[2] < 0;
     o->b_cshift = o->b_rev ? o->pc[2] - (k - 1) : o->pc[2];
+    if (o->post.alpha_sel >= 0) o->post.alpha_sel += sh;     // the alpha axis moves with the rotation
     return true;
 }
 
@@ -203,6 +221,8 @@ int launch_fold_taps(int dtype, const void *x, void *xcol, const GemmGeom &g, in
 int launch_mask_gt0(int dtype, void *data, const void *mask, size_t n, hipStream_t stream);   // data *= (mask > 0)
 struct PoolGeom { int batch, ih, iw, C, wh, ww, oh, ow; };
 int launch_maxpool(int dtype, bool backward, const void *x, const void *dy, void *out, const PoolGeom &g, hipStream_t stream);
+int launch_postop(int dtype, bool backward, const void *pre, const void *dy, void *out, float *dalpha, const PostOp &p,
+                  long long rows, int channels, int key_div, int key_mod, hipStream_t stream);
 int launch_adam(float *p, float *g, float *m, float *v, size_t n, float lr, float b1,
                 float b2, float eps, int step, float gscale, bool zero_grad, hipStream_t stream);
 

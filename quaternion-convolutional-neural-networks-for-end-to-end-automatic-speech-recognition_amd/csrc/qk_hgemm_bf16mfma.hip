@@ -22,6 +22,7 @@
 // buffer k feeds the MFMAs, tile k+1 moves registers -> LDS and tile k+2 is in flight from L2/HBM
 // (issue-only loads with clamped addresses; zero fill and the relu mask are applied at LDS-store time).
 #include "qk_common.h"
+#include "qk_postop.h"
 
 namespace qk {
 namespace {
@@ -366,12 +367,35 @@ k_hgemm16(const T *__restrict__ in, const T *__restrict__ mask, const uint4 *__r
     float bia4[4];                                                 // up front: see k_hgemm16_band
 #pragma unroll
     for (int b = 0; b < 4; ++b) bia4[b] = g.has_bias ? bias[b * g.J + j0 + wn * 32 + lr] : 0.f;
+    // post-op (PReLU / dropout, qk_postop.h): forward writes pre and y; backward-data applies the derivative
+    const bool post_on = g.post.kind != 0;
+    const bool post_bwd = post_on && g.ep_mask != nullptr, post_fwd = post_on && g.pre_out != nullptr;
+    float *aslab = reinterpret_cast<float *>(reinterpret_cast<char *>(lds) + 32768);
+    if (post_bwd && g.dalpha) {
+        if (tid < 256) aslab[tid] = 0.f;
+        __syncthreads();
+    }
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        const int ch0 = b * g.J + j0 + wn * 32;
-        const float bia = bia4[b];
+    for (int mt = 0; mt < MT; ++mt) {
+        int a_key[2] = {0, 0};
+        float a_val[2] = {0.f, 0.f}, dal[2] = {0.f, 0.f};
+        if (post_on) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
+            for (int pass = 0; pass < 2; ++pass) {
+                const int m = m0 + (wm * MT + mt) * 32 + e_row + 16 * pass;
+                if (m < g.M && g.post.alpha_sel >= 0) {
+                    const int q2 = fastdiv(m, g.dv_mul[0], g.dv_shr[0]), o2 = m - q2 * g.osp[2];
+                    const int q1 = fastdiv(q2, g.dv_mul[1], g.dv_shr[1]), o1 = q2 - q1 * g.osp[1];
+                    const int nn = fastdiv(q1, g.dv_mul[2], g.dv_shr[2]), o0 = q1 - nn * g.osp[0];
+                    a_key[pass] = g.post.alpha_sel == 0 ? o0 : g.post.alpha_sel == 1 ? o1 : o2;
+                }
+                a_val[pass] = g.post.alpha[a_key[pass]];
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int ch0 = b * g.J + j0 + wn * 32;
+            const float bia = bia4[b];
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {               // registers r, r + 1 hold consecutive rows
                 float v0 = acc[mt][b][r] + bia, v1 = acc[mt][b][r + 1] + bia;
@@ -390,11 +414,27 @@ k_hgemm16(const T *__restrict__ in, const T *__restrict__ mask, const uint4 *__r
                 if (m < g.M) {
                     const long long o = (long long)m * (int)g.out_ss + ch0 + e_chunk * 8;
                     uint4 v = val;
-                    if (g.ep_mask) v = mask8(v, *reinterpret_cast<const uint4 *>(static_cast<const T *>(g.ep_mask) + o));
+                    if (g.ep_mask) {
+                        const uint4 mk = *reinterpret_cast<const uint4 *>(static_cast<const T *>(g.ep_mask) + o);
+                        if (post_bwd) v = post_bwd8<T>(v, mk, a_val[pass], (unsigned)o, g.post, dal[pass]);
+                        else v = mask8(v, mk);
+                    }
+                    if (post_fwd) {
+                        *reinterpret_cast<uint4 *>(static_cast<T *>(g.pre_out) + o) = v;
+                        v = post_fwd8<T>(v, a_val[pass], (unsigned)o, g.post);
+                    }
                     *reinterpret_cast<uint4 *>(out + o) = v;
                 }
             }
         }
+        if (post_bwd && g.dalpha) {
+            wave_add_by_key(dal[0], a_key[0], aslab, lane);
+            wave_add_by_key(dal[1], a_key[1], aslab, lane);
+        }
+    }
+    if (post_bwd && g.dalpha) {
+        __syncthreads();
+        if (tid < g.post.alpha_len && aslab[tid] != 0.f) atomicAdd(g.dalpha + tid, aslab[tid]);
     }
 }
 
@@ -451,7 +491,7 @@ constexpr int band_op(int R, int K, int ti, int k)
 //   TRIM (N = 128, 4 x 1 waves): the band buffer holds exactly BM = 128 rows, so a tile yields BM - (KIN - 1)
 //     output rows and the last KIN - 1 rows of the wave tiles are computed and dropped (3 %): 2 x 128 rows x 256 B
 //     + 2 B tiles = 80 KB is what lets two such workgroups share a CU.
-template <typename T, int WM, int WN, int KIN, bool CONJ, bool TRIM, bool EPM>
+template <typename T, int WM, int WN, int KIN, bool CONJ, bool TRIM, bool EPM, bool POSTF>
 __global__ void __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *__restrict__ zero_line,
                const float *__restrict__ bias, T *__restrict__ out, const GemmGeom g)
@@ -693,6 +733,8 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
     // up front so that their latency hides under the transposes (the staging registers are idle here)
     long long o_row[2];
     bool o_ok[2];
+    int a_key[2] = {0, 0};                                           // post-op: alpha index of the lane's two rows
+    const bool post_on = (EPM || POSTF) && g.post.kind != 0;
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
         const int tr = wm * 32 + e_row + 16 * pass;                  // row inside the tile
@@ -701,6 +743,20 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
         const int u = P - line * WP;
         o_ok[pass] = line < g.b_nlines && u < g.osp[2] && (!TRIM || tr < BMU);
         o_row[pass] = (long long)(line * g.osp[2] + u) * (int)g.out_ss + j0 + wn * 32 + e_chunk * 8;
+        if ((EPM || POSTF) && post_on && g.post.alpha_sel >= 0 && o_ok[pass]) {
+            const int l2 = fastdiv(line, g.dv_mul[1], g.dv_shr[1]), o1 = line - l2 * g.osp[1];
+            const int nn = fastdiv(l2, g.dv_mul[2], g.dv_shr[2]), o0 = l2 - nn * g.osp[0];
+            a_key[pass] = g.post.alpha_sel == 0 ? o0 : g.post.alpha_sel == 1 ? o1 : u;
+        }
+    }
+    float a_val[2] = {0.f, 0.f}, dal[2] = {0.f, 0.f};
+    float *aslab = reinterpret_cast<float *>(reinterpret_cast<char *>(lds) + 32768);   // 256 d-alpha sums (backward post-op)
+    if ((EPM || POSTF) && post_on) {
+        a_val[0] = g.post.alpha[a_key[0]]; a_val[1] = g.post.alpha[a_key[1]];
+        if (EPM && g.dalpha) {
+            if (tid < 256) aslab[tid] = 0.f;
+            __syncthreads();
+        }
     }
     uint4 em[EPM ? 4 : 1][2];
     if (EPM && g.ep_mask) {
@@ -733,9 +789,29 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
             const int row = e_row + 16 * pass;
             uint4 v = *reinterpret_cast<const uint4 *>(ep + row * EP_PITCH + e_chunk * 16);
             if (o_ok[pass]) {
-                if constexpr (EPM) { if (g.ep_mask) v = mask8(v, em[b][pass]); }
-                *reinterpret_cast<uint4 *>(out + o_row[pass] + b * g.J) = v;
+                const long long o = o_row[pass] + b * g.J;
+                if constexpr (EPM) {
+                    if (g.ep_mask) {
+                        if (post_on) v = post_bwd8<T>(v, em[b][pass], a_val[pass], (unsigned)o, g.post, dal[pass]);
+                        else v = mask8(v, em[b][pass]);
+                    }
+                }
+                if constexpr (POSTF) {
+                    if (post_on) {
+                        *reinterpret_cast<uint4 *>(static_cast<T *>(g.pre_out) + o) = v;
+                        v = post_fwd8<T>(v, a_val[pass], (unsigned)o, g.post);
+                    }
+                }
+                *reinterpret_cast<uint4 *>(out + o) = v;
             }
+        }
+    }
+    if constexpr (EPM) {
+        if (post_on && g.dalpha) {                        // d alpha: wave sums by key -> LDS -> one global atomic per key
+            wave_add_by_key(dal[0], a_key[0], aslab, lane);
+            wave_add_by_key(dal[1], a_key[1], aslab, lane);
+            __syncthreads();
+            if (tid < g.post.alpha_len && aslab[tid] != 0.f) atomicAdd(g.dalpha + tid, aslab[tid]);
         }
     }
 }
@@ -748,10 +824,11 @@ int run16_band(const T *in, const uint4 *wq, const T *zero_line, const float *bi
     const int n_mt = (int)(((long long)g.b_nlines * g.b_wp + BMU - 1) / BMU);
     dim3 grid((n_mt + 7) / 8 * 8, g.J / BF, 1);
     // EPM (epilogue mask, QK_BWD_MASK_DX) is its own instantiation: its eight prefetched mask pieces cost 32 VGPRs
-#define QK_GO(C, E) hipLaunchKernelGGL((k_hgemm16_band<T, WM, WN, KIN, C, TRIM, E>), grid, dim3(NTHR), 0, stream, in, wq, zero_line, bias, out, g)
-    const bool conj = g.sign_tbl == kSignConj, epm = g.ep_mask != nullptr;
-    if (conj) { if (epm) QK_GO(true, true); else QK_GO(true, false); }
-    else      { if (epm) QK_GO(false, true); else QK_GO(false, false); }
+    // ... and so is POSTF (forward post-op: PReLU / dropout, pre-activation written beside y)
+#define QK_GO(C, E, P) hipLaunchKernelGGL((k_hgemm16_band<T, WM, WN, KIN, C, TRIM, E, P>), grid, dim3(NTHR), 0, stream, in, wq, zero_line, bias, out, g)
+    const bool conj = g.sign_tbl == kSignConj, epm = g.ep_mask != nullptr, pf = g.post.kind != 0 && g.pre_out != nullptr;
+    if (conj) { if (epm) QK_GO(true, true, false); else if (pf) QK_GO(true, false, true); else QK_GO(true, false, false); }
+    else      { if (epm) QK_GO(false, true, false); else if (pf) QK_GO(false, false, true); else QK_GO(false, false, false); }
 #undef QK_GO
     return hipGetLastError() == hipSuccess ? 1 : QK_ERR_LAUNCH;
 }

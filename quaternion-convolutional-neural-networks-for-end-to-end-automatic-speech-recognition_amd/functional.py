@@ -122,6 +122,30 @@ class _Call(object):
         return dw, db
 
 
+    def fwd_post(self, x, w, bias, post):
+        """(pre, y) = qk_conv_fwd_post: the LINEAR convolution and post(pre) (PReLU / dropout) from one launch."""
+        pre = torch.empty(self.y_shape, dtype=x.dtype, device=x.device)
+        y = torch.empty(self.y_shape, dtype=x.dtype, device=x.device)
+        ws, n = self._ws(L.QK_OP_FWD, x)
+        with _on_device(x.device):
+            rc = L.lib().qk_conv_fwd_post(ctypes.byref(self.desc), ctypes.byref(post.struct), _ptr(x), _ptr(w), _ptr(bias),
+                                          _ptr(pre), _ptr(y), _ptr(ws), n, _stream(x))
+        L.check(rc, 'qk_conv_fwd_post')
+        return pre, y
+
+    def bwd_post(self, x, dy, w, has_bias, post_x, x_pre, dalpha_x):
+        """Fused backward of a LINEAR layer whose input x = post_x(x_pre): returns (d x_pre, dw, db) and accumulates
+        the slope gradient of post_x into dalpha_x (qk_conv_bwd_post)."""
+        dx = torch.empty(self.x_shape, dtype=dy.dtype, device=dy.device)
+        dw = torch.empty(self.w_shape, dtype=torch.float32, device=x.device)
+        db = torch.empty((self.w_shape[-1],), dtype=torch.float32, device=x.device) if has_bias else None
+        ws, n = self._ws(L.QK_OP_BWD, x)
+        with _on_device(x.device):
+            rc = L.lib().qk_conv_bwd_post(ctypes.byref(self.desc), _ptr(x), _ptr(dy), _ptr(w), _ptr(dx), _ptr(dw), _ptr(db),
+                                          ctypes.byref(post_x.struct), _ptr(x_pre), _ptr(dalpha_x), _ptr(ws), n, _stream(x))
+        L.check(rc, 'qk_conv_bwd_post')
+        return dx, dw, db
+
     def bwd(self, x, dy, y, w, has_bias, out=None, flags=0):
         """Fused backward (qk_*_bwd, or qk_*_bwd_chain with L.QK_BWD_* flags): returns (dx, dw, db)."""
         if out is not None:
@@ -142,6 +166,75 @@ class _Call(object):
                                             _ptr(dw), _ptr(db), _ptr(ws), n, _stream(x))
         L.check(rc, name)
         return dx, dw, db
+
+
+class PostOp(object):
+    """PReLU (+ Dropout) behind a quaternion layer (include/qk.h: qk_postop_t).  `alpha`: float32 device tensor, one
+    slope (alpha_axis = -1) or one per position along spatial axis `alpha_axis` of the channels_last activation;
+    `rate`: dropout rate (0 = off); `seed`: 32-bit seed of the counter-based mask (a new one every step)."""
+
+    def __init__(self, alpha, alpha_axis=-1, rate=0.0, seed=0):
+        if alpha.dtype != torch.float32 or not alpha.is_cuda:
+            raise TypeError('PReLU slopes must be float32 device tensors')
+        self.alpha, self.alpha_axis, self.rate, self.seed = alpha, int(alpha_axis), float(rate), int(seed) & 0xffffffff
+        self.flat = alpha.detach().reshape(-1).contiguous()
+        self.struct = L.PostOp(self.alpha_axis, self.flat.numel(), self.flat.data_ptr(), self.rate, self.seed)
+
+
+def _tensor_desc(t):
+    """ConvDesc fields the post-op entry points read, for a channels_last (N, *spatial, 4F) or (M, 4F) tensor."""
+    d = L.ConvDesc()
+    d.rank, d.batch, d.fq, d.dtype = t.dim() - 2, t.shape[0], t.shape[-1] // 4, _DTYPES[t.dtype]
+    for i in range(3):
+        d.out_spatial[i] = t.shape[1 + i] if i < t.dim() - 2 else 1
+    return d
+
+
+def postop_fwd(pre, post):
+    y = torch.empty_like(pre)
+    d = _tensor_desc(pre)
+    with _on_device(pre.device):
+        rc = L.lib().qk_postop_fwd(ctypes.byref(d), ctypes.byref(post.struct), _ptr(pre), _ptr(y), _stream(pre))
+    L.check(rc, 'qk_postop_fwd')
+    return y
+
+
+def postop_bwd(pre, dy, post, dalpha):
+    """d pre (returned) and the slope gradient (accumulated into the float32 buffer `dalpha`)."""
+    dpre = torch.empty_like(pre)
+    d = _tensor_desc(pre)
+    with _on_device(pre.device):
+        rc = L.lib().qk_postop_bwd(ctypes.byref(d), ctypes.byref(post.struct), _ptr(pre), _ptr(dy), _ptr(dpre), _ptr(dalpha),
+                                   _stream(pre))
+    L.check(rc, 'qk_postop_bwd')
+    return dpre
+
+
+class _PostOpFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pre, alpha, post):
+        ctx.post = post
+        ctx.save_for_backward(pre)
+        return postop_fwd(pre, post)
+
+    @staticmethod
+    def backward(ctx, dy):
+        pre, = ctx.saved_tensors
+        post = ctx.post
+        dalpha = torch.zeros(post.flat.numel(), dtype=torch.float32, device=pre.device)
+        dpre = postop_bwd(pre, dy.contiguous(), post, dalpha)
+        return dpre, dalpha.reshape(post.alpha.shape), None
+
+
+def prelu_dropout(x, alpha, alpha_axis=-1, rate=0.0, seed=0):
+    """y = dropout(prelu(x)) in ONE pass over a contiguous channels_last (N, *spatial, C) / (M, C) device tensor
+    (keras PReLU + Dropout, interspeech_model.py:99-101,117-121); alpha: one slope or one per position along spatial
+    axis `alpha_axis`.  The mask is a hash of (seed, element index): nothing is stored, the backward regenerates it."""
+    _require_device(x, 'prelu_dropout')
+    xc = x.contiguous()
+    if xc.shape[-1] % (4 if xc.dtype == torch.float32 else 8) or xc.dim() < 2 or xc.dim() > 5:
+        raise ValueError('prelu_dropout: unsupported shape %s' % (tuple(x.shape),))
+    return _PostOpFn.apply(xc, alpha, PostOp(alpha, alpha_axis, rate, seed))
 
 
 class _HamiltonFn(torch.autograd.Function):
@@ -247,7 +340,7 @@ def dense_call(x_shape, w_shape, dtype, activation=None, use_bias=True):
 
 def quaternion_conv(x, kernel, bias=None, strides=1, padding='valid', data_format='channels_last',
                     dilation_rate=1, activation=None, conj=False, internal_layout='channels_last',
-                    fold_small_cq=True):
+                    fold_small_cq=True, post=None):
     """y = act(W (x) x + b): Hamilton-product convolution of rank kernel.dim()-2.
 
     x       (N, *spatial, 4Cq) or (N, 4Cq, *spatial) -- component-planar channels (r|i|j|k)
@@ -258,6 +351,8 @@ def quaternion_conv(x, kernel, bias=None, strides=1, padding='valid', data_forma
     internal_layout='native' runs the channels_first buffers as they are.
     fold_small_cq: layers with 1-2 quaternion input channels whose input needs no gradient (the first
     layer of a network) are run as a 1x1 convolution on a tap-folded copy of x (qk_conv_fold_taps).
+    post: dict(alpha=, alpha_axis=, rate=, seed=) -- PReLU (+ dropout) behind a LINEAR layer, fused into the
+    kernel epilogues (see quaternion_conv_chain); alpha_axis counts the spatial axes of the layer output.
     """
     _require_device(x, 'quaternion_conv')
     rank = kernel.dim() - 2
@@ -266,9 +361,16 @@ def quaternion_conv(x, kernel, bias=None, strides=1, padding='valid', data_forma
     taps, cq = int(math.prod(kernel.shape[:rank])), kernel.shape[-2]
     if x.shape[0] == 0:
         return _empty_batch(x, kernel, bias, rank, strides, padding, data_format, dilation_rate)
+    if post is not None and internal_layout != 'channels_last':
+        raise ValueError('a post-op needs internal_layout="channels_last"')
     if fold_small_cq and cq <= 2 and taps > 1 and taps * cq <= 64 and not x.requires_grad and not conj:
         return _folded_conv(x, kernel, bias, rank, strides, padding, data_format, dilation_rate, activation,
-                            internal_layout)
+                            internal_layout, post)
+    if post is not None:
+        xl = x.movedim(1, -1) if ch_first else x
+        y = quaternion_conv_chain(xl, [(kernel, bias, dict(strides=strides, padding=padding, dilation_rate=dilation_rate,
+                                                           activation=activation, conj=conj, post=post))])
+        return y.movedim(-1, 1) if ch_first else y
     if ch_first and internal_layout == 'channels_last':
         xp = x.movedim(1, -1).contiguous()
         layout = 'channels_last'
@@ -299,7 +401,8 @@ def _empty_batch(x, kernel, bias, rank, strides, padding, data_format, dilation_
     return y + tie
 
 
-def _folded_conv(x, kernel, bias, rank, strides, padding, data_format, dilation_rate, activation, internal_layout):
+def _folded_conv(x, kernel, bias, rank, strides, padding, data_format, dilation_rate, activation, internal_layout,
+                 post=None):
     ch_first = data_format == 'channels_first'
     xp = x.contiguous()
     taps, cq = int(math.prod(kernel.shape[:rank])), kernel.shape[-2]
@@ -317,7 +420,7 @@ def _folded_conv(x, kernel, bias, rank, strides, padding, data_format, dilation_
     L.check(rc, 'qk_conv_fold_taps')
     w2 = torch.nn.functional.pad(kernel.reshape(taps * cq, kernel.shape[-1]), (0, 0, 0, cq2 - taps * cq))
     w2 = w2.reshape((1,) * rank + (cq2, kernel.shape[-1]))
-    y = quaternion_conv(xcol, w2, bias, 1, 'valid', 'channels_last', 1, activation, False, 'channels_last', False)
+    y = quaternion_conv(xcol, w2, bias, 1, 'valid', 'channels_last', 1, activation, False, 'channels_last', False, post)
     return y.movedim(-1, 1) if ch_first else y
 
 
@@ -386,59 +489,89 @@ def maxpool2d_supported(x, window, strides):
 
 
 class _ConvChainFn(torch.autograd.Function):
-    """A run of quaternion convolutions applied back to back (y_i = act_i(W_i (x) y_{i-1} + b_i)) as ONE
-    autograd node, so that the backward knows the structure: where layer i-1 ends in a fused relu, layer
-    i's backward-data returns its input gradient already multiplied by (y_{i-1} > 0) (epilogue of the
-    kernel, QK_BWD_MASK_DX) and layer i-1 runs its backward without the relu mask and without reading
-    y_{i-1} again (QK_BWD_DY_PREMASKED).  Gradients are identical to the layer-by-layer form."""
+    """A run of quaternion convolutions applied back to back as ONE autograd node, so that the backward knows the
+    structure.  Each layer ends in a fused relu (y_i = relu(W_i (x) y_{i-1} + b_i)), is linear, or carries a POST-OP
+    (y_i = dropout(prelu(pre_i)), pre_i written beside y_i by the same launch):
+      * relu: layer i+1's backward-data returns its input gradient already multiplied by (y_i > 0) (epilogue of the
+        kernel, QK_BWD_MASK_DX) and layer i runs its backward without the mask and without reading y_i again
+        (QK_BWD_DY_PREMASKED);
+      * post-op: layer i+1's backward-data epilogue turns d y_i into d pre_i (dropout mask regenerated from the seed,
+        PReLU derivative from pre_i) and accumulates d alpha_i (qk_conv_bwd_post); only the LAST layer's post-op needs
+        a pass of its own (qk_postop_bwd).
+    Gradients are identical to the layer-by-layer form."""
 
     @staticmethod
-    def forward(ctx, x, calls, *params):
+    def forward(ctx, x, calls, posts, *params):
         n = len(calls)
-        ws, bs = params[:n], params[n:]
-        acts = [x]
-        for call, w, b in zip(calls, ws, bs):
-            acts.append(call.fwd(acts[-1], w, b))
-        ctx.calls = calls
+        ws, bs, alphas = params[:n], params[n:2 * n], params[2 * n:]
+        acts, pres = [x], []
+        for call, w, b, post in zip(calls, ws, bs, posts):
+            if post is None:
+                acts.append(call.fwd(acts[-1], w, b))
+                pres.append(None)
+            else:
+                pre, y = call.fwd_post(acts[-1], w, b, post)
+                acts.append(y)
+                pres.append(pre)
+        ctx.calls, ctx.posts = calls, posts
         ctx.has_bias = [b is not None for b in bs]
-        ctx.save_for_backward(*acts, *ws)
+        ctx.n_pre = [p is not None for p in pres]
+        ctx.save_for_backward(*acts, *ws, *[p for p in pres if p is not None])
         return acts[-1]
 
     @staticmethod
     def backward(ctx, dy):
-        calls = ctx.calls
+        calls, posts = ctx.calls, ctx.posts
         n = len(calls)
         saved = ctx.saved_tensors
-        acts, ws = saved[:n + 1], saved[n + 1:]
-        dy = dy.contiguous()
-        dws, dbs = [None] * n, [None] * n
+        acts, ws = saved[:n + 1], saved[n + 1:2 * n + 1]
+        it = iter(saved[2 * n + 1:])
+        pres = [next(it) if has else None for has in ctx.n_pre]
+        g = dy.contiguous()
+        dws, dbs, das = [None] * n, [None] * n, [None] * n
+        for i, post in enumerate(posts):
+            if post is not None:
+                das[i] = torch.zeros(post.flat.numel(), dtype=torch.float32, device=g.device)
+        if posts[n - 1] is not None:                      # the last post-op has no consumer inside the chain
+            g = postop_bwd(pres[n - 1], g, posts[n - 1], das[n - 1])
         for i in range(n - 1, -1, -1):
+            if i > 0 and posts[i - 1] is not None:
+                g, dws[i], dbs[i] = calls[i].bwd_post(acts[i], g, ws[i], ctx.has_bias[i], posts[i - 1], pres[i - 1], das[i - 1])
+                continue
             flags = 0
             if i > 0 and calls[i - 1].relu:
                 flags |= L.QK_BWD_MASK_DX
             if i < n - 1 and calls[i].relu:
                 flags |= L.QK_BWD_DY_PREMASKED
-            dy, dws[i], dbs[i] = calls[i].bwd(acts[i], dy, acts[i + 1], ws[i], ctx.has_bias[i], flags=flags)
-        return (dy, None) + tuple(dws) + tuple(dbs)
+            g, dws[i], dbs[i] = calls[i].bwd(acts[i], g, acts[i + 1], ws[i], ctx.has_bias[i], flags=flags)
+        das = [None if d is None else d.reshape(p.alpha.shape) for d, p in zip(das, posts)]
+        return (g, None, None) + tuple(dws) + tuple(dbs) + tuple(das)
 
 
 def quaternion_conv_chain(x, layers):
     """Apply consecutive quaternion convolutions as one autograd node (see _ConvChainFn).
     `layers`: sequence of (kernel, bias, kwargs) with the keyword arguments of quaternion_conv
-    (strides, padding, dilation_rate, activation ('relu' / 'linear' / None), conj); x and every layer are
-    channels_last here -- channels_first callers pass the channels-last view and move the axis back."""
+    (strides, padding, dilation_rate, activation ('relu' / 'linear' / None), conj) and optionally
+    post=dict(alpha=<float32 tensor>, alpha_axis=-1|0|1|2, rate=<dropout rate>, seed=<int>): PReLU (+ dropout) behind
+    a LINEAR layer; x and every layer are channels_last here -- channels_first callers pass the channels-last view
+    and move the axis back."""
     _require_device(x, 'quaternion_conv_chain')
     xp = x.contiguous()
-    calls, ws, bs = [], [], []
+    calls, ws, bs, posts, alphas = [], [], [], [], []
     shape = tuple(xp.shape)
     for kernel, bias, kw in layers:
         rank = kernel.dim() - 2
         _check_weights(kernel, bias, kernel.shape[-1])
+        po = kw.get('post')
+        if po is not None and kw.get('activation') not in (None, 'linear'):
+            raise ValueError('a layer with a post-op must be linear (the post-op is its activation)')
         call = conv_call(shape, tuple(kernel.shape), xp.dtype, rank, kw.get('strides', 1), kw.get('padding', 'valid'),
                          'channels_last', kw.get('dilation_rate', 1), kw.get('activation'), bias is not None,
                          bool(kw.get('conj', False)))
         calls.append(call)
         ws.append(kernel.contiguous())
         bs.append(bias)
+        posts.append(None if po is None else PostOp(po['alpha'], po.get('alpha_axis', -1), po.get('rate', 0.0), po.get('seed', 0)))
+        alphas.append(None if po is None else po['alpha'])
         shape = tuple(call.y_shape)
-    return _ConvChainFn.apply(xp, tuple(calls), *ws, *bs)
+    return _ConvChainFn.apply(xp, tuple(calls), tuple(posts), *ws, *bs, *alphas)

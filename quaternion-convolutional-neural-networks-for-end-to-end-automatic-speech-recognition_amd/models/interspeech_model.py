@@ -42,13 +42,35 @@ class TimitQCNN(torch.nn.Module):
         n_act = 1 + len(widths) + 3
         self.prelu = torch.nn.ModuleList([PReLU(shared_axes=[1, 0]) for _ in range(n_act)]) if aact == 'prelu' else None
         self.drop = Dropout(dropout)
+        self._drop_seed, self._drop_calls, self._zero_alpha, self._dev = 0x5EED, 0, None, None
         self.pred = TimeDistributed(Dense(62, activation='softmax', kernel_regularizer=reg, use_bias=True,
                                           bias_initializer='zeros', kernel_initializer='random_uniform'))
 
     def _act(self, x, i):
         return self.prelu[i](x) if self.prelu is not None else x
 
+    # ---- PReLU / Dropout fused into the kernels (functional.quaternion_conv_chain post-ops) ----------------------
+    def _post(self, k, out_shape, dropout=True):
+        """Post-op spec of activation slot k behind a quaternion layer whose (channels_first / TimeDistributed) output
+        shape is `out_shape`: the PReLU slopes of self.prelu[k] (built here: (1, F, 1) behind a convolution, i.e. one
+        per position of spatial axis 0 of the channels-last buffer; (1, 1) behind a dense layer) and the dropout rate
+        while training, with a fresh mask seed per call."""
+        rate = self.rate if (dropout and self.training) else 0.0
+        self._drop_calls += 1
+        seed = (self._drop_seed + 7919 * self._drop_calls) & 0xffffffff
+        pl = self.prelu[k]
+        if not pl.built:
+            pl._build_device = self._dev
+            pl.build(tuple(out_shape))
+        axis = 0 if pl.alpha.numel() > 1 else -1
+        return dict(alpha=pl.alpha, alpha_axis=axis, rate=rate, seed=seed)
+
     def forward(self, x):
+        self._dev = x.device
+        fused_post = (self.prelu is not None and self.chain_convs and x.is_cuda and x.dtype in (torch.bfloat16, torch.float16, torch.float32)
+                      and not os.environ.get('QK_NO_FUSED_PRELU'))
+        if fused_post:
+            return self._forward_fused_prelu(x)
         o = self._act(self.conv(x), 0)
         o = self.pool(o)
         k = 1
@@ -75,6 +97,49 @@ class TimitQCNN(torch.nn.Module):
             k += 1
             if i < 2:
                 o = self.drop(o)
+        return self.pred(o)
+
+    def _forward_fused_prelu(self, x):
+        """aact == 'prelu' (interspeech_model.py:55-56,99-101,117-121: linear layers, PReLU(shared_axes=[1,0]) and
+        Dropout behind each) with both fused into the quaternion kernels: the producing kernel writes the
+        pre-activation and the activated / dropped tensor, the next layer's backward-data applies the derivative."""
+        from .. import functional as Fq
+        from ..keras_like import activations
+        c = self.conv
+        if not c.built:
+            c._build_device = x.device
+            c.build(tuple(x.shape))
+        shape = c.compute_output_shape(tuple(x.shape))
+        o = Fq.quaternion_conv(x, c.kernel, c.bias, strides=c.strides, padding=c.padding, data_format='channels_first',
+                               dilation_rate=c.dilation_rate, activation=None, post=self._post(0, shape, dropout=False))
+        o = self.pool(o)
+        shape = tuple(o.shape)
+        layers = []
+        for i, cv in enumerate(self.convs):
+            if not cv.built:
+                cv._build_device = x.device
+                cv.build(shape)
+            shape = cv.compute_output_shape(shape)
+            layers.append((cv.kernel, cv.bias, dict(strides=cv.strides, padding=cv.padding, dilation_rate=cv.dilation_rate,
+                                                    activation=None, post=self._post(1 + i, shape))))
+        k = 1 + len(self.convs)
+        dl, w = self._head_kernel(shape, x.device)
+        head_shape = (shape[0], dl.r.shape[-1], shape[3])                       # (B, units, T): TimeDistributed output, channels_first view
+        layers.append((w, dl.bias, dict(strides=1, padding='valid', dilation_rate=1, activation=None, conj=True,
+                                        post=self._post(k, (shape[0], shape[3], dl.r.shape[-1])))))
+        y = Fq.quaternion_conv_chain(o.movedim(1, -1), layers)                  # (B, 1, T, units)
+        o = y.reshape(y.shape[0], y.shape[2], y.shape[3])
+        k += 1
+        for i in (1, 2):
+            dn = self.dense[i].layer
+            b, t = o.shape[0], o.shape[1]
+            if not dn.built:
+                dn._build_device = x.device
+                dn.build((None, o.shape[2]))
+            h = Fq.quaternion_dense(o.reshape(b * t, o.shape[2]), dn.r, dn.bias, activation=None).reshape(b, t, -1)
+            po = self._post(k, (b, t, h.shape[-1]), dropout=(i < 2))
+            o = Fq.prelu_dropout(h, po['alpha'], po['alpha_axis'], po['rate'], po['seed'])
+            k += 1
         return self.pred(o)
 
     def _head_kernel(self, o_shape, device):

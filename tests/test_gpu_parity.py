@@ -796,3 +796,111 @@ def test_cfg5_stack_full_size_16bit_kernels_agree_with_exact_fp32_kernels():
         assert err <= (1e-2 if i == 0 else 3e-2), 'tensor %d: rel err %.3g' % (i, err)
         ssum = abs(float(a.double().sum()) - float(e.double().sum())) / float(e.double().abs().sum())
         assert ssum <= 1e-3, 'tensor %d: checksum drift %.3g' % (i, ssum)
+
+
+# ---- post-ops: PReLU + Dropout fused into the kernels (interspeech_model.py:99-101,117-121) ----------------------------
+def _np_drop_factor(shape, seed, rate):
+    """The counter-based dropout mask of csrc/qk_postop.h restated in numpy: one 32-bit hash per element PAIR of
+    the flat channels_last tensor, 16 bits per element, keep iff value >= round(rate * 65536); scale 1 / (1 - rate)."""
+    if rate == 0:
+        return np.ones(shape)
+    n = int(np.prod(shape))
+    idx = np.arange(n, dtype=np.uint64)
+    M = np.uint64(0xffffffff)
+    h = ((idx >> np.uint64(1)) ^ np.uint64(seed)) * np.uint64(0x9E3779B1) & M
+    h ^= h >> np.uint64(15); h = h * np.uint64(0x85EBCA77) & M
+    h ^= h >> np.uint64(13); h = h * np.uint64(0xC2B2AE3D) & M
+    h ^= h >> np.uint64(16)
+    v = np.where(idx & np.uint64(1), h >> np.uint64(16), h & np.uint64(0xffff))
+    thr = min(int(rate * 65536 + 0.5), 65535)
+    return (np.where(v >= thr, 1.0 / (1.0 - rate), 0.0)).reshape(shape)
+
+
+def _np_post(pre, alpha_b, keep):
+    return (np.maximum(pre, 0) + alpha_b * np.minimum(pre, 0)) * keep
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16], ids=['fp32', 'bf16', 'fp16'])
+@pytest.mark.parametrize('shape,axis', [((3, 5, 7, 16), 0), ((2, 6, 9, 32), 1), ((4, 11, 24), -1), ((50, 64), -1)],
+                         ids=['axis0', 'axis1', 'scalar3d', 'scalar2d'])
+def test_prelu_dropout_op_matches_numpy(shape, axis, dtype):
+    """qk_postop_fwd / qk_postop_bwd on their own: values, d input, d alpha, with and without dropout."""
+    import qcnn_amd
+    F = qcnn_amd.functional
+    dev = _dev()
+    rng = np.random.RandomState(43)
+    rnd = lambda a: torch.tensor(a).to(dtype).double().numpy()
+    x = rnd(rng.randn(*shape))
+    dy = rnd(rng.randn(*shape))
+    alen = shape[1 + axis] if axis >= 0 else 1
+    alpha = (0.05 + 0.3 * rng.rand(alen)).astype(np.float32)
+    ab = alpha.astype(np.float64).reshape([alen if (axis >= 0 and i == 1 + axis) else 1 for i in range(len(shape))]) if axis >= 0 else alpha.astype(np.float64)[0]
+    for rate, seed in ((0.0, 0), (0.3, 12345)):
+        keep = _np_drop_factor(shape, seed, rate)
+        want = _np_post(x, ab, keep)
+        g = dy * keep
+        want_dx = np.where(x > 0, g, np.where(x < 0, ab * g, 0.0))
+        red = tuple(i for i in range(len(shape)) if not (axis >= 0 and i == 1 + axis))
+        want_da = (g * np.minimum(x, 0)).sum(axis=red).reshape(-1)
+        xt = torch.tensor(x, device=dev).to(dtype).requires_grad_(True)
+        at = torch.tensor(alpha, device=dev, requires_grad=True)
+        y = F.prelu_dropout(xt, at, axis, rate, seed)
+        y.backward(torch.tensor(dy, device=dev).to(dtype))
+        tol = 1e-6 if dtype == torch.float32 else (1e-2 if dtype == torch.bfloat16 else 2e-3)
+        assert _rel_err(y.detach().float().cpu().numpy(), want) <= tol
+        assert _rel_err(xt.grad.float().cpu().numpy(), want_dx) <= tol
+        assert _rel_err(at.grad.cpu().numpy(), want_da) <= max(tol / 10, 1e-5)
+        if rate:
+            frac = float((keep == 0).mean())
+            assert abs(frac - rate) < 0.05, frac               # the hash drops about `rate` of the elements
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['fp32', 'bf16'])
+@pytest.mark.parametrize('rate', [0.0, 0.25], ids=['nodrop', 'drop'])
+def test_conv_chain_with_prelu_dropout_matches_oracle_composition(dtype, rate):
+    """quaternion_conv_chain with post-ops (qk_conv_fwd_post / qk_conv_bwd_post: PReLU slopes per position of spatial
+    axis 0, dropout masks regenerated from the seed) against the oracle's LINEAR layers + the numpy post-op:
+    values, d input, every kernel / bias / slope gradient.  32 -> 32 -> 64 (band kernels), then a conj 'valid' head."""
+    import qcnn_amd
+    from oracle import oracle
+    F = qcnn_amd.functional
+    dev = _dev()
+    rng = np.random.RandomState(47)
+    rnd = (lambda a: a) if dtype == torch.float32 else (lambda a: torch.tensor(a).to(dtype).double().numpy())
+    specs = [((3, 5, 32, 128), dict(padding='same', activation=None), 0),
+             ((3, 5, 32, 256), dict(padding='same', activation=None), 0),
+             ((6, 1, 64, 128), dict(padding='valid', activation=None, conj=True), -1)]
+    x = rnd(rng.randn(2, 6, 40, 128).astype(np.float32).astype(np.float64))
+    ws = [rnd((rng.randn(*s) / np.sqrt(np.prod(s[:-1]) * 4)).astype(np.float32).astype(np.float64)) for s, _, _ in specs]
+    bs = [(0.1 * rng.randn(s[-1])).astype(np.float32).astype(np.float64) for s, _, _ in specs]
+    alphas = [(0.05 + 0.3 * rng.rand(6 if ax == 0 else 1)).astype(np.float32) for _, _, ax in specs]
+    seeds = [101, 202, 303]
+    acts, pres, keeps = [x], [], []
+    for w, b, (_, kw, ax), al, sd in zip(ws, bs, specs, alphas, seeds):
+        pre = rnd(oracle.forward(acts[-1], w, b, 2, **kw))
+        keep = _np_drop_factor(pre.shape, sd, rate)
+        ab = al.astype(np.float64).reshape(1, -1, 1, 1) if ax == 0 else float(al[0])
+        pres.append(pre); keeps.append(keep)
+        acts.append(rnd(_np_post(pre, ab, keep)))
+    dy = rnd(rng.randn(*acts[-1].shape).astype(np.float32).astype(np.float64))
+    xt = torch.tensor(x, device=dev).to(dtype).requires_grad_(True)
+    wt = [torch.tensor(w, device=dev, dtype=torch.float32, requires_grad=True) for w in ws]
+    bt = [torch.tensor(b, device=dev, dtype=torch.float32, requires_grad=True) for b in bs]
+    at = [torch.tensor(a, device=dev, requires_grad=True) for a in alphas]
+    layers = [(wt[i], bt[i], dict(specs[i][1], post=dict(alpha=at[i], alpha_axis=specs[i][2], rate=rate, seed=seeds[i]))) for i in range(3)]
+    y = F.quaternion_conv_chain(xt, layers)
+    y.backward(torch.tensor(dy, device=dev).to(dtype))
+    tol_y, tol_g = (1e-4, 2e-4) if dtype == torch.float32 else (1e-2, 3e-2)
+    assert _rel_err(y.detach().float().cpu().numpy(), acts[-1]) <= tol_y
+    g = dy
+    for i in reversed(range(3)):
+        ax = specs[i][2]
+        ab = alphas[i].astype(np.float64).reshape(1, -1, 1, 1) if ax == 0 else float(alphas[i][0])
+        gk = g * keeps[i]
+        want_da = (gk * np.minimum(pres[i], 0)).sum(axis=(0, 2, 3)) if ax == 0 else np.array([(gk * np.minimum(pres[i], 0)).sum()])
+        dpre = np.where(pres[i] > 0, gk, np.where(pres[i] < 0, ab * gk, 0.0))
+        g, dw, db = oracle.backward(acts[i], ws[i], bs[i], dpre, 2, **specs[i][1])
+        assert _rel_err(wt[i].grad.cpu().numpy(), dw) <= tol_g, 'dkernel %d' % i
+        assert _rel_err(bt[i].grad.cpu().numpy(), db) <= tol_g, 'dbias %d' % i
+        assert _rel_err(at[i].grad.cpu().numpy(), want_da) <= tol_g, 'dalpha %d' % i
+    assert _rel_err(xt.grad.float().cpu().numpy(), g) <= tol_g
