@@ -511,6 +511,21 @@ def main():
         except Exception as e:
             out['hamilton_gemm'] = {'error': repr(e)}
         if not args.no_extras:
+            try:        # the reference's own activation setting: linear layers + PReLU + Dropout(0.3), fused post-ops
+                pcfg = dict(WORKLOADS['cfg3_qcnn_prelu_dropout_b256_bf16'], activation='prelu')
+                pj = ModelTrainStep(pcfg, dev, 0, 1)
+                el = timed_steps(pj, 30, 5, 2, barrier, 1, dev, dist)
+                ptf = 3 * pj.flops_per_kernel / (el / 30) / 1e12
+                out['qcnn_prelu_dropout_step'] = {'workload': 'cfg3_qcnn_prelu_dropout_b256_bf16', 'steps': 30, 'warmup': 5,
+                                                  'pre_warmup_steps': 2, 'ms_per_step': 1e3 * el / 30,
+                                                  'samples_per_s': pcfg['batch'] * 30 / el, 'tflops': ptf,
+                                                  'frac_of_peak': ptf / PEAK_TFLOPS['bf16'],
+                                                  'note': 'aact=prelu, dropout=0.3 (interspeech_model.py:99-137): dense (no exact zeros) '
+                                                          'activations and gradients -- the chip clocks lower than on the relu variant'}
+                del pj
+                torch.cuda.empty_cache()
+            except Exception as e:
+                out['qcnn_prelu_dropout_step'] = {'error': repr(e)}
             try:        # BASELINE configs[1]: the single QuaternionConv1D layer, step + kernels
                 c2 = dict(WORKLOADS['cfg2_qconv1d_timit_b64_fp32'], activation='relu')
                 j2 = LayerTrainStep(c2, dev, 0, 1)

@@ -201,7 +201,8 @@ int qk_dense_bwd_chain(const qk_dense_desc_t *desc, const void *x, const void *d
  * `alpha_axis` (0 .. rank-1) of the tensor -- what Keras builds for shared_axes=[1,0] on a channels_first (C, F, T)
  * activation is (1, F, 1): alpha_axis = 0, alpha_len = F.  The dropout mask is never stored: keep(e) is a hash of
  * (drop_seed, flat element index of y in its channels_last buffer), identical in forward and backward; pass a new
- * seed every step.  drop_rate = 0 disables dropout. */
+ * seed every step.  Each element gets 8 random bits: the rate applied is round(drop_rate * 256) / 256 (the kept
+ * elements are scaled by the reciprocal of THAT keep probability).  drop_rate = 0 disables dropout. */
 typedef struct {
     int32_t alpha_axis;      /* -1: scalar; 0..2: spatial axis of the activation that indexes alpha       */
     int32_t alpha_len;       /* 1 for a scalar, else the extent of that axis                                */

@@ -188,8 +188,9 @@ int to_postop(const qk_postop_t *q, int rank, const int32_t *sp, PostOp *p)
     if (q->alpha_len != want) { set_error("post-op: alpha_len %d, expected %d", q->alpha_len, want); return QK_ERR_INVALID_ARG; }
     p->kind = 1; p->alpha_sel = q->alpha_axis; p->alpha_len = q->alpha_len; p->alpha = q->alpha;
     p->drop_scale = 1.f / (1.f - q->drop_rate);
-    unsigned thr = (unsigned)(q->drop_rate * 65536.f + 0.5f);
-    p->drop_thr = thr > 65535u ? 65535u : thr;
+    unsigned thr = (unsigned)(q->drop_rate * 256.f + 0.5f);      // 8 random bits per element: rates are multiples of 1/256
+    p->drop_thr = thr > 255u ? 255u : thr;
+    p->drop_scale = p->drop_thr ? 256.f / (256.f - (float)p->drop_thr) : 1.f;   // the scale of the rate actually applied
     p->drop_seed = q->drop_seed;
     return 0;
 }

@@ -197,10 +197,13 @@ k_postop(const T *__restrict__ pre, const T *__restrict__ dy, T *__restrict__ ou
                 const float4 q = *reinterpret_cast<const float4 *>(pre + e0);
                 float v[4] = {q.x, q.y, q.z, q.w}, g[4] = {0.f, 0.f, 0.f, 0.f};
                 if constexpr (BWD) { const float4 t = *reinterpret_cast<const float4 *>(dy + e0); g[0] = t.x; g[1] = t.y; g[2] = t.z; g[3] = t.w; }
+                unsigned rb[2] = {0u, 0u};
+                if (p.drop_thr) drop_bits8((unsigned)(e0 >> 3), p.drop_seed, rb[0], rb[1]);
+                const unsigned bits = rb[(e0 >> 2) & 1];                   // this thread's 4 elements: half a unit
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
                     float ka = 1.f, kb = 1.f;
-                    if (p.drop_thr) { const unsigned h = drop_hash((unsigned)(e0 >> 1) + k, p.drop_seed); ka = drop_factor(h, 0, p); kb = drop_factor(h, 1, p); }
+                    if (p.drop_thr) { ka = drop_factor(bits, 2 * k, p); kb = drop_factor(bits, 2 * k + 1, p); }
                     if constexpr (BWD) {
                         v[2 * k] = post_bwd1(g[2 * k] * ka, v[2 * k], alpha, dal);
                         v[2 * k + 1] = post_bwd1(g[2 * k + 1] * kb, v[2 * k + 1], alpha, dal);

@@ -40,7 +40,7 @@ struct PostOp {
     int alpha_len;          // entries of alpha (<= 256 on the fused paths)
     const float *alpha;     // device, float32
     float drop_scale;       // 1 / (1 - rate); 1 without dropout
-    unsigned drop_thr;      // keep iff hash16 >= drop_thr; 0 = no dropout
+    unsigned drop_thr;      // keep iff the element's 8 random bits >= drop_thr (= round(rate * 256)); 0 = no dropout
     unsigned drop_seed;
 };
 

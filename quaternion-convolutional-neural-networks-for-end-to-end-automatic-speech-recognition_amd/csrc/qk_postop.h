@@ -11,26 +11,27 @@
 // alpha is either one scalar or one slope per position along ONE spatial axis of the layer output (what Keras'
 // `shared_axes=[1, 0]` yields for a channels_first (C, F, T) tensor: (1, F, 1), see layers.PReLU).  The dropout mask
 // is not stored: it is a counter-based hash of (seed, flat element index of y in its channels-last buffer), evaluated
-// again in the backward.  One hash serves two neighbouring elements (16 bits each).
+// again in the backward.  One hash (+ one extra mixing round) serves the 8 elements of a 16-byte unit, 8 bits each:
+// keep iff bits >= round(rate * 256).
 #pragma once
 #include "qk_common.h"
 
 namespace qk {
 
-__device__ __forceinline__ unsigned drop_hash(unsigned pair_index, unsigned seed)
+// 64 random bits for the 8 elements of unit `unit_index` (= flat index / 8): 8 bits per element, keep iff >= drop_thr
+__device__ __forceinline__ void drop_bits8(unsigned unit_index, unsigned seed, unsigned &lo, unsigned &hi)
 {
-    unsigned h = (pair_index ^ seed) * 0x9E3779B1u;
+    unsigned h = (unit_index ^ seed) * 0x9E3779B1u;
     h ^= h >> 15; h *= 0x85EBCA77u;
     h ^= h >> 13; h *= 0xC2B2AE3Du;
-    h ^= h >> 16;
-    return h;
+    lo = h ^ (h >> 16);
+    hi = (lo ^ 0x68E31DA4u) * 0xB5297A4Du;
+    hi ^= hi >> 15;
 }
-
-// scale factor of element `e` (0 / 1) of the pair whose hash is h: 0 when dropped
-__device__ __forceinline__ float drop_factor(unsigned h, int e, const PostOp &p)
+// scale factor of element e (0..3) of the half-unit whose bits are `bits`: 0 when dropped
+__device__ __forceinline__ float drop_factor(unsigned bits, int e, const PostOp &p)
 {
-    const unsigned v = e ? (h >> 16) : (h & 0xffffu);
-    return v >= p.drop_thr ? p.drop_scale : 0.f;
+    return ((bits >> (8 * e)) & 0xffu) >= p.drop_thr ? p.drop_scale : 0.f;
 }
 
 template <typename T> __device__ __forceinline__ void unpack2(unsigned u, float &a, float &b);
@@ -60,26 +61,27 @@ __device__ __forceinline__ unsigned repack2(f16, float a, float b)
 
 __device__ __forceinline__ float post_fwd1(float v, float alpha, float keep)
 {
-    return (v > 0.f ? v : alpha * v) * keep;
+    return (fmaxf(v, 0.f) + alpha * fminf(v, 0.f)) * keep;
 }
 // d pre and the slope-gradient term of one element; g = dy * keep
 __device__ __forceinline__ float post_bwd1(float g, float pre, float alpha, float &dal)
 {
-    dal += pre < 0.f ? g * pre : 0.f;
-    return pre > 0.f ? g : (pre < 0.f ? alpha * g : 0.f);
+    dal = fmaf(g, fminf(pre, 0.f), dal);
+    return g * (pre > 0.f ? 1.f : (pre < 0.f ? alpha : 0.f));
 }
 
 // 8 consecutive 16-bit elements starting at flat index `idx` (a multiple of 8)
 template <typename T>
 __device__ __forceinline__ uint4 post_fwd8(const uint4 &pre, float alpha, unsigned idx, const PostOp &p)
 {
-    unsigned in[4] = {pre.x, pre.y, pre.z, pre.w}, out[4];
+    unsigned in[4] = {pre.x, pre.y, pre.z, pre.w}, out[4], rb[2] = {0u, 0u};
+    if (p.drop_thr) drop_bits8(idx >> 3, p.drop_seed, rb[0], rb[1]);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         float a, b;
         unpack2<T>(in[k], a, b);
         float ka = 1.f, kb = 1.f;
-        if (p.drop_thr) { const unsigned h = drop_hash((idx >> 1) + k, p.drop_seed); ka = drop_factor(h, 0, p); kb = drop_factor(h, 1, p); }
+        if (p.drop_thr) { ka = drop_factor(rb[k >> 1], 2 * (k & 1), p); kb = drop_factor(rb[k >> 1], 2 * (k & 1) + 1, p); }
         out[k] = repack2(T(), post_fwd1(a, alpha, ka), post_fwd1(b, alpha, kb));
     }
     return make_uint4(out[0], out[1], out[2], out[3]);
@@ -88,13 +90,14 @@ __device__ __forceinline__ uint4 post_fwd8(const uint4 &pre, float alpha, unsign
 template <typename T>
 __device__ __forceinline__ uint4 post_bwd8(const uint4 &dy, const uint4 &pre, float alpha, unsigned idx, const PostOp &p, float &dal)
 {
-    unsigned g[4] = {dy.x, dy.y, dy.z, dy.w}, q[4] = {pre.x, pre.y, pre.z, pre.w}, out[4];
+    unsigned g[4] = {dy.x, dy.y, dy.z, dy.w}, q[4] = {pre.x, pre.y, pre.z, pre.w}, out[4], rb[2] = {0u, 0u};
+    if (p.drop_thr) drop_bits8(idx >> 3, p.drop_seed, rb[0], rb[1]);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         float ga, gb, pa, pb;
         unpack2<T>(g[k], ga, gb);
         unpack2<T>(q[k], pa, pb);
-        if (p.drop_thr) { const unsigned h = drop_hash((idx >> 1) + k, p.drop_seed); ga *= drop_factor(h, 0, p); gb *= drop_factor(h, 1, p); }
+        if (p.drop_thr) { ga *= drop_factor(rb[k >> 1], 2 * (k & 1), p); gb *= drop_factor(rb[k >> 1], 2 * (k & 1) + 1, p); }
         out[k] = repack2(T(), post_bwd1(ga, pa, alpha, dal), post_bwd1(gb, pb, alpha, dal));
     }
     return make_uint4(out[0], out[1], out[2], out[3]);
@@ -103,17 +106,38 @@ __device__ __forceinline__ uint4 post_bwd8(const uint4 &dy, const uint4 &pre, fl
 // Sum `v` over the lanes of the wave that share `key` and add each sum to slab[key] (LDS, float) -- a tile's rows
 // belong to one or two positions of the alpha axis, so this is one or two rounds of a butterfly reduction and one
 // LDS atomic each, instead of 64 atomics on the same word.
+// sum over the 64 lanes with DPP row shifts / broadcasts (no LDS traffic): lane 63 ends up with the total
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ float dpp_add(float v)
+{
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, BANK_MASK, false));
+}
+__device__ __forceinline__ float wave_sum_to_lane63(float v)
+{
+    v = dpp_add<0x111, 0xf, 0xf>(v);     // row_shr:1
+    v = dpp_add<0x112, 0xf, 0xf>(v);     // row_shr:2
+    v = dpp_add<0x114, 0xf, 0xe>(v);     // row_shr:4 (banks 1-3)
+    v = dpp_add<0x118, 0xf, 0xc>(v);     // row_shr:8 (banks 2-3)
+    v = dpp_add<0x142, 0xa, 0xf>(v);     // row_bcast:15 into rows 1, 3
+    v = dpp_add<0x143, 0xc, 0xf>(v);     // row_bcast:31 into rows 2, 3
+    return v;
+}
+
 __device__ __forceinline__ void wave_add_by_key(float v, int key, float *slab, int lane)
 {
+    const int k0 = __builtin_amdgcn_readfirstlane(key);
+    if (__builtin_amdgcn_ballot_w64(key != k0) == 0) {                 // the usual case: one key in the wave
+        const float s = wave_sum_to_lane63(v);
+        if (lane == 63) atomicAdd(&slab[k0], s);
+        return;
+    }
     unsigned long long todo = __builtin_amdgcn_ballot_w64(true);
     while (todo) {
         const int first = __builtin_ctzll(todo);
         const int k = __builtin_amdgcn_readlane(key, first);
         const bool mine = key == k;
-        float s = mine ? v : 0.f;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-        if (lane == first) atomicAdd(&slab[k], s);
+        const float s = wave_sum_to_lane63(mine ? v : 0.f);
+        if (lane == 63) atomicAdd(&slab[k], s);
         todo &= ~__builtin_amdgcn_ballot_w64(mine);
     }
 }

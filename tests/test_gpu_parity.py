@@ -800,20 +800,25 @@ def test_cfg5_stack_full_size_16bit_kernels_agree_with_exact_fp32_kernels():
 
 # ---- post-ops: PReLU + Dropout fused into the kernels (interspeech_model.py:99-101,117-121) ----------------------------
 def _np_drop_factor(shape, seed, rate):
-    """The counter-based dropout mask of csrc/qk_postop.h restated in numpy: one 32-bit hash per element PAIR of
-    the flat channels_last tensor, 16 bits per element, keep iff value >= round(rate * 65536); scale 1 / (1 - rate)."""
+    """The counter-based dropout mask of csrc/qk_postop.h restated in numpy: one 32-bit hash (+ one extra mixing round)
+    per 16-byte unit of 8 elements of the flat channels_last tensor, 8 bits per element, keep iff bits >= round(rate * 256);
+    kept elements are scaled by 256 / (256 - thr)."""
     if rate == 0:
         return np.ones(shape)
     n = int(np.prod(shape))
     idx = np.arange(n, dtype=np.uint64)
     M = np.uint64(0xffffffff)
-    h = ((idx >> np.uint64(1)) ^ np.uint64(seed)) * np.uint64(0x9E3779B1) & M
+    h = ((idx >> np.uint64(3)) ^ np.uint64(seed)) * np.uint64(0x9E3779B1) & M
     h ^= h >> np.uint64(15); h = h * np.uint64(0x85EBCA77) & M
     h ^= h >> np.uint64(13); h = h * np.uint64(0xC2B2AE3D) & M
-    h ^= h >> np.uint64(16)
-    v = np.where(idx & np.uint64(1), h >> np.uint64(16), h & np.uint64(0xffff))
-    thr = min(int(rate * 65536 + 0.5), 65535)
-    return (np.where(v >= thr, 1.0 / (1.0 - rate), 0.0)).reshape(shape)
+    lo = h ^ (h >> np.uint64(16))
+    hi = (lo ^ np.uint64(0x68E31DA4)) * np.uint64(0xB5297A4D) & M
+    hi ^= hi >> np.uint64(15)
+    e = idx & np.uint64(7)
+    word = np.where(e < 4, lo, hi)
+    v = (word >> (np.uint64(8) * (e & np.uint64(3)))) & np.uint64(0xff)
+    thr = min(int(rate * 256 + 0.5), 255)
+    return (np.where(v >= thr, 256.0 / (256.0 - thr), 0.0)).reshape(shape)
 
 
 def _np_post(pre, alpha_b, keep):
