@@ -230,6 +230,22 @@ int qk_postop_fwd(const qk_conv_desc_t *t, const qk_postop_t *post, const void *
 int qk_postop_bwd(const qk_conv_desc_t *t, const qk_postop_t *post, const void *pre, const void *dy, void *dpre,
                   float *dalpha, void *stream);
 
+/* The first layer of the TIMIT model as ONE kernel per direction (models/interspeech_model.py:97-103):
+ *     QuaternionConv2D(F, (3,5), padding='same', relu) on ONE quaternion channel -> MaxPooling2D over the first
+ *     spatial axis with window = stride = `pool`, 'same' (partial last window).
+ * The layer is HBM-bound; fused, the forward reads x (N, H, W, 4) and writes only the pooled tensor
+ * (N, ceil(H / pool), W, 4F) plus `aux` (2 bits per pooled element: which window row held the maximum, or "relu
+ * killed it"), the backward reads x, the pooled gradient and aux and returns dw / dbias (overwritten) -- the 537 MB
+ * pre-pool activation of the B = 256 model never exists.  Supported: rank 2, QK_CH_LAST, bf16 / fp16, cq == 1, kernel
+ * (3,5), unit stride / dilation, pad_lo (1,2), activation RELU, conj 0, fq % 32 == 0, pool == 3; anything else returns
+ * QK_ERR_UNSUPPORTED (qk_conv_relu_pool_aux_bytes: 0) and the caller runs qk_conv_fwd + qk_maxpool2d_* instead.
+ * `aux` may be NULL in the forward (inference). */
+size_t qk_conv_relu_pool_aux_bytes(const qk_conv_desc_t *desc, int32_t pool);
+int qk_conv_relu_pool_fwd(const qk_conv_desc_t *desc, int32_t pool, const void *x, const float *w, const float *bias,
+                          void *pooled, void *aux, void *stream);
+int qk_conv_relu_pool_bwd(const qk_conv_desc_t *desc, int32_t pool, const void *x, const void *dpooled, const void *aux,
+                          float *dw, float *dbias, void *stream);
+
 /* Tap folding for layers with very few input channels (the first TIMIT layer has cq = 1: K = 4*taps).
  *   xcol[m, a*cq2 + t*cq + c] = x[pos(m, t), a*cq + c]      (0 in the padding and for t*cq + c >= taps*cq)
  * xcol is channels_last (N, *out_spatial, 4*cq2), cq2 a multiple of 8 with cq2 >= taps*cq.  The layer

@@ -614,6 +614,50 @@ int qk_dense_bwd_weight(const qk_dense_desc_t *desc, const void *x, const void *
     return check_launch(conv_bwd_weight_impl(&c, x, dy, y, dw, dbias, dym, (hipStream_t)stream), "qk_dense_bwd_weight");
 }
 
+static bool conv1_pool_ok(const qk_conv_desc_t *d, int32_t pool)
+{
+    return d->rank == 2 && d->layout == QK_CH_LAST && (d->dtype == QK_BF16 || d->dtype == QK_F16) && d->cq == 1 &&
+           d->kernel[0] == 3 && d->kernel[1] == 5 && d->stride[0] == 1 && d->stride[1] == 1 && d->dilation[0] == 1 &&
+           d->dilation[1] == 1 && d->pad_lo[0] == 1 && d->pad_lo[1] == 2 && d->out_spatial[0] == d->in_spatial[0] &&
+           d->out_spatial[1] == d->in_spatial[1] && d->activation == QK_ACT_RELU && d->conj == 0 && d->fq % 32 == 0 && pool == 3 &&
+           (long long)d->batch * ((d->in_spatial[0] + 2) / 3) * d->in_spatial[1] * 4 * d->fq < INT_MAX;
+}
+
+size_t qk_conv_relu_pool_aux_bytes(const qk_conv_desc_t *desc, int32_t pool)
+{
+    if (validate(desc, false) || !conv1_pool_ok(desc, pool)) return 0;
+    return conv1_pool_argbits_bytes(desc->batch, desc->in_spatial[0], desc->in_spatial[1], desc->fq);
+}
+
+int qk_conv_relu_pool_fwd(const qk_conv_desc_t *desc, int32_t pool, const void *x, const float *w, const float *bias,
+                          void *pooled, void *aux, void *stream)
+{
+    if (int rc = validate(desc, false)) return rc;
+    if (!conv1_pool_ok(desc, pool)) { set_error("qk_conv_relu_pool: geometry outside the fused first-layer kernel (see include/qk.h)"); return QK_ERR_UNSUPPORTED; }
+    if (!x || !w || !pooled || (desc->has_bias && !bias)) { set_error("qk_conv_relu_pool_fwd: NULL argument"); return QK_ERR_INVALID_ARG; }
+    if (!aligned(x, 8) || !aligned(pooled, 16) || (aux && !aligned(aux, 16))) { set_error("qk_conv_relu_pool_fwd: alignment"); return QK_ERR_INVALID_ARG; }
+    note_path(QK_PATH_MFMA16);
+    return check_launch(launch_conv1_pool(desc->dtype, false, x, w, bias, pooled, aux, nullptr, nullptr, desc->batch, desc->in_spatial[0],
+                                          desc->in_spatial[1], desc->fq, desc->has_bias, (hipStream_t)stream), "qk_conv_relu_pool_fwd");
+}
+
+int qk_conv_relu_pool_bwd(const qk_conv_desc_t *desc, int32_t pool, const void *x, const void *dpooled, const void *aux,
+                          float *dw, float *dbias, void *stream)
+{
+    if (int rc = validate(desc, false)) return rc;
+    if (!conv1_pool_ok(desc, pool)) { set_error("qk_conv_relu_pool: geometry outside the fused first-layer kernel (see include/qk.h)"); return QK_ERR_UNSUPPORTED; }
+    if (!x || !dpooled || !aux || !dw || (desc->has_bias && !dbias)) { set_error("qk_conv_relu_pool_bwd: NULL argument"); return QK_ERR_INVALID_ARG; }
+    if (!aligned(x, 8) || !aligned(dpooled, 16) || !aligned(aux, 16)) { set_error("qk_conv_relu_pool_bwd: alignment"); return QK_ERR_INVALID_ARG; }
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(dw, 0, w_floats(desc) * sizeof(float), st) != hipSuccess ||
+        (desc->has_bias && hipMemsetAsync(dbias, 0, 4 * (size_t)desc->fq * sizeof(float), st) != hipSuccess)) {
+        set_error("memset dw failed"); return QK_ERR_LAUNCH;
+    }
+    note_path(QK_PATH_MFMA16);
+    return check_launch(launch_conv1_pool(desc->dtype, true, x, nullptr, nullptr, dpooled, const_cast<void *>(aux), dw, desc->has_bias ? dbias : nullptr,
+                                          desc->batch, desc->in_spatial[0], desc->in_spatial[1], desc->fq, desc->has_bias, st), "qk_conv_relu_pool_bwd");
+}
+
 int qk_conv_fold_taps(const qk_conv_desc_t *desc, const void *x, void *xcol, int32_t cq2, void *stream)
 {
     if (int rc = validate(desc, false)) return rc;

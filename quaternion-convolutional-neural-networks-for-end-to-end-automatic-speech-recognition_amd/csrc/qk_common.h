@@ -221,6 +221,9 @@ int launch_fold_taps(int dtype, const void *x, void *xcol, const GemmGeom &g, in
 int launch_mask_gt0(int dtype, void *data, const void *mask, size_t n, hipStream_t stream);   // data *= (mask > 0)
 struct PoolGeom { int batch, ih, iw, C, wh, ww, oh, ow; };
 int launch_maxpool(int dtype, bool backward, const void *x, const void *dy, void *out, const PoolGeom &g, hipStream_t stream);
+size_t conv1_pool_argbits_bytes(int N, int H, int W, int F);
+int launch_conv1_pool(int dtype, bool backward, const void *x, const float *w, const float *bias, const void *io, void *argbits,
+                      float *dw, float *dbias, int N, int H, int W, int F, int has_bias, hipStream_t stream);
 int launch_postop(int dtype, bool backward, const void *pre, const void *dy, void *out, float *dalpha, const PostOp &p,
                   long long rows, int channels, int key_div, int key_mod, hipStream_t stream);
 int launch_adam(float *p, float *g, float *m, float *v, size_t n, float lr, float b1,

@@ -1,0 +1,385 @@
+// First layer of the TIMIT model as ONE kernel per direction (models/interspeech_model.py:97-103 of the reference):
+//
+//     QuaternionConv2D(F, (3,5), 'same', relu) on ONE quaternion input channel  ->  MaxPooling2D((1,3), 'same')
+//                                                                                   (pools the frequency axis)
+//
+// The layer is HBM-bound (K = 4 x 15, 58 FLOP per byte of its 537 MB output), and as separate launches it moves
+// 2.4 GB forward (tap-folded copy of x, y, pooled y) and 1.6 GB backward for 17 MB of input and 184 MB of pooled
+// output.  Here the forward reads x and writes ONLY the pooled tensor plus 2 bits per pooled element (which of the
+// window's rows held the maximum; 3 = the relu killed it: 23 MB); the backward reads x, the pooled gradient and those
+// bits, rebuilds dy in registers and accumulates the kernel / bias gradient there -- y never exists in memory.
+//
+// Geometry: x (N, H, W, 4) channels_last (r,i,j,k of the one channel), kernel (KH, KW, 1, 4F), taps KH*KW <= 16;
+// pooled (N, ceil(H / PH), W, 4F).  A workgroup of 7 waves owns one pooled line segment (n, ho, 224 positions of
+// W); a wave owns 32 consecutive positions x (4 components x 32 filters).  The x patch (PH + KH - 1 rows x 228
+// positions x 8 B) sits in LDS, zero padded.
+//   forward MFMA   y_b[pos, f] += A_a[pos, tap] * W_{a^b}[tap, f]   v_mfma_f32_32x32x16: K = the 16 (15 + 1 zero) taps
+//   backward MFMA  dW_p[tap, f] += x_a[pos, tap]^T * (+-dy_b)[pos, f]   K = positions, two 16-deep steps per tile;
+//                  dy of row tile fi = dpool where fi is the window's arg-max (first maximum wins) and max + bias > 0.
+// Fragments are assembled from 8-byte LDS reads (all four components of one position) with v_perm_b32.
+#include "qk_common.h"
+
+namespace qk {
+namespace {
+
+typedef __bf16 c1_bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 c1_f16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ floatx16 c1_mfma(bf16, const uint4 &a, const uint4 &b, const floatx16 &c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(c1_bf16x8, a), __builtin_bit_cast(c1_bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ floatx16 c1_mfma(f16, const uint4 &a, const uint4 &b, const floatx16 &c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(c1_f16x8, a), __builtin_bit_cast(c1_f16x8, b), c, 0, 0, 0);
+}
+typedef float c1_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned c1_pack(bf16, float a, float b)
+{
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    const c1_f2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, b2));
+}
+__device__ __forceinline__ unsigned c1_pack(f16, float a, float b)
+{
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const c1_f2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, h2));
+}
+__device__ __forceinline__ uint4 c1_neg(const uint4 &v)
+{
+    return make_uint4(v.x ^ 0x80008000u, v.y ^ 0x80008000u, v.z ^ 0x80008000u, v.w ^ 0x80008000u);
+}
+
+struct C1Geom {
+    int N, H, W, F;            // x (N, H, W, 4); F quaternion filters (output channels 4F)
+    int Ho;                    // ceil(H / PH)
+    int n_chunks;              // ceil(W / 224)
+    int n_lines;               // N * Ho * n_chunks   (work items)
+    int has_bias;
+};
+
+constexpr int C1_TW = 224;                 // positions per workgroup (7 waves x 32)
+constexpr int C1_PW = C1_TW + 4 + 4;       // patch width in positions (KW - 1 <= 4 halo, + slack for the tap-15 clamp)
+
+// Everything the two kernels share: patch staging, fragment assembly.
+template <typename T, int KH, int KW, int PH>
+struct C1 {
+    static constexpr int TAPS = KH * KW, NR = PH + KH - 1, PADH = (KH - 1) / 2, PADW = (KW - 1) / 2;
+    static_assert(TAPS <= 16 && KW - 1 <= 4, "one 16-deep MFMA step holds the taps");
+    static constexpr int PATCH_BYTES = NR * C1_PW * 8;
+
+    // x rows [PH*ho - PADH, +NR) x positions [t0 - PADW, +C1_PW) of sample n -> LDS, zeros outside the tensor
+    static __device__ __forceinline__ void stage_patch(const T *__restrict__ x, char *patch, const C1Geom &g, int n, int ho, int t0, int tid, int nthr)
+    {
+        const int f_lo = PH * ho - PADH;
+        for (int e0 = tid; e0 < NR * C1_PW; e0 += nthr) {
+            int e = e0;
+            asm volatile("" : "+v"(e));                            // (opaque, see k_conv1_pool_bwd)
+            const int r = e / C1_PW, c = e - r * C1_PW;
+            const int f = f_lo + r, t = t0 - PADW + c;
+            uint2 v = make_uint2(0u, 0u);
+            if (f >= 0 && f < g.H && t >= 0 && t < g.W)
+                v = *reinterpret_cast<const uint2 *>(x + (((long long)n * g.H + f) * g.W + t) * 4);
+            *reinterpret_cast<uint2 *>(patch + e * 8) = v;
+        }
+    }
+    // byte offset (relative to the lane's position) of tap k inside the patch; taps >= TAPS are clamped (their B row is zero)
+    static __device__ __forceinline__ int tap_off(int k)
+    {
+        k = k < TAPS ? k : TAPS - 1;
+        const int df = k / KW, dt = k - df * KW;
+        return (df * C1_PW + dt) * 8;
+    }
+    // the four per-component fragments of 8 positions-or-taps worth of 8-byte reads: element i of component a
+    static __device__ __forceinline__ void split4(const uint2 (&v)[8], uint4 (&A)[4])
+    {
+        unsigned lo[4], hi[4], lo2[4], hi2[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            lo[j] = __builtin_amdgcn_perm(v[2 * j + 1].x, v[2 * j].x, 0x05040100u);    // component 0 of elements 2j, 2j+1
+            hi[j] = __builtin_amdgcn_perm(v[2 * j + 1].x, v[2 * j].x, 0x07060302u);    // component 1
+            lo2[j] = __builtin_amdgcn_perm(v[2 * j + 1].y, v[2 * j].y, 0x05040100u);   // component 2
+            hi2[j] = __builtin_amdgcn_perm(v[2 * j + 1].y, v[2 * j].y, 0x07060302u);   // component 3
+        }
+        A[0] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+        A[1] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+        A[2] = make_uint4(lo2[0], lo2[1], lo2[2], lo2[3]);
+        A[3] = make_uint4(hi2[0], hi2[1], hi2[2], hi2[3]);
+    }
+    // compact kernel -> the four per-part B fragments of this lane (column = filter j0 + lr, K = taps 8 lh .. 8 lh + 7)
+    static __device__ __forceinline__ void load_w(const float *__restrict__ w, int F, int f, int lh, uint4 (&B)[4])
+    {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            unsigned d[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k0 = 8 * lh + 2 * j, k1 = k0 + 1;
+                const float a = k0 < TAPS ? w[(k0 * 4 + p) * F + f] : 0.f;
+                const float b = k1 < TAPS ? w[(k1 * 4 + p) * F + f] : 0.f;
+                d[j] = c1_pack(T(), a, b);
+            }
+            B[p] = make_uint4(d[0], d[1], d[2], d[3]);
+        }
+    }
+    // A fragments of row tile fi from the lane's 8 tap reads, then the conv values of component b: acc (32 positions x 32 filters)
+    static __device__ __forceinline__ void tap_frags(const char *lane_base, const int (&toff)[8], int fi, uint4 (&A)[4])
+    {
+        uint2 v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const uint2 *>(lane_base + fi * (C1_PW * 8) + toff[i]);
+        split4(v, A);
+    }
+    static __device__ __forceinline__ floatx16 conv_b(const uint4 (&A)[4], const uint4 (&B)[4], int b)
+    {
+        floatx16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const bool ng = (kSignConv >> (a * 4 + b)) & 1u;
+            acc = c1_mfma(T(), A[a], ng ? c1_neg(B[a ^ b]) : B[a ^ b], acc);
+        }
+        return acc;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T, int KH, int KW, int PH>
+__global__ void __launch_bounds__(448) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_conv1_pool_fwd(const T *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias, T *__restrict__ out,
+                 uint4 *__restrict__ argbits, const C1Geom g)
+{
+    typedef C1<T, KH, KW, PH> K;
+    constexpr int EP_PITCH = 80;
+    __shared__ __attribute__((aligned(16))) char lds[K::PATCH_BYTES + 7 * 32 * EP_PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 31, lh = lane >> 5;
+    const int item = blockIdx.x;                                  // (n, ho, chunk)
+    const int chunk = item % g.n_chunks, line = item / g.n_chunks;
+    const int ho = line % g.Ho, n = line / g.Ho;
+    const int t0 = chunk * C1_TW;
+    const int j0 = blockIdx.y * 32;
+    K::stage_patch(x, lds, g, n, ho, t0, tid, 448);
+    uint4 B[4];
+    K::load_w(w, g.F, j0 + lr, lh, B);
+    int toff[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) toff[i] = K::tap_off(8 * lh + i);
+    __syncthreads();
+
+    const int tw = t0 + wave * 32;                                // first position of this wave's tile
+    if (tw < g.W) {
+        const char *lane_base = lds + (wave * 32 + lr) * 8;
+        // window maximum and WHICH row tile holds it (first maximum wins, as in TF / torch): 2 bits per element, kept for
+        // the backward (argbits: 16 bytes per lane and tile); 3 = nothing flows back (relu: max + bias <= 0)
+        floatx16 pooled[4];
+        unsigned argw[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int fi = 0; fi < PH; ++fi) {
+            if (PH * ho + fi >= g.H) break;                       // partial last window ('same' pooling: high side only)
+            uint4 A[4];
+            K::tap_frags(lane_base, toff, fi, A);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const floatx16 acc = K::conv_b(A, B, b);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    if (fi == 0) pooled[b][r] = acc[r];
+                    else {
+                        const bool up = acc[r] > pooled[b][r];
+                        pooled[b][r] = up ? acc[r] : pooled[b][r];
+                        argw[b] = up ? ((argw[b] & ~(3u << (2 * r))) | ((unsigned)fi << (2 * r))) : argw[b];
+                    }
+                }
+            }
+        }
+        // relu(max + bias) (== max of relu(conv + bias)), transpose through LDS, 16-byte stores
+        char *ep = lds + K::PATCH_BYTES + wave * (32 * EP_PITCH);
+        const int e_row = lane >> 2, e_chunk = lane & 3;
+        float bia4[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) bia4[b] = g.has_bias ? bias[b * g.F + j0 + lr] : 0.f;
+        if (argbits) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) argw[b] |= pooled[b][r] + bia4[b] > 0.f ? 0u : (3u << (2 * r));
+            argbits[(((long long)blockIdx.y * g.n_lines + item) * 7 + wave) * 64 + lane] = make_uint4(argw[0], argw[1], argw[2], argw[3]);
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const float v0 = fmaxf(pooled[b][r] + bia4[b], 0.f), v1 = fmaxf(pooled[b][r + 1] + bia4[b], 0.f);
+                const unsigned pk = c1_pack(T(), v0, v1);
+                char *dst = ep + mfma32_row(r, lane) * EP_PITCH + lr * 2;
+                *reinterpret_cast<unsigned short *>(dst) = (unsigned short)pk;
+                *reinterpret_cast<unsigned short *>(dst + EP_PITCH) = (unsigned short)(pk >> 16);
+            }
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) {
+                const int row = e_row + 16 * pass;
+                const uint4 v = *reinterpret_cast<const uint4 *>(ep + row * EP_PITCH + e_chunk * 16);
+                const int t = tw + row;
+                if (t < g.W)
+                    *reinterpret_cast<uint4 *>(out + (((long long)n * g.Ho + ho) * g.W + t) * (4 * g.F) + b * g.F + j0 + e_chunk * 8) = v;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T, int KH, int KW, int PH>
+__global__ void __launch_bounds__(448) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_conv1_pool_bwd(const T *__restrict__ x, const T *__restrict__ dout, const uint4 *__restrict__ argbits,
+                 float *__restrict__ dw, float *__restrict__ dbias, const C1Geom g)
+{
+    typedef C1<T, KH, KW, PH> K;
+    constexpr int DP_PITCH = 4 * 32 * 2 + 16;                     // one dpool row of this column tile: 4 components x 32 filters (+ pad)
+    __shared__ __attribute__((aligned(16))) char lds[K::PATCH_BYTES + 7 * 32 * DP_PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 31, lh = lane >> 5;
+    const int j0 = blockIdx.y * 32;
+    // backward A operand (x^T): this lane's row = tap lr & 15 (lanes 16 - 31 repeat them; their accumulator rows are ignored)
+    const int my_tap_off = K::tap_off(lr & 15);
+    floatx16 dwacc[4];                                            // [part p]: rows = taps, columns = filters
+    float dbacc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dwacc[p][r] = 0.f;
+
+    // One pooled line segment per workgroup (a persistent loop over segments kept ~50 loop-invariant address values
+    // alive across iterations and spilled them; 2 K atomics per workgroup on 2 K addresses cost less than that).
+    {
+        const int item = blockIdx.x;
+        const int chunk = item % g.n_chunks, line = item / g.n_chunks;
+        const int ho = line % g.Ho, n = line / g.Ho;
+        const int t0 = chunk * C1_TW;
+        K::stage_patch(x, lds, g, n, ho, t0, tid, 448);
+        // this wave's dpool tile: 32 positions x (4 x 32) channels, rows past W are zero
+        char *dp = lds + K::PATCH_BYTES + wave * (32 * DP_PITCH);
+        const int tw = t0 + wave * 32;
+#pragma unroll 2
+        for (int u0 = lane; u0 < 32 * 16; u0 += 64) {              // 16-byte units: row u / 16, (component, 8 filters) u % 16
+            int u = u0;
+            asm volatile("" : "+v"(u));                            // (opaque: the per-iteration addresses must not be hoisted out
+                                                                   //  of the persistent loop as eight 64-bit values -- they spilled)
+            const int row = u >> 4, q = u & 15, b = q >> 2, sub = (q & 3) * 8;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (tw + row < g.W)
+                v = *reinterpret_cast<const uint4 *>(dout + (((long long)n * g.Ho + ho) * g.W + tw + row) * (4 * g.F) + b * g.F + j0 + sub);
+            *reinterpret_cast<uint4 *>(dp + row * DP_PITCH + (b * 32 + sub) * 2) = v;
+        }
+        uint4 aw = make_uint4(~0u, ~0u, ~0u, ~0u);                // 3 everywhere: nothing flows
+        if (tw < g.W) aw = argbits[(((long long)blockIdx.y * g.n_lines + item) * 7 + wave) * 64 + lane];
+        const unsigned argw[4] = {aw.x, aw.y, aw.z, aw.w};
+        __syncthreads();
+        const int n_fi = tw < g.W ? min(PH, g.H - PH * ho) : 0;
+        // accumulator row 4 lh + ..., column lr of this wave's tile, as ONE opaque LDS byte offset (a pointer would turn
+        // generic behind the asm and cost flat loads with 64-bit addresses)
+        int dp_off = K::PATCH_BYTES + wave * (32 * DP_PITCH) + 4 * lh * DP_PITCH + lr * 2;
+        asm volatile("" : "+v"(dp_off));
+#pragma unroll 1
+        for (int fi = 0; fi < n_fi; ++fi) {                        // dy of row tile fi (where fi is the window's arg-max), dW += x^T dy
+            // x^T fragments: row = this lane's tap, K slot i of step s = position 16 s + 4 lh + (i & 3) + 8 (i >> 2)
+            uint4 XT[2][4];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                uint2 v[8];
+                const char *xb = lds + (wave * 32 + 16 * s + 4 * lh) * 8 + fi * (C1_PW * 8) + my_tap_off;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const uint2 *>(xb + ((i & 3) + 8 * (i >> 2)) * 8);
+                K::split4(v, XT[s]);
+            }
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                __builtin_amdgcn_sched_barrier(0);                 // (one component at a time: all 64 LDS reads hoisted up front spill)
+                unsigned d[8];                                     // dy of component b, K = positions in accumulator order
+                float sum = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    // (one per-lane base + compile-time offsets: 64 separately hoisted addresses spilled)
+                    const char *src = lds + dp_off + ((r & 3) + 8 * (r >> 2)) * DP_PITCH + b * 64;
+                    const unsigned v0 = *reinterpret_cast<const unsigned short *>(src);
+                    const unsigned v1 = *reinterpret_cast<const unsigned short *>(src + DP_PITCH);
+                    const unsigned g0 = ((argw[b] >> (2 * r)) & 3u) == (unsigned)fi ? v0 : 0u;
+                    const unsigned g1 = ((argw[b] >> (2 * r + 2)) & 3u) == (unsigned)fi ? v1 : 0u;
+                    d[r >> 1] = g0 | (g1 << 16);
+                    sum += to_f32(__builtin_bit_cast(T, (unsigned short)g0)) + to_f32(__builtin_bit_cast(T, (unsigned short)g1));
+                }
+                dbacc[b] += sum;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const uint4 dy = make_uint4(d[4 * s], d[4 * s + 1], d[4 * s + 2], d[4 * s + 3]);
+                    const uint4 dyn = c1_neg(dy);
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        const bool ng = (kSignConv >> (a * 4 + b)) & 1u;
+                        dwacc[a ^ b] = c1_mfma(T(), XT[s][a], ng ? dyn : dy, dwacc[a ^ b]);
+                    }
+                }
+            }
+        }
+    }
+    // ---- flush: the seven waves' gradients are summed in LDS (taps = accumulator rows 0 .. 15 = registers 0 .. 7, columns =
+    // filters), then one atomic per element and workgroup
+    __syncthreads();
+    float *slab = reinterpret_cast<float *>(lds);                 // [part 4][tap 16][filter 32] + [component 4][filter 32]
+    for (int e = tid; e < 4 * 16 * 32 + 4 * 32; e += 448) slab[e] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int r = 0; r < 8; ++r) atomicAdd(&slab[(p * 16 + mfma32_row(r, lane)) * 32 + lr], dwacc[p][r]);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) atomicAdd(&slab[4 * 16 * 32 + b * 32 + lr], dbacc[b]);
+    __syncthreads();
+    for (int e = tid; e < 4 * 16 * 32; e += 448) {
+        const int f = e & 31, tap = (e >> 5) & 15, p = e >> 9;
+        if (tap < K::TAPS) atomicAdd(dw + (tap * 4 + p) * g.F + j0 + f, slab[e]);
+    }
+    if (dbias && tid < 128) atomicAdd(dbias + (tid >> 5) * g.F + j0 + (tid & 31), slab[4 * 16 * 32 + tid]);
+}
+
+template <typename T>
+int run_conv1_pool(bool backward, const void *x, const float *w, const float *bias, const void *io, void *argbits, float *dw,
+                   float *dbias, const C1Geom &g, hipStream_t stream)
+{
+    if (!backward) {
+        dim3 grid((unsigned)g.n_lines, (unsigned)(g.F / 32), 1);
+        hipLaunchKernelGGL((k_conv1_pool_fwd<T, 3, 5, 3>), grid, dim3(448), 0, stream, (const T *)x, w, bias, (T *)const_cast<void *>(io),
+                           (uint4 *)argbits, g);
+    } else {
+        dim3 grid((unsigned)g.n_lines, (unsigned)(g.F / 32), 1);
+        hipLaunchKernelGGL((k_conv1_pool_bwd<T, 3, 5, 3>), grid, dim3(448), 0, stream, (const T *)x, (const T *)io, (const uint4 *)argbits, dw, dbias, g);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : QK_ERR_LAUNCH;
+}
+
+}  // namespace
+
+// conv (3,5) 'same' on one quaternion channel + relu + max-pool (3,1) 'same' over H.  `argbits`: the arg-max side tensor
+// (conv1_pool_argbits_bytes), written by the forward (may be NULL there: inference), read by the backward.
+size_t conv1_pool_argbits_bytes(int N, int H, int W, int F)
+{
+    const long long lines = (long long)N * ((H + 2) / 3) * ((W + C1_TW - 1) / C1_TW);
+    return (size_t)(lines * (F / 32) * 7 * 64 * 16);
+}
+
+int launch_conv1_pool(int dtype, bool backward, const void *x, const float *w, const float *bias, const void *io, void *argbits,
+                      float *dw, float *dbias, int N, int H, int W, int F, int has_bias, hipStream_t stream)
+{
+    C1Geom g;
+    g.N = N; g.H = H; g.W = W; g.F = F; g.has_bias = has_bias;
+    g.Ho = (H + 2) / 3;
+    g.n_chunks = (W + C1_TW - 1) / C1_TW;
+    g.n_lines = N * g.Ho * g.n_chunks;
+    if (dtype == QK_BF16) return run_conv1_pool<bf16>(backward, x, w, bias, io, argbits, dw, dbias, g, stream);
+    if (dtype == QK_F16) return run_conv1_pool<f16>(backward, x, w, bias, io, argbits, dw, dbias, g, stream);
+    return QK_ERR_UNSUPPORTED;
+}
+
+}  // namespace qk

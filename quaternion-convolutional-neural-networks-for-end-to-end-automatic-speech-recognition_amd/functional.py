@@ -488,6 +488,57 @@ def maxpool2d_supported(x, window, strides):
             and x.shape[-1] % vec == 0 and x.numel() > 0 and x.numel() < 2 ** 31 and x.data_ptr() % 16 == 0)
 
 
+class _ConvReluPoolFn(torch.autograd.Function):
+    """qk_conv_relu_pool_fwd / _bwd: conv (3,5) 'same' + relu + max-pool over the first spatial axis as one launch per
+    direction (the TIMIT model's first layer); the input gets no gradient."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, call, pool):
+        n, h, wd, _ = x.shape
+        out = torch.empty((n, -(-h // pool), wd, w.shape[-1]), dtype=x.dtype, device=x.device)
+        nb = int(L.lib().qk_conv_relu_pool_aux_bytes(ctypes.byref(call.desc), pool))
+        keep = any(ctx.needs_input_grad[1:3])
+        aux = torch.empty(nb, dtype=torch.uint8, device=x.device) if keep else None
+        with _on_device(x.device):
+            rc = L.lib().qk_conv_relu_pool_fwd(ctypes.byref(call.desc), pool, _ptr(x), _ptr(w), _ptr(bias), _ptr(out), _ptr(aux), _stream(x))
+        L.check(rc, 'qk_conv_relu_pool_fwd')
+        ctx.call, ctx.pool, ctx.has_bias = call, pool, bias is not None
+        ctx.w_shape = tuple(w.shape)
+        ctx.save_for_backward(x, aux)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, aux = ctx.saved_tensors
+        dout = dout.contiguous()
+        dw = torch.empty(ctx.w_shape, dtype=torch.float32, device=x.device)
+        db = torch.empty((ctx.w_shape[-1],), dtype=torch.float32, device=x.device) if ctx.has_bias else None
+        with _on_device(x.device):
+            rc = L.lib().qk_conv_relu_pool_bwd(ctypes.byref(ctx.call.desc), ctx.pool, _ptr(x), _ptr(dout), _ptr(aux), _ptr(dw), _ptr(db), _stream(x))
+        L.check(rc, 'qk_conv_relu_pool_bwd')
+        return None, dw, db, None, None
+
+
+def conv_relu_pool_supported(x, kernel, pool):
+    """True when relu(QuaternionConv2D(kernel, 'same')(x)) followed by MaxPooling over the first spatial axis (window =
+    stride = pool, 'same') can run as the fused first-layer kernels: x a contiguous channels_last (N, H, W, 4) 16-bit
+    device tensor that needs no gradient, kernel (3, 5, 1, 4F) with F % 32 == 0, pool == 3."""
+    return (x.is_cuda and x.dtype in (torch.bfloat16, torch.float16) and x.dim() == 4 and x.shape[-1] == 4 and not x.requires_grad
+            and tuple(kernel.shape[:3]) == (3, 5, 1) and kernel.shape[-1] % 128 == 0 and pool == 3 and x.shape[0] > 0)
+
+
+def conv_relu_pool(x, kernel, bias=None, pool=3):
+    """(N, H, W, 4) -> (N, ceil(H / pool), W, 4F): the first TIMIT layer and its frequency pooling in one kernel
+    (include/qk.h: qk_conv_relu_pool_*).  Check conv_relu_pool_supported first."""
+    _require_device(x, 'conv_relu_pool')
+    _check_weights(kernel, bias, kernel.shape[-1])
+    xc = x.contiguous()
+    call = conv_call(tuple(xc.shape), tuple(kernel.shape), xc.dtype, 2, 1, 'same', 'channels_last', 1, 'relu', bias is not None, False)
+    if not L.lib().qk_conv_relu_pool_aux_bytes(ctypes.byref(call.desc), pool):
+        raise RuntimeError('conv_relu_pool: geometry outside the fused first-layer kernel')
+    return _ConvReluPoolFn.apply(xc, kernel.contiguous(), bias, call, pool)
+
+
 class _ConvChainFn(torch.autograd.Function):
     """A run of quaternion convolutions applied back to back as ONE autograd node, so that the backward knows the
     structure.  Each layer ends in a fused relu (y_i = relu(W_i (x) y_{i-1} + b_i)), is linear, or carries a POST-OP

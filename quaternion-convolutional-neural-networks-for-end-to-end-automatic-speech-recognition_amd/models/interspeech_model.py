@@ -71,8 +71,10 @@ class TimitQCNN(torch.nn.Module):
                       and not os.environ.get('QK_NO_FUSED_PRELU'))
         if fused_post:
             return self._forward_fused_prelu(x)
-        o = self._act(self.conv(x), 0)
-        o = self.pool(o)
+        o = self._first_layer_fused(x) if self.prelu is None else None
+        if o is None:
+            o = self._act(self.conv(x), 0)
+            o = self.pool(o)
         k = 1
         plain = self.prelu is None and not (self.training and self.rate > 0)
         first = 0
@@ -98,6 +100,27 @@ class TimitQCNN(torch.nn.Module):
             if i < 2:
                 o = self.drop(o)
         return self.pred(o)
+
+    def _first_layer_fused(self, x):
+        """conv (3,5) 'same' relu + MaxPooling2D((1,3), 'same') over the frequency axis (interspeech_model.py:97-103)
+        as ONE kernel per direction (functional.conv_relu_pool): the 41-bin activation is never written.  Returns None
+        when the configuration is outside that kernel (the layers then run one by one)."""
+        from .. import functional as Fq
+        from ..keras_like import activations
+        c, pl = self.conv, self.pool
+        if os.environ.get('QK_NO_FUSED_FIRST') or not x.is_cuda or x.dim() != 4:
+            return None
+        if not c.built:
+            c._build_device = x.device
+            c.build(tuple(x.shape))
+        xl = x.movedim(1, -1)                                        # (B, F, T, 4): the channels-last buffer
+        ok = (activations.serialize(c.activation) == 'relu' and c.padding == 'same' and c.strides == (1, 1) and
+              c.dilation_rate == (1, 1) and c.internal_layout == 'channels_last' and pl.pool_size == (1, 3) and
+              pl.strides == (1, 3) and pl.padding == 'same' and pl.data_format == 'channels_last' and
+              Fq.conv_relu_pool_supported(xl, c.kernel, 3))
+        if not ok:
+            return None
+        return Fq.conv_relu_pool(xl, c.kernel, c.bias, 3).movedim(-1, 1)
 
     def _forward_fused_prelu(self, x):
         """aact == 'prelu' (interspeech_model.py:55-56,99-101,117-121: linear layers, PReLU(shared_axes=[1,0]) and

@@ -909,3 +909,53 @@ def test_conv_chain_with_prelu_dropout_matches_oracle_composition(dtype, rate):
         assert _rel_err(bt[i].grad.cpu().numpy(), db) <= tol_g, 'dbias %d' % i
         assert _rel_err(at[i].grad.cpu().numpy(), want_da) <= tol_g, 'dalpha %d' % i
     assert _rel_err(xt.grad.float().cpu().numpy(), g) <= tol_g
+
+
+# ---- the first TIMIT layer fused with its frequency pooling (qk_conv_relu_pool_*) ------------------------------------
+def _np_pool_h_same(y, pool=3):
+    n, h, w, c = y.shape
+    out = -(-h // pool)
+    p = np.empty((n, out, w, c)); arg = np.empty((n, out, w, c), dtype=np.int64)
+    for o in range(out):
+        seg = y[:, o * pool:min((o + 1) * pool, h)]
+        arg[:, o] = seg.argmax(1) + o * pool
+        p[:, o] = seg.max(1)
+    return p, arg
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16], ids=['bf16', 'fp16'])
+@pytest.mark.parametrize('shape,F', [((3, 41, 50, 4), 32), ((2, 9, 230, 4), 64), ((1, 7, 19, 4), 32)],
+                         ids=['timit_small', 'two_chunks_two_column_tiles', 'partial_window'])
+def test_fused_first_layer_conv_relu_pool_matches_oracle(shape, F, dtype):
+    """qk_conv_relu_pool_fwd / _bwd (conv (3,5) 'same' + relu + max-pool (3,1) 'same' over H, one kernel per direction,
+    no pre-pool tensor) against oracle conv + numpy pooling: pooled values, d kernel, d bias.  Widths beyond one
+    224-position chunk, two 32-filter column tiles and a partial last window are covered."""
+    import qcnn_amd
+    from oracle import oracle
+    Fq = qcnn_amd.functional
+    dev = _dev()
+    rng = np.random.RandomState(53)
+    rnd = lambda a: torch.tensor(a).to(dtype).double().numpy()
+    x = rnd(rng.randn(*shape))
+    w = rnd(rng.randn(3, 5, 1, 4 * F) / np.sqrt(60.0))
+    b = (0.1 * rng.randn(4 * F)).astype(np.float32).astype(np.float64)
+    kw = dict(padding='same', activation='relu')
+    y = oracle.forward(x, w, b, 2, **kw)
+    pooled, arg = _np_pool_h_same(y)
+    dp = rnd(rng.randn(*pooled.shape))
+    dy = np.zeros_like(y)
+    n, ho, wd, c = pooled.shape
+    ii = np.meshgrid(np.arange(n), np.arange(ho), np.arange(wd), np.arange(c), indexing='ij')
+    np.add.at(dy, (ii[0], arg, ii[2], ii[3]), dp)
+    _, dw, db = oracle.backward(x, w, b, dy, 2, y=y, **kw)
+    xt = torch.tensor(x, device=dev).to(dtype)
+    wt = torch.tensor(w, device=dev, dtype=torch.float32, requires_grad=True)
+    bt = torch.tensor(b, device=dev, dtype=torch.float32, requires_grad=True)
+    assert Fq.conv_relu_pool_supported(xt, wt, 3)
+    out = Fq.conv_relu_pool(xt, wt, bt, 3)
+    out.backward(torch.tensor(dp, device=dev).to(dtype))
+    tol16, tol32 = (1e-2, 4e-3) if dtype == torch.bfloat16 else (2e-3, 2e-3)
+    assert tuple(out.shape) == pooled.shape
+    assert _rel_err(out.detach().float().cpu().numpy(), pooled) <= tol16
+    assert _rel_err(wt.grad.cpu().numpy(), dw) <= tol32
+    assert _rel_err(bt.grad.cpu().numpy(), db) <= tol32
