@@ -251,13 +251,17 @@ k_conv1_pool_bwd(const T *__restrict__ x, const T *__restrict__ dout, const uint
 #pragma unroll
         for (int r = 0; r < 16; ++r) dwacc[p][r] = 0.f;
 
-    // One pooled line segment per workgroup (a persistent loop over segments kept ~50 loop-invariant address values
-    // alive across iterations and spilled them; 2 K atomics per workgroup on 2 K addresses cost less than that).
-    {
-        const int item = blockIdx.x;
+    // Persistent: a workgroup walks over pooled line segments and keeps the gradients in registers (one flush of 2 K
+    // atomics per workgroup instead of per segment).  `item` is made opaque so that no per-segment address is
+    // hoisted out of the loop as a loop invariant (that cost ~50 spilled registers).
+#pragma unroll 1
+    for (int item0 = blockIdx.x; item0 < g.n_lines; item0 += gridDim.x) {
+        int item = item0;
+        asm volatile("" : "+s"(item));
         const int chunk = item % g.n_chunks, line = item / g.n_chunks;
         const int ho = line % g.Ho, n = line / g.Ho;
         const int t0 = chunk * C1_TW;
+        __syncthreads();                                          // the previous segment's LDS reads are done
         K::stage_patch(x, lds, g, n, ho, t0, tid, 448);
         // this wave's dpool tile: 32 positions x (4 x 32) channels, rows past W are zero
         char *dp = lds + K::PATCH_BYTES + wave * (32 * DP_PITCH);
@@ -324,24 +328,33 @@ k_conv1_pool_bwd(const T *__restrict__ x, const T *__restrict__ dout, const uint
             }
         }
     }
-    // ---- flush: the seven waves' gradients are summed in LDS (taps = accumulator rows 0 .. 15 = registers 0 .. 7, columns =
-    // filters), then one atomic per element and workgroup
+    // ---- flush: every wave parks its gradients in its own LDS slab (taps = accumulator rows 0 .. 15 = registers 0 .. 7,
+    // columns = filters), the workgroup sums the seven slabs and issues one atomic per element
     __syncthreads();
-    float *slab = reinterpret_cast<float *>(lds);                 // [part 4][tap 16][filter 32] + [component 4][filter 32]
-    for (int e = tid; e < 4 * 16 * 32 + 4 * 32; e += 448) slab[e] = 0.f;
-    __syncthreads();
+    constexpr int SLAB = 4 * 16 * 32 + 4 * 64;                    // [part 4][tap 16][filter 32] + [component 4][lane 64] floats
+    float *slab = reinterpret_cast<float *>(lds) + wave * SLAB;
 #pragma unroll
     for (int p = 0; p < 4; ++p)
 #pragma unroll
-        for (int r = 0; r < 8; ++r) atomicAdd(&slab[(p * 16 + mfma32_row(r, lane)) * 32 + lr], dwacc[p][r]);
+        for (int r = 0; r < 8; ++r) slab[(p * 16 + mfma32_row(r, lane)) * 32 + lr] = dwacc[p][r];
 #pragma unroll
-    for (int b = 0; b < 4; ++b) atomicAdd(&slab[4 * 16 * 32 + b * 32 + lr], dbacc[b]);
+    for (int b = 0; b < 4; ++b) slab[4 * 16 * 32 + b * 64 + lane] = dbacc[b];
     __syncthreads();
+    const float *all = reinterpret_cast<const float *>(lds);
     for (int e = tid; e < 4 * 16 * 32; e += 448) {
         const int f = e & 31, tap = (e >> 5) & 15, p = e >> 9;
-        if (tap < K::TAPS) atomicAdd(dw + (tap * 4 + p) * g.F + j0 + f, slab[e]);
+        float v = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < 7; ++wv) v += all[wv * SLAB + e];
+        if (tap < K::TAPS && v != 0.f) atomicAdd(dw + (tap * 4 + p) * g.F + j0 + f, v);
     }
-    if (dbias && tid < 128) atomicAdd(dbias + (tid >> 5) * g.F + j0 + (tid & 31), slab[4 * 16 * 32 + tid]);
+    if (dbias && tid < 128) {
+        const int b = tid >> 5, f = tid & 31;
+        float v = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < 7; ++wv) v += all[wv * SLAB + 4 * 16 * 32 + b * 64 + f] + all[wv * SLAB + 4 * 16 * 32 + b * 64 + 32 + f];
+        atomicAdd(dbias + b * g.F + j0 + f, v);
+    }
 }
 
 template <typename T>
@@ -353,7 +366,9 @@ int run_conv1_pool(bool backward, const void *x, const float *w, const float *bi
         hipLaunchKernelGGL((k_conv1_pool_fwd<T, 3, 5, 3>), grid, dim3(448), 0, stream, (const T *)x, w, bias, (T *)const_cast<void *>(io),
                            (uint4 *)argbits, g);
     } else {
-        dim3 grid((unsigned)g.n_lines, (unsigned)(g.F / 32), 1);
+        int blocks = 2 * device_cu_count();                        // 70 KB of LDS: two workgroups per CU
+        if (blocks > g.n_lines) blocks = g.n_lines;
+        dim3 grid((unsigned)blocks, (unsigned)(g.F / 32), 1);
         hipLaunchKernelGGL((k_conv1_pool_bwd<T, 3, 5, 3>), grid, dim3(448), 0, stream, (const T *)x, (const T *)io, (const uint4 *)argbits, dw, dbias, g);
     }
     return hipGetLastError() == hipSuccess ? 0 : QK_ERR_LAUNCH;
