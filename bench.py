@@ -55,6 +55,9 @@ WORKLOADS = {
     # BASELINE.json configs[4] body layer: Cq = F = 256, fp16, 32 samples per GPU
     'cfg5_body_qconv2d_b32_fp16': dict(kind='conv', rank=2, batch=32, spatial=(14, 200), cq=256, filters=256,
                                        kernel=(3, 5), dtype='fp16'),
+    # BASELINE.json configs[4] per-GPU stack: QuaternionConv2D 1 -> 256, 9 x (256 -> 256) (3,5) 'same' relu on (14, 200),
+    # TimeDistributed(QuaternionDense(256)) head (in_q = 3584), fp16, 32 samples per GPU
+    'cfg5_stack_b32_fp16': dict(kind='stack', batch=32, frames=200, freq=14, width=256, body=9, dtype='fp16'),
     # BASELINE.json configs[2]: the full TIMIT QCNN (models/interspeech_model.py:45-185), n=10, sf=32
     'cfg3_qcnn_timit_b256_bf16': dict(kind='model', batch=256, frames=200, sf=32, layers=10, dtype='bf16'),
     'cfg3_qcnn_timit_b64_fp32': dict(kind='model', batch=64, frames=200, sf=32, layers=10, dtype='fp32'),
@@ -128,6 +131,55 @@ class ModelTrainStep(object):
 
     def capture(self):
         raise RuntimeError('model workloads run eagerly (launch overhead is negligible at this size)')
+
+
+class StackTrainStep(object):
+    """BASELINE configs[4] per-GPU workload: conv 1 -> W (tap-folded first layer), `body` x conv W -> W and the head
+    (TimeDistributed QuaternionDense(256) as an (F, 1) conj convolution) as ONE conv chain, sum loss, bucketed all-reduce
+    of the ~36 M parameters (one 15.7 MB bucket per body layer, launched while the backward is still running), Adam."""
+
+    def __init__(self, cfg, dev, rank, world):
+        import qcnn_amd
+        from qcnn_amd import dp, functional as F
+        from qcnn_amd.complexnn.init import qconv_init
+        self.F, self.dp, self.world, self.cfg = F, dp, world, cfg
+        dt = TORCH_DT[cfg['dtype']]
+        gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+        B, T, Fr, W = cfg['batch'], cfg['frames'], cfg['freq'], cfg['width']
+        self.x = torch.randn(B, Fr, T, 4, device=dev, generator=gen).to(dt)
+        np.random.seed(0)
+        shapes = [(3, 5, 1, 4 * W)] + [(3, 5, W, 4 * W)] * cfg['body'] + [(Fr, 1, W, 256)]
+        params = []
+        for s in shapes:
+            w0 = qconv_init(kernel_size=s[:2], input_dim=s[2], weight_dim=2, nb_filters=s[3] // 4, criterion='he')()
+            params.append(torch.nn.Parameter(torch.tensor(w0, dtype=torch.float32, device=dev)))
+            params.append(torch.nn.Parameter(torch.zeros(s[3], device=dev)))
+        self.flat = dp.FlatParams(params)
+        dp.broadcast_params(self.flat)
+        self.reducer = dp.BucketedAllReduce(self.flat, bucket_bytes=8 << 20)
+        self.ws, self.bs = params[0::2], params[1::2]
+        self.kws = [dict(padding='same', activation='relu')] * (1 + cfg['body']) + [dict(padding='valid', activation='relu', conj=True)]
+        self.m = torch.zeros_like(self.flat.param)
+        self.v = torch.zeros_like(self.flat.param)
+        self.target = torch.randn(B, 1, T, 256, device=dev, generator=gen).to(dt)
+        self.t = 0
+        m1 = B * Fr * T
+        self.flops_per_kernel = 2.0 * m1 * 4 * W * 60 + cfg['body'] * 2.0 * m1 * 4 * W * 15 * 4 * W + 2.0 * B * T * 256 * Fr * 4 * W
+        self.gemm = dict(layers='conv 1->%d, %dx conv %d->%d, TD-dense head' % (W, cfg['body'], W, W),
+                         parameters=int(sum(p.numel() for p in params)), allreduce_buckets=len(self.reducer.buckets))
+        self.y = self.x
+
+    def step(self):
+        self.t += 1
+        F = self.F
+        h = F.quaternion_conv(self.x, self.ws[0], self.bs[0], **self.kws[0])
+        y = F.quaternion_conv_chain(h, [(self.ws[i], self.bs[i], self.kws[i]) for i in range(1, len(self.ws))])
+        (y.float() * self.target).sum().backward()
+        self.reducer.finish()
+        F.adam_step(self.flat.param, self.flat.grad, self.m, self.v, self.t, lr=5e-4, grad_scale=1.0 / self.world, zero_grad=True)
+
+    def capture(self):
+        raise RuntimeError('stack workloads run eagerly')
 
 
 class LayerTrainStep(object):
@@ -433,10 +485,11 @@ def main():
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
     cfg = dict(WORKLOADS[args.workload], activation=args.activation)
-    is_model = cfg.get('kind') == 'model'
-    steps = args.steps if args.steps is not None else (100 if is_model else 300)
-    warmup = args.warmup if args.warmup is not None else (10 if is_model else 30)
-    job = ModelTrainStep(cfg, dev, rank, world) if is_model else LayerTrainStep(cfg, dev, rank, world)
+    is_stack = cfg.get('kind') == 'stack'
+    is_model = cfg.get('kind') == 'model' or is_stack
+    steps = args.steps if args.steps is not None else (30 if is_stack else 100 if is_model else 300)
+    warmup = args.warmup if args.warmup is not None else (3 if is_stack else 10 if is_model else 30)
+    job = (StackTrainStep if is_stack else ModelTrainStep if is_model else LayerTrainStep)(cfg, dev, rank, world)
 
     def barrier():
         if world > 1 or dist.is_initialized():
@@ -459,7 +512,7 @@ def main():
     samples_per_s = world * cfg['batch'] * steps / elapsed
 
     out = {
-        'metric': 'quaternion-conv samples/sec (fwd+bwd+Adam of %s)' % ('the full TIMIT QCNN, per-GPU batch %d' % cfg['batch'] if is_model else 'one QuaternionConv layer'),
+        'metric': 'quaternion-conv samples/sec (fwd+bwd+Adam of %s)' % ('the config-5 stack, per-GPU batch %d' % cfg['batch'] if is_stack else 'the full TIMIT QCNN, per-GPU batch %d' % cfg['batch'] if is_model else 'one QuaternionConv layer'),
         'value': samples_per_s, 'unit': 'samples/s', 'n_gpus': world, 'steps': steps,
         'warmup': warmup, 'pre_warmup_steps': pre, 'ms_per_step': ms_per_step, 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': cfg['dtype'], 'data': 'synthetic',
@@ -471,11 +524,11 @@ def main():
     }
     peak = PEAK_TFLOPS[cfg['dtype']]
     stream = torch.cuda.current_stream(dev)
-    timing = rank == 0 and world == 1 and not args.no_kernel_timing
+    timing = rank == 0 and world == 1 and not args.no_kernel_timing and not is_stack
 
     if rank == 0 and is_model:
         tf = 3 * job.flops_per_kernel / (ms_per_step * 1e-3) / 1e12
-        out['qcnn_step'] = {'ms_per_step': ms_per_step, 'tflops': tf, 'frac_of_peak': tf / peak,
+        out['stack_step' if is_stack else 'qcnn_step'] = {'ms_per_step': ms_per_step, 'tflops': tf, 'frac_of_peak': tf / peak,
                             'flops_per_step': 3 * job.flops_per_kernel,
                             'note': 'algorithmic 2MNK fwd + 4MNK bwd of the quaternion layers / whole-step wall time'}
         out['step_tflops'] = tf
@@ -558,7 +611,7 @@ def main():
         out['step_tflops'] = 3 * job.flops_per_kernel / (ms_per_step * 1e-3) / 1e12
     if world > 1:
         dist.barrier()
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not is_stack:
         out['cpu_baseline'] = cpu_baseline(cfg, args.cpu_seconds)
     if rank == 0:
         print(json.dumps(out))
