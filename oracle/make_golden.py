@@ -199,6 +199,18 @@ def api_goldens(cn):
     except Exception as e:
         errs['qconv_init_dim_mismatch'] = type(e).__name__
     out['errors'] = errs
+    # component getters (complexnn/utils.py:17-115): which slice of an arange tensor each one returns, per rank
+    import torch
+    getters = []
+    for shape in [(3, 8), (2, 5, 8), (2, 8, 3, 5), (2, 8, 3, 2, 2)]:
+        x = torch.arange(float(np.prod(shape)), dtype=torch.float64).reshape(shape)
+        for part in 'rijk':
+            for y in (getattr(cn.utils, 'get_%spart_first' % part)(x), getattr(cn.utils, 'Get%sFirst' % part.upper())().call(x)):
+                getters.append(dict(input_shape=list(shape), part=part, output_shape=list(y.shape),
+                                    values=[float(v) for v in y.reshape(-1).tolist()]))
+        getters.append(dict(input_shape=list(shape), part='shape',
+                            output_shape=list(cn.utils.getpart_quaternion_output_shape_first((None,) + shape[1:]))))
+    out['getters'] = getters
     return out
 
 

@@ -256,6 +256,26 @@ def test_component_getters_follow_reference_axis_rule():
     assert GetRFirst().compute_output_shape((None, 8)) == (None, 2)
 
 
+def test_component_getters_match_reference_captured_slices():
+    """g00_api.json['getters']: what the reference's get_*part_first / Get*First / getpart_..._shape_first
+    (complexnn/utils.py:17-115) return for arange tensors of rank 2..5, captured by oracle/make_golden.py."""
+    from qcnn_amd.complexnn import utils as U
+    recs = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'g00_api.json')))['getters']
+    assert len(recs) == 36
+    seen = {}
+    for r in recs:
+        shape = tuple(r['input_shape'])
+        if r['part'] == 'shape':
+            assert list(U.getpart_quaternion_output_shape_first((None,) + shape[1:])) == r['output_shape']
+            continue
+        x = torch.arange(float(np.prod(shape)), dtype=torch.float64).reshape(shape)
+        k = (shape, r['part'])
+        fn = getattr(U, 'get_%spart_first' % r['part']) if k not in seen else getattr(U, 'Get%sFirst' % r['part'].upper())()
+        seen[k] = True
+        y = fn(x)
+        assert list(y.shape) == r['output_shape'] and y.reshape(-1).tolist() == r['values'], (shape, r['part'])
+
+
 def test_debug_flags_are_a_process_wide_mask_set_through_the_c_abi():
     """qk_set_debug_flags / qk_get_debug_flags (include/qk.h): the diagnostic switches are one atomic word, not
     getenv calls on the launch path; the Python context manager restores the previous mask."""
