@@ -78,7 +78,7 @@ __device__ __forceinline__ uint4 mask8(const uint4 &v, const uint4 &m)
 // ---------------------------------------------------------------------------------------
 template <typename T>
 __global__ void __launch_bounds__(256)
-k_prep_w16(const float *__restrict__ w, T *__restrict__ wq, int taps, int Cq, int F, int transposed)
+k_prep_w16(const float *__restrict__ w, T *__restrict__ wq, int taps, int Cq, int F, int transposed, int neg_ijk)
 {
     const int Q = transposed ? F : Cq;
     const int J = transposed ? Cq : F;
@@ -94,7 +94,8 @@ k_prep_w16(const float *__restrict__ w, T *__restrict__ wq, int taps, int Cq, in
         const int k = kc * 32 + slot * 8 + e;
         const int c = transposed ? j : k;
         const int f = transposed ? k : j;
-        wq[idx] = from_f32<T>(w[((long long)(t * Cq + c) * 4 + p) * F + f]);
+        const float v = w[((long long)(t * Cq + c) * 4 + p) * F + f];
+        wq[idx] = from_f32<T>(neg_ijk && p ? -v : v);
     }
     if (blockIdx.x == 0 && threadIdx.x < 128) wq[total + threadIdx.x] = from_f32<T>(0.f);   // zero line for padding rows
 }
@@ -826,9 +827,9 @@ int run16_band(const T *in, const uint4 *wq, const T *zero_line, const float *bi
     // EPM (epilogue mask, QK_BWD_MASK_DX) is its own instantiation: its eight prefetched mask pieces cost 32 VGPRs
     // ... and so is POSTF (forward post-op: PReLU / dropout, pre-activation written beside y)
 #define QK_GO(C, E, P) hipLaunchKernelGGL((k_hgemm16_band<T, WM, WN, KIN, C, TRIM, E, P>), grid, dim3(NTHR), 0, stream, in, wq, zero_line, bias, out, g)
-    const bool conj = g.sign_tbl == kSignConj, epm = g.ep_mask != nullptr, pf = g.post.kind != 0 && g.pre_out != nullptr;
-    if (conj) { if (epm) QK_GO(true, true, false); else if (pf) QK_GO(true, false, true); else QK_GO(true, false, false); }
-    else      { if (epm) QK_GO(false, true, false); else if (pf) QK_GO(false, false, true); else QK_GO(false, false, false); }
+    const bool epm = g.ep_mask != nullptr, pf = g.post.kind != 0 && g.pre_out != nullptr;
+    if (g.sign_tbl != kSignConj) return QK_ERR_LAUNCH;                 // go16 folds the plain table into the kernel
+    if (epm) QK_GO(true, true, false); else if (pf) QK_GO(true, false, true); else QK_GO(true, false, false);
 #undef QK_GO
     return hipGetLastError() == hipSuccess ? 1 : QK_ERR_LAUNCH;
 }
@@ -841,11 +842,10 @@ int run16(const T *in, const T *mask, const uint4 *wq, const T *zero_line, const
     const GemmGeom &g = g_in;
     const int n_mt = (g.M + BM - 1) / BM;
     dim3 grid((n_mt + 7) / 8 * 8, g.J / BF, 1);       // padded to the 8 XCDs (see the tile remap)
-    const bool conj = g.sign_tbl == kSignConj;
     const bool m = g.has_mask != 0;
+    if (g.sign_tbl != kSignConj) return QK_ERR_LAUNCH;                 // go16 folds the plain table into the kernel
 #define QK_GO(C, K) hipLaunchKernelGGL((k_hgemm16<T, MT, WM, WN, C, K>), grid, dim3(512), 0, stream, in, mask, wq, zero_line, bias, out, g)
-    if (conj) { if (m) QK_GO(true, true); else QK_GO(true, false); }
-    else      { if (m) QK_GO(false, true); else QK_GO(false, false); }
+    if (m) QK_GO(true, true); else QK_GO(true, false);
 #undef QK_GO
     return hipGetLastError() == hipSuccess ? 1 : QK_ERR_LAUNCH;
 }
@@ -856,13 +856,20 @@ int go16(const void *in, const void *mask, const float *w, const float *bias, vo
 {
     GemmGeom g = g_in;
     g.ablate = debug_ablate();
+    // One sign table for every 16-bit kernel: the plain table is the conjugate one applied to the conjugated kernel
+    // quaternion (S_conv[a][b] = S_conj[a][b] * s[a ^ b] with s = (+, -, -, -)), so the i, j, k components are negated
+    // while the kernel is re-laid out (exact in bf16 / fp16) and only the CONJ instantiations exist -- the conjugate
+    // table never subtracts into output component 0, i.e. it needs 7 accumulator tiles, not 8, which is what lets the
+    // 64-row 4-wave band kernel fit two workgroups per CU without spilling.
+    const bool neg_ijk = g.sign_tbl == kSignConv;
+    g.sign_tbl = kSignConj;
     for (int i = 0; i < 3; ++i) fastdiv_of((unsigned)g.osp[2 - i], &g.dv_mul[i], &g.dv_shr[i]);
     T *wq = static_cast<T *>(ws);
     const int Cq = transposed ? g.J : g.Q, F = transposed ? g.Q : g.J;
     const long long total = (long long)g.taps * Cq * 4 * F;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL((k_prep_w16<T>), dim3(blocks), dim3(256), 0, stream, w, wq, g.taps, Cq, F, transposed ? 1 : 0);
+    hipLaunchKernelGGL((k_prep_w16<T>), dim3(blocks), dim3(256), 0, stream, w, wq, g.taps, Cq, F, transposed ? 1 : 0, neg_ijk ? 1 : 0);
     if (hipGetLastError() != hipSuccess) return QK_ERR_LAUNCH;
     const uint4 *wq4 = reinterpret_cast<const uint4 *>(wq);
     const T *zero_line = wq + total;                 // 256 zeroed bytes behind the re-laid-out kernel
@@ -876,12 +883,10 @@ int go16(const void *in, const void *mask, const float *w, const float *bias, vo
         note_path(QK_PATH_MFMA16_BAND);
         // Workgroup shape, by measurement on MI355X (tools/gpu_ab.sh, B = 256 TIMIT layers, us per launch):
         //   N = 128 (J = 32):  8 waves 384 / 376 (fwd / bwd-data)  ->  4 waves x 2 per CU, trimmed band  327 / 319
-        //   N = 256 (J = 64):  8 waves 1166 / 1158                ->  4 waves (64-row tiles)           1166 / 1113
-        // The 64-row tiles stage twice the B units per MFMA and their conv-table instantiation spills inside the
-        // K loop, so N = 256 takes the 4-wave form only with the transposed table (the backward-data of a plain
-        // convolution); QK_DBG_BAND16_8WAVES forces the 8-wave tilings everywhere (A/B switch).
+        //   N = 256 (J = 64):  8 waves 1166 / 1158                ->  4 waves (64-row tiles)
+        // QK_DBG_BAND16_8WAVES forces the 8-wave tilings everywhere (A/B switch).
         const bool w8 = (debug_flags() & kDbgBand8Waves) != 0;
-        const bool w8_wide = w8 || bg.sign_tbl != kSignConj;
+        const bool w8_wide = w8;
         if (bg.ks[2] == 5) {
             if (g.J % 64 == 0) return w8_wide ? run16_band<T, 4, 2, 5, false>(ip, wq4, zero_line, bias, op, bg, stream)
                                               : run16_band<T, 2, 2, 5, false>(ip, wq4, zero_line, bias, op, bg, stream);
