@@ -76,6 +76,11 @@ struct GemmGeom {
     void *pre_out;
     float *dalpha;
     int b_wp, b_nlines, b_cshift, b_rev;
+    // k_hgemm16 row order: 0 = rows run over (n, o0, o1, o2); batch = rows run over (o0, n, o1, o2) (dv_*[2] then divides
+    // by batch).  Chosen when the gathered tensor has ONE position along axis 0 under a multi-tap kernel axis (the
+    // backward-data of the (F, 1) 'valid' head convolution): the single valid tap of a row is then a function of o0
+    // alone and every 128-row tile uses exactly one tap instead of the two a line boundary inside the tile brings.
+    int o0_major;
     unsigned b_in_bytes, b_w_bytes;      // extents of the input tensor and of the re-laid-out kernel (buffer resources)
 };
 

@@ -162,6 +162,19 @@ k_hgemm16(const T *__restrict__ in, const T *__restrict__ mask, const uint4 *__r
     // being patched afterwards.
     constexpr int RPT2 = BM / 64;                   // rows per thread (passes of 64 rows)
     const int s_row = tid >> 3, s8 = tid & 7;
+    // GEMM row -> (sample, output position); see GemmGeom::o0_major for the second row order
+    struct RowPos { int n, o0, o1, o2; };
+    auto row_of = [&g](int m) -> RowPos {
+        RowPos r;
+        const int q2 = fastdiv(m, g.dv_mul[0], g.dv_shr[0]);
+        r.o2 = m - q2 * g.osp[2];
+        const int q1 = fastdiv(q2, g.dv_mul[1], g.dv_shr[1]);
+        r.o1 = q2 - q1 * g.osp[1];
+        const int hi = fastdiv(q1, g.dv_mul[2], g.dv_shr[2]);
+        r.n = g.o0_major ? q1 - hi * g.o0_major : hi;
+        r.o0 = g.o0_major ? hi : q1 - hi * g.osp[0];
+        return r;
+    };
     int base_off[RPT2];
     unsigned tapmask[RPT2];
 #pragma unroll
@@ -169,9 +182,8 @@ k_hgemm16(const T *__restrict__ in, const T *__restrict__ mask, const uint4 *__r
         int m = m0 + s_row + r * 64;
         base_off[r] = 0; tapmask[r] = 0;
         if (m < g.M) {
-            const int q2 = fastdiv(m, g.dv_mul[0], g.dv_shr[0]), o2 = m - q2 * g.osp[2];
-            const int q1 = fastdiv(q2, g.dv_mul[1], g.dv_shr[1]), o1 = q2 - q1 * g.osp[1];
-            const int n = fastdiv(q1, g.dv_mul[2], g.dv_shr[2]), o0 = q1 - n * g.osp[0];
+            const RowPos rp = row_of(m);
+            const int n = rp.n, o0 = rp.o0, o1 = rp.o1, o2 = rp.o2;
             const int p0 = o0 * g.pa[0] + g.pc[0], p1 = o1 * g.pa[1] + g.pc[1], p2 = o2 * g.pa[2] + g.pc[2];
             base_off[r] = n * (int)g.in_sn + p0 * (int)g.in_ss[0] + p1 * (int)g.in_ss[1] + p2 * (int)g.in_ss[2];
             int t = 0;
@@ -385,9 +397,8 @@ k_hgemm16(const T *__restrict__ in, const T *__restrict__ mask, const uint4 *__r
             for (int pass = 0; pass < 2; ++pass) {
                 const int m = m0 + (wm * MT + mt) * 32 + e_row + 16 * pass;
                 if (m < g.M && g.post.alpha_sel >= 0) {
-                    const int q2 = fastdiv(m, g.dv_mul[0], g.dv_shr[0]), o2 = m - q2 * g.osp[2];
-                    const int q1 = fastdiv(q2, g.dv_mul[1], g.dv_shr[1]), o1 = q2 - q1 * g.osp[1];
-                    const int nn = fastdiv(q1, g.dv_mul[2], g.dv_shr[2]), o0 = q1 - nn * g.osp[0];
+                    const RowPos rp = row_of(m);
+                    const int o0 = rp.o0, o1 = rp.o1, o2 = rp.o2;
                     a_key[pass] = g.post.alpha_sel == 0 ? o0 : g.post.alpha_sel == 1 ? o1 : o2;
                 }
                 a_val[pass] = g.post.alpha[a_key[pass]];
@@ -413,7 +424,12 @@ k_hgemm16(const T *__restrict__ in, const T *__restrict__ mask, const uint4 *__r
                 const uint4 val = *reinterpret_cast<const uint4 *>(ep + row * EP_PITCH + e_chunk * 16);
                 const int m = m0 + (wm * MT + mt) * 32 + row;
                 if (m < g.M) {
-                    const long long o = (long long)m * (int)g.out_ss + ch0 + e_chunk * 8;
+                    int orow = m;
+                    if (g.o0_major) {
+                        const RowPos rp = row_of(m);
+                        orow = ((rp.n * g.osp[0] + rp.o0) * g.osp[1] + rp.o1) * g.osp[2] + rp.o2;
+                    }
+                    const long long o = (long long)orow * (int)g.out_ss + ch0 + e_chunk * 8;
                     uint4 v = val;
                     if (g.ep_mask) {
                         const uint4 mk = *reinterpret_cast<const uint4 *>(static_cast<const T *>(g.ep_mask) + o);
@@ -899,6 +915,10 @@ int go16(const void *in, const void *mask, const float *w, const float *bias, vo
                   : run16_band<T, 4, 1, 3, true>(ip, wq4, zero_line, bias, op, bg, stream);
     }
     note_path(QK_PATH_MFMA16);
+    if (g.isp[0] == 1 && g.ks[0] > 1 && g.batch > 1 && g.osp[0] > 1) {       // see GemmGeom::o0_major
+        g.o0_major = g.batch;
+        fastdiv_of((unsigned)g.batch, &g.dv_mul[2], &g.dv_shr[2]);
+    }
     if (g.J % 64 == 0) {
         // (256-row tiles, MT = 2, were measured: no gain over 128 rows, and they spill)
         return run16<T, 1, 4, 2>((const T *)in, (const T *)mask, wq4, zero_line, bias, (T *)out, g, stream);
