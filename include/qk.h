@@ -114,6 +114,8 @@ const char *qk_last_error(void);
  *   QK_DBG_WGRAD16_ONE_TAP  16-bit backward-weight: one tap per block for 32-channel layers
  *   QK_DBG_BAND16_8WAVES    16-bit band kernels in their 8-wave form (env QK_BAND16_8WAVES)
  *   QK_DBG_NO_WGRAD_BAND    16-bit backward-weight without the band kernel (env QK_NO_WGRAD_BAND)
+ *   QK_DBG_NO_POINT16       16-bit one-tap-per-row shapes (1 x 1, head backward-data) on the implicit-GEMM kernel
+ *                           instead of the streaming point-form kernel (env QK_NO_POINT16)
  *   bits 8..15              kernel ablation for profiling (skip the MFMA loop / epilogue / atomics): WRONG RESULTS
  * qk_set_debug_flags returns the previous mask. */
 #define QK_DBG_NO_MFMA16 1u
@@ -121,13 +123,15 @@ const char *qk_last_error(void);
 #define QK_DBG_NO_BAND32 4u
 #define QK_DBG_WGRAD16_ONE_TAP 8u
 #define QK_DBG_NO_WGRAD_BAND 32u   /* 16-bit backward-weight: one block per tap (k_wgrad16) instead of the band kernel */
+#define QK_DBG_NO_POINT16 64u
 #define QK_DBG_BAND16_8WAVES 16u   /* 16-bit band kernels: 8-wave workgroups (one per CU) instead of 4-wave (two per CU) */
 unsigned qk_set_debug_flags(unsigned flags);
 unsigned qk_get_debug_flags(void);
 
 /* Which kernel family served the most recent qk_* compute call of the calling thread (thread-local, like
  * qk_last_error): lets a caller see when a shape fell off the 16-bit matrix-core fast path. */
-typedef enum { QK_PATH_NONE = 0, QK_PATH_MFMA16 = 1, QK_PATH_MFMA16_BAND = 2, QK_PATH_FP32_MFMA = 3 } qk_path_t;
+typedef enum { QK_PATH_NONE = 0, QK_PATH_MFMA16 = 1, QK_PATH_MFMA16_BAND = 2, QK_PATH_FP32_MFMA = 3,
+               QK_PATH_MFMA16_POINT = 4 } qk_path_t;
 int qk_last_path(void);
 
 /* Bytes of caller-owned device workspace `op` needs for this descriptor (0 = none). */

@@ -483,6 +483,17 @@ __device__ __forceinline__ uint4 buf_load16b(__amdgpu_buffer_rsrc_t r, unsigned 
     return make_uint4(v.x, v.y, v.z, v.w);
 }
 
+// 16-byte buffer store.  The wave-uniform part of the offset is ADDED to the per-lane offset instead of going into the
+// instruction's soffset SGPR: hipcc (ROCm 7.2) inserts the wait states between a > 8-byte VMEM store and a VALU write
+// of its data registers only when soffset is not a register (the documented exception), and on gfx950 a
+// `buffer_store_dwordx4 v[a:a+3], ..., sN offen` directly followed by a VALU write of v[a] stored the NEW value in
+// part of the lanes (lanes 12-15 of every 16: measured, k_hgemm16_point with an epilogue mask).
+__device__ __forceinline__ void buf_store16b(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, const uint4 &v)
+{
+    const u32x4 d = {v.x, v.y, v.z, v.w};
+    __builtin_amdgcn_raw_buffer_store_b128(d, r, (int)(voff + soff), 0, 0);
+}
+
 // A-band staging schedule of one group: op code q < R loads row pass q of the NEXT band into its
 // registers, R <= q < 2R stores pass q - R into the other band buffer, -1 = nothing.  A store comes at
 // least one sub-step after its load (so it never waits on it), and at most three passes are in flight
@@ -833,6 +844,215 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Point form: every produced row gathers ONE row of the input under ONE tap.
+//
+// That is a 1 x 1 convolution / dense layer (one tap), and the backward-data of a 'valid' convolution whose kernel
+// spans axis 0 (the TimeDistributed dense head run as an (F, 1) convolution): dx[n, f, s, :] = dy[n, s, :] (x) W[f].
+// Per 128-row tile the implicit GEMM above runs Q / 32 = 2 K steps -- its pipeline prologue, tap bookkeeping and
+// 64 KB epilogue are then 90 % of the tile (measured: 15 us per tile for 1.7 us of MFMAs).  This kernel is the
+// streaming form of the same arithmetic:
+//   * the tap's re-laid-out kernel (32 KB at Q = J = 64) stays in LDS; persistent workgroups walk units
+//     (tap, 64-channel column block, 128-row tile) in tap-major order and reload it only when the tap changes;
+//   * A fragments go from global memory straight into registers (a row's 16-byte pieces ARE MFMA A operands),
+//     and the registers of a fragment are refilled for the NEXT unit as soon as its last MFMA has issued, so the
+//     loads of unit u + 1 fly under the MFMAs and the epilogue of unit u -- no barrier in steady state, the two
+//     waves of a SIMD drift apart and overlap each other's epilogue;
+//   * epilogue as in k_hgemm16 (per-wave LDS transpose, 16-byte stores), optional bias / relu / epilogue mask.
+// HBM-bound by construction: the head backward-data writes 367 MB for 94 GFLOP.
+// ---------------------------------------------------------------------------------------
+template <typename T, int NKC, bool EPM>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_hgemm16_point(const T *__restrict__ in, const uint4 *__restrict__ wq, const float *__restrict__ bias,
+                T *__restrict__ out, const GemmGeom g, const int n_tiles, const int n_units, const unsigned in_bytes,
+                const unsigned out_bytes)
+{
+    constexpr int WN = 2, BM = 128, BF = 64;
+    constexpr int NF = 2 * NKC;                      // 16-channel K slices per component
+    constexpr int B_U = NKC * 16 * BF;               // 16-byte units of one (tap, column block) kernel slice
+    constexpr unsigned TBL = kSignConj;              // go16 folds the plain table into the kernel
+    constexpr int EP_PITCH = 80;
+    __shared__ __attribute__((aligned(16))) uint4 lds[B_U + 4 * BF / 4 + 8 * 32 * EP_PITCH / 16];   // kernel slice, its bias (4 x BF floats), transpose patches
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int JB = g.J / BF;
+    const int S = g.osp[1] * g.osp[2];               // rows per (sample, tap)
+    const int R = g.batch * S;                       // gathered rows
+    const int T_ = g.ks[0];
+    const __amdgpu_buffer_rsrc_t rin = make_rsrc16(in, in_bytes);
+
+    // this workgroup's contiguous range of units, unit = (tap * JB + jb) * n_tiles + tile
+    const int u_lo = (int)((long long)blockIdx.x * n_units / gridDim.x);
+    const int u_hi = (int)((long long)(blockIdx.x + 1) * n_units / gridDim.x);
+    if (u_lo >= u_hi) return;
+
+    // byte offset of gathered row r (its component 0, channel 0); rows past the end read as zeros
+    auto row_voff = [&](int r) -> unsigned {
+        if (r >= R) return kOutOfRange16;
+        const int q2 = fastdiv(r, g.dv_mul[0], g.dv_shr[0]), o2 = r - q2 * g.osp[2];
+        const int n = fastdiv(q2, g.dv_mul[1], g.dv_shr[1]), o1 = q2 - n * g.osp[1];
+        return (unsigned)(n * (int)g.in_sn + o1 * (int)g.in_ss[1] + o2 * (int)g.in_ss[2]) * 2u + (unsigned)lh * 16u;
+    };
+    uint4 A[4][NF];
+    auto load_frag = [&](unsigned voff, int a, int f) {
+        A[a][f] = buf_load16b(rin, voff, (unsigned)(a * g.Q + f * 16) * 2u);
+    };
+    {
+        const int tile0 = u_lo % n_tiles;
+        const unsigned v0 = row_voff(tile0 * BM + wm * 32 + lr);
+#pragma unroll
+        for (int f = 0; f < NF; ++f)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) load_frag(v0, a, f);
+    }
+    int cur_slice = -1;
+    const uint4 *w_rd = lds + wn * 32 + lr;
+    const float *bias_rd = reinterpret_cast<const float *>(lds + B_U) + wn * 32 + lr;
+    char *ep = reinterpret_cast<char *>(lds + B_U + BF) + wave * (32 * EP_PITCH);
+    const int e_row = lane >> 2, e_chunk = lane & 3;
+    // Stores and mask loads go through buffer resources, rows past the end get an out-of-range offset: no branch
+    // around them.
+    const __amdgpu_buffer_rsrc_t rout = make_rsrc16(out, out_bytes);
+    const __amdgpu_buffer_rsrc_t rmask = make_rsrc16(EPM ? g.ep_mask : out, out_bytes);
+
+    for (int u = u_lo; u < u_hi; ++u) {
+        const int slice = u / n_tiles, tile = u - slice * n_tiles;      // slice = tap * JB + jb
+        const int tap = slice / JB, jb = slice - tap * JB;
+        if (slice != cur_slice) {                    // (uniform over the workgroup: every wave walks the same units)
+            __syncthreads();
+            const uint4 *src = wq + (long long)tap * (NKC * 16) * g.J + jb * BF;
+            uint4 t[B_U / 512];                       // all loads first: one round trip, not B_U / 512 of them
+#pragma unroll
+            for (int k = 0; k < B_U / 512; ++k) t[k] = src[((tid + k * 512) / BF) * g.J + (tid + k * 512) % BF];
+#pragma unroll
+            for (int k = 0; k < B_U / 512; ++k) lds[tid + k * 512] = t[k];
+            if (g.has_bias && tid < 4 * BF)
+                reinterpret_cast<float *>(lds + B_U)[tid] = bias[(tid / BF) * g.J + jb * BF + tid % BF];
+            __syncthreads();
+            cur_slice = slice;
+        }
+        // rows this lane stores (two passes of 16): byte offsets of their component-0 pieces
+        unsigned o_off[2];
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            const int r = tile * BM + wm * 32 + e_row + 16 * pass;
+            const int n = fastdiv(r, g.dv_mul[2], g.dv_shr[2]), sp = r - n * S;
+            const unsigned o = (unsigned)(((n * T_ + tap) * S + sp) * (int)g.out_ss + jb * BF + wn * 32 + e_chunk * 8) * 2u;
+            o_off[pass] = r < R ? o : kOutOfRange16;
+        }
+        // next unit's rows (same rows when only the tap changes); past the range: nothing is fetched
+        const bool more = u + 1 < u_hi;
+        const int ntile = (u + 1) % n_tiles;
+        const unsigned vnext = more ? row_voff(ntile * BM + wm * 32 + lr) : kOutOfRange16;
+
+        uint4 em[EPM ? 4 : 1][2];
+        if constexpr (EPM) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int pass = 0; pass < 2; ++pass) em[b][pass] = buf_load16b(rmask, o_off[pass], (unsigned)(b * g.J) * 2u);
+        }
+        floatx16 acc[4], accn[4];
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            uint4 W[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) W[p] = w_rd[(((f >> 1) * 4 + (f & 1) * 2 + lh) * 4 + p) * BF];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    constexpr unsigned tbl = TBL;
+                    const bool ng = (tbl >> (a * 4 + b)) & 1u;
+                    // first product of an accumulator starts from zero (no per-unit clearing pass)
+                    bool first = f == 0;
+#pragma unroll
+                    for (int a2 = 0; a2 < 4; ++a2)
+                        if (a2 < a && (((tbl >> (a2 * 4 + b)) & 1u) != 0) == ng) first = false;
+                    floatx16 zero;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+                    if (ng) accn[b] = mfma16(T(), A[a][f], W[a ^ b], first ? zero : accn[b]);
+                    else acc[b] = mfma16(T(), A[a][f], W[a ^ b], first ? zero : acc[b]);
+                }
+                load_frag(vnext, a, f);               // this fragment's registers are free: fetch the next unit's
+            }
+        }
+        // ---- epilogue as in k_hgemm16: per-wave LDS transpose, 16-byte stores -------------------------------
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            constexpr unsigned tbl = TBL;
+            constexpr unsigned col_neg = (tbl >> 0 | tbl >> 4 | tbl >> 8 | tbl >> 12) & 0xfu;   // columns with negative entries
+            const float bia = g.has_bias ? bias_rd[b * BF] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                float v0 = acc[b][r] + bia, v1 = acc[b][r + 1] + bia;
+                if ((col_neg >> b) & 1u) { v0 -= accn[b][r]; v1 -= accn[b][r + 1]; }
+                if (g.relu) { v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f; }
+                const unsigned pk = pack2(T(), v0, v1);
+                char *dst = ep + mfma32_row(r, lane) * EP_PITCH + lr * 2;
+                *reinterpret_cast<unsigned short *>(dst) = (unsigned short)pk;
+                *reinterpret_cast<unsigned short *>(dst + EP_PITCH) = (unsigned short)(pk >> 16);
+            }
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) {
+                uint4 v = *reinterpret_cast<const uint4 *>(ep + (e_row + 16 * pass) * EP_PITCH + e_chunk * 16);
+                if constexpr (EPM) v = mask8(v, em[b][pass]);
+                buf_store16b(rout, o_off[pass], (unsigned)(b * g.J) * 2u, v);
+            }
+        }
+    }
+}
+
+// shapes the point form takes (see k_hgemm16_point), normalised into *o; everything else stays with the implicit-GEMM
+// kernels.  A one-tap layer over a dense channels-last tensor (1 x 1 convolution, dense) becomes batch = rows, no
+// spatial axes.
+inline bool point_geom(const GemmGeom &g, GemmGeom *o)
+{
+    if (g.has_mask || g.post.kind != 0 || (g.Q != 32 && g.Q != 64) || g.J % 64 != 0) return false;
+    *o = g;
+    if (g.taps == 1) {
+        for (int i = 0; i < 3; ++i)
+            if (g.pa[i] != 1 || g.pc[i] != 0 || g.isp[i] != g.osp[i]) return false;
+        if (g.in_ss[1] != g.isp[2] * g.in_ss[2] || g.in_ss[0] != g.isp[1] * g.in_ss[1] || g.in_sn != g.isp[0] * g.in_ss[0]) return false;
+        o->batch = g.M;
+        o->in_sn = g.in_ss[2];
+        for (int i = 0; i < 3; ++i) { o->osp[i] = o->isp[i] = 1; o->in_ss[i] = 0; }
+    } else {
+        if (g.ks[1] != 1 || g.ks[2] != 1 || g.isp[0] != 1 || g.ks[0] != g.osp[0]) return false;
+        for (int i = 1; i < 3; ++i)
+            if (g.pa[i] != 1 || g.pc[i] != 0 || g.isp[i] != g.osp[i]) return false;
+        if (g.pc[0] != 0 || g.pa[0] != 1 || g.pb[0] != -1) return false;      // tap of output position o0 is o0 itself
+    }
+    if ((long long)o->batch * o->in_sn * 2 >= (1ll << 31) || (long long)g.M * g.out_ss >= (1ll << 31)) return false;
+    return true;
+}
+
+template <typename T>
+int run16_point(const T *in, const uint4 *wq, const float *bias, T *out, GemmGeom g, hipStream_t stream)
+{
+    const int S = g.osp[1] * g.osp[2], R = g.batch * S;
+    fastdiv_of((unsigned)g.osp[2], &g.dv_mul[0], &g.dv_shr[0]);
+    fastdiv_of((unsigned)g.osp[1], &g.dv_mul[1], &g.dv_shr[1]);
+    fastdiv_of((unsigned)S, &g.dv_mul[2], &g.dv_shr[2]);
+    const int n_tiles = (R + 127) / 128;
+    const int n_units = g.ks[0] * (g.J / 64) * n_tiles;
+    int blocks = device_cu_count();                   // 8 waves at a 256-register budget: one workgroup per CU
+    if (blocks > n_units) blocks = n_units;
+    const unsigned in_bytes = (unsigned)((long long)g.batch * g.in_sn * 2);
+    const unsigned out_bytes = (unsigned)((long long)g.M * g.out_ss * 2);
+#define QK_GO(NKC, E) hipLaunchKernelGGL((k_hgemm16_point<T, NKC, E>), dim3(blocks), dim3(512), 0, stream, in, wq, bias, out, g, n_tiles, n_units, in_bytes, out_bytes)
+    const bool epm = g.ep_mask != nullptr;
+    if (g.Q == 64) { if (epm) QK_GO(2, true); else QK_GO(2, false); }
+    else           { if (epm) QK_GO(1, true); else QK_GO(1, false); }
+#undef QK_GO
+    return hipGetLastError() == hipSuccess ? 1 : QK_ERR_LAUNCH;
+}
+
 template <typename T, int WM, int WN, int KIN, bool TRIM>
 int run16_band(const T *in, const uint4 *wq, const T *zero_line, const float *bias, T *out, const GemmGeom &g,
                hipStream_t stream)
@@ -890,6 +1110,10 @@ int go16(const void *in, const void *mask, const float *w, const float *bias, vo
     const uint4 *wq4 = reinterpret_cast<const uint4 *>(wq);
     const T *zero_line = wq + total;                 // 256 zeroed bytes behind the re-laid-out kernel
     GemmGeom bg;
+    if (!(debug_flags() & kDbgNoPoint16) && point_geom(g, &bg)) {
+        note_path(QK_PATH_MFMA16_POINT);
+        return run16_point<T>((const T *)in, wq4, bias, (T *)out, bg, stream);
+    }
     if (!(debug_flags() & kDbgNoBand16) && band_geom(g, 2, &bg)) {
         fastdiv_of((unsigned)bg.b_wp, &bg.dv_mul[0], &bg.dv_shr[0]);
         fastdiv_of((unsigned)bg.osp[1], &bg.dv_mul[1], &bg.dv_shr[1]);

@@ -133,6 +133,11 @@ ORACLE_CASES = [
      dict(padding='same', strides=(2, 1), activation='relu')),
     ('conv2d_64ch_valid_wide', 2, (1, 6, 70, 256), (3, 5, 64, 128),
      dict(padding='valid', activation=None)),
+    # one tap per produced row: the streaming point-form kernel (k_hgemm16_point) in 16 bit
+    ('dense_point_64', 0, (333, 256), (64, 256), dict(activation='relu')),
+    ('dense_point_32to128', 0, (200, 128), (32, 512), dict(activation=None)),
+    ('conv2d_head_valid_conj', 2, (3, 6, 50, 256), (6, 1, 64, 256), dict(padding='valid', activation=None, conj=True)),
+    ('conv1d_1x1_64', 1, (4, 77, 256), (1, 64, 256), dict(padding='same', activation='relu')),
     ('dense_qdnn0', 0, (32, 1000), (250, 512), dict(activation='relu')),
     ('dense_timit_head', 0, (300, 3584), (896, 256), dict(activation='relu')),
     ('dense_wide', 0, (130, 512), (128, 1024), dict(activation=None)),
@@ -165,7 +170,7 @@ def test_fp32_matches_oracle(case):
 HALF_CASES = [c for c in ORACLE_CASES if c[0] in (
     'cfg2_conv1d_b8_f64', 'conv1d_odd_channels', 'conv2d_body_small', 'conv2d_body64_small', 'conv2d_32to64', 'conv1d_64to32_valid',
     'conv2d_chfirst_body_small',
-    'conv2d_first_layer', 'dense_timit_head', 'conv3d_32ch', 'conv2d_32ch_outer_stride_dil', 'conv2d_64ch_valid_wide')]
+    'conv2d_first_layer', 'dense_timit_head', 'dense_point_64', 'dense_point_32to128', 'conv2d_head_valid_conj', 'conv1d_1x1_64', 'conv3d_32ch', 'conv2d_32ch_outer_stride_dil', 'conv2d_64ch_valid_wide')]
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16], ids=['bf16', 'fp16'])
@@ -211,6 +216,44 @@ def test_first_layer_tap_folding_matches_oracle(dtype, tol, fmt):
     assert _rel_err(bt.grad.cpu().numpy(), db) <= max(tol / 5, 1e-4)
     y_plain = F.quaternion_conv(xt, wt, bt, fold_small_cq=False, **kw)   # the unfolded kernels agree
     assert _rel_err(y_plain.detach().float().cpu().numpy(), yt.detach().float().cpu().numpy()) <= tol
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16], ids=['bf16', 'fp16'])
+def test_point_form_kernel_serves_one_tap_per_row_shapes(dtype):
+    """k_hgemm16_point (streaming form: kernel slice resident in LDS, A fragments straight from global memory) takes
+    1 x 1 / dense forwards and the backward-data of a kernel-spans-the-axis 'valid' convolution (the TIMIT head);
+    qk_last_path reports it, QK_DBG_NO_POINT16 routes the same call to the implicit-GEMM kernel, and both match the
+    oracle (rows not a multiple of the 128-row tile, more units than workgroups so kernel slices get reloaded)."""
+    import qcnn_amd
+    from qcnn_amd import _lib
+    from oracle import oracle
+    F = qcnn_amd.functional
+    dev = _dev()
+    rng = np.random.RandomState(3)
+    rnd = lambda *s: torch.tensor(rng.randn(*s).astype(np.float32)).to(dtype).float().numpy()
+    tol = 1e-2 if dtype == torch.bfloat16 else 2e-3
+    # backward-data of an (F, 1) 'valid' conj convolution: 9 taps x 5 row tiles x 2 column blocks
+    xs, ws = (37, 9, 17, 512), (9, 1, 128, 256)
+    w = (rnd(*ws) / 30).astype(np.float32)
+    w = torch.tensor(w).to(dtype).float().numpy()
+    dy = rnd(37, 1, 17, 256)
+    call = F.conv_call(xs, ws, dtype, 2, 1, 'valid', 'channels_last', 1, None, True, True)
+    wt, dyt = torch.tensor(w, device=dev), torch.tensor(dy, device=dev).to(dtype)
+    dx = call.bwd_data(dyt, None, wt)
+    assert _lib.last_path() == 'mfma16_point'
+    with _lib.debug_flags(_lib.QK_DBG_NO_POINT16):
+        dx_gemm = call.bwd_data(dyt, None, wt)
+        assert _lib.last_path() == 'mfma16'
+    want, _, _ = oracle.backward(np.zeros(xs, np.float32), w, None, dy, 2, padding='valid', activation=None, conj=True)
+    assert _rel_err(dx.float().cpu().numpy(), want) <= tol
+    assert _rel_err(dx_gemm.float().cpu().numpy(), want) <= tol
+    # 1 x 1 forward with bias and relu, 32 -> 128 quaternion channels (two column blocks)
+    xs, ws = (5, 61, 128), (1, 32, 512)
+    x, w, b = rnd(*xs), torch.tensor((rnd(*ws) / 8)).to(dtype).float().numpy(), (0.1 * rng.randn(512)).astype(np.float32)
+    call = F.conv_call(xs, ws, dtype, 1, 1, 'same', 'channels_last', 1, 'relu', True, False)
+    y = call.fwd(torch.tensor(x, device=dev).to(dtype), torch.tensor(w, device=dev), torch.tensor(b, device=dev))
+    assert _lib.last_path() == 'mfma16_point'
+    assert _rel_err(y.float().cpu().numpy(), oracle.forward(x, w, b, 1, padding='same', activation='relu')) <= tol
 
 
 def test_cpu_tensor_raises_no_fallback():
@@ -324,7 +367,7 @@ def test_full_size_16bit_mfma_kernels_agree_with_exact_fp32_kernels(case):
 
     from qcnn_amd import _lib
     fast = run(None)
-    assert _lib.last_path() in ('mfma16', 'mfma16_band')
+    assert _lib.last_path() in ('mfma16', 'mfma16_band', 'mfma16_point')
     with _lib.debug_flags(_lib.QK_DBG_NO_MFMA16):
         exact = run(fast[0])
         assert _lib.last_path() == 'fp32_mfma'
