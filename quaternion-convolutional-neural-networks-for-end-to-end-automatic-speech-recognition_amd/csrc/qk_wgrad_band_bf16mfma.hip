@@ -59,7 +59,8 @@ __device__ __forceinline__ uint4 bload16(__amdgpu_buffer_rsrc_t r, unsigned voff
 __device__ __forceinline__ void bstore16(const uint4 &d, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
 {
     u32x4 v; v.x = d.x; v.y = d.y; v.z = d.z; v.w = d.w;
-    __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)voff, (int)soff, 0);
+    // (soffset stays 0: gfx950 store-data hazard, see buf_store16b in qk_hgemm_bf16mfma.hip)
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)(voff + soff), 0, 0);
 }
 typedef unsigned short u2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned keep2(unsigned v, unsigned m)       // see relu_keep2 in qk_wgrad_bf16mfma.hip
