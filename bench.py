@@ -436,6 +436,34 @@ DEFAULT_WORKLOAD = 'cfg3_qcnn_timit_b256_bf16'
 QCNN_LAYER_COUNTS = {'cfg3_body_qconv2d_b256_bf16': 4, 'cfg3_stage1_qconv2d_b256_bf16': 5, 'cfg3_32to64_qconv2d_b256_bf16': 1}
 
 
+def in_step_kernel_times(job, dev, peak, steps=3):
+    """Every quaternion-layer call of `steps` training steps, timed by the library itself (qk_prof_*: a pair of HIP
+    events around each call's launches on their stream -- the backward runs on autograd's thread, several kernels per
+    C call).  Grouped by (operation, GEMM view); `ms` is the mean per call (kernel re-layout and memsets of the call
+    included), sorted by share of the step."""
+    from qcnn_amd import _lib
+    job.step()
+    torch.cuda.synchronize(dev)
+    with _lib.profile() as p:
+        for _ in range(steps):
+            job.step()
+        torch.cuda.synchronize(dev)
+        recs = p.records()
+    groups = {}
+    for r in recs:
+        groups.setdefault((r['op'], r['rows'], r['n'], r['k'], r['path']), []).append(r['ms'])
+    calls = []
+    for (op, rows, n, k, path), ms in groups.items():
+        mean = sum(ms) / len(ms)
+        tf = 2.0 * rows * n * k / (mean * 1e-3) / 1e12
+        calls.append({'op': op, 'rows': rows, 'n': n, 'k': k, 'path': path, 'calls_per_step': len(ms) // steps, 'ms': mean,
+                      'ms_min': min(ms), 'tflops': tf, 'frac_of_peak': tf / peak})
+    calls.sort(key=lambda c: -c['ms'] * c['calls_per_step'])
+    return {'steps': steps, 'calls': calls, 'ms_per_step_in_calls': sum(c['ms'] * c['calls_per_step'] for c in calls),
+            'timing': 'qk_prof_*: HIP events on the launch stream around each forward / backward-data / backward-weight call, '
+                      'mean over %d steps taken right after the timed region' % steps}
+
+
 def timed_steps(job, steps, warmup, pre, barrier, world, dev, dist):
     for _ in range(pre):
         job.step()
@@ -532,6 +560,11 @@ def main():
                             'flops_per_step': 3 * job.flops_per_kernel,
                             'note': 'algorithmic 2MNK fwd + 4MNK bwd of the quaternion layers / whole-step wall time'}
         out['step_tflops'] = tf
+    if rank == 0 and world == 1 and is_model and not args.no_kernel_timing:
+        try:
+            out['in_step_kernels'] = in_step_kernel_times(job, dev, peak)
+        except Exception as e:
+            out['in_step_kernels'] = {'error': repr(e)}
     if timing and is_model:
         # free the model's activations before the layer-level timing runs
         model_job, job = job, None
@@ -556,11 +589,29 @@ def main():
             (dwl, dom) = max(share, key=share.get)
             kern = hk[dom] if dwl == 'cfg3_body_qconv2d_b256_bf16' else out['layer_kernels'][dwl]['kernels'][dom]
             dflops = flops if dwl == 'cfg3_body_qconv2d_b256_bf16' else LayerFlops(dwl)
-            out['roofline'] = {'bound': 'mfma', 'kernel': '%s of %s (largest share of the step: %d launches x %.3f ms)'
-                                                       % (dom, dwl, QCNN_LAYER_COUNTS[dwl], kern['ms']),
-                               'achieved': kern['tflops'], 'peak': PEAK_TFLOPS['bf16'], 'unit': 'TFLOP/s',
-                               'frac': kern['tflops'] / PEAK_TFLOPS['bf16'], 'traffic': kern['hbm_bytes'],
-                               'flops_per_launch': dflops, 'avg_launch_ms': kern['ms']}
+            standalone = {'bound': 'mfma', 'kernel': '%s of %s (largest share of the step: %d launches x %.3f ms)'
+                                                     % (dom, dwl, QCNN_LAYER_COUNTS[dwl], kern['ms']),
+                          'achieved': kern['tflops'], 'peak': PEAK_TFLOPS['bf16'], 'unit': 'TFLOP/s',
+                          'frac': kern['tflops'] / PEAK_TFLOPS['bf16'], 'traffic': kern['hbm_bytes'],
+                          'flops_per_launch': dflops, 'avg_launch_ms': kern['ms'],
+                          'note': 'the same kernel launched alone, back to back, on dense random operands'}
+            top = (out.get('in_step_kernels') or {}).get('calls') or []
+            if top:
+                # the dominant kernel, timed where the metric is: inside the training step (HIP events of the library's
+                # qk_prof_* on the launch stream, activations as the network produces them)
+                t = top[0]
+                wl_of = {(716800, 256, 3840): 'cfg3_body_qconv2d_b256_bf16', (716800, 128, 1920): 'cfg3_stage1_qconv2d_b256_bf16',
+                         (716800, 256, 1920): 'cfg3_32to64_qconv2d_b256_bf16'}
+                kname = {'fwd': 'fwd', 'bwd_weight': 'bwd_weight_chain', 'bwd_data': 'bwd_data_chain'}[t['op']]
+                twl = wl_of.get((t['rows'], t['n'], t['k']))
+                out['roofline'] = {'bound': 'mfma', 'kernel': '%s of the %d x %d x %d layer, in the step (%d calls per step x %.3f ms: largest share)'
+                                                           % (t['op'], t['rows'], t['n'], t['k'], t['calls_per_step'], t['ms']),
+                                   'achieved': t['tflops'], 'peak': PEAK_TFLOPS['bf16'], 'unit': 'TFLOP/s', 'frac': t['frac_of_peak'],
+                                   'traffic': pmc_traffic(twl, kname) if twl else None,
+                                   'flops_per_launch': 2.0 * t['rows'] * t['n'] * t['k'], 'avg_launch_ms': t['ms'],
+                                   'standalone': standalone}
+            else:
+                out['roofline'] = standalone
         except Exception as e:
             out['hamilton_gemm'] = {'error': repr(e)}
         if not args.no_extras:

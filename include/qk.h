@@ -134,6 +134,25 @@ typedef enum { QK_PATH_NONE = 0, QK_PATH_MFMA16 = 1, QK_PATH_MFMA16_BAND = 2, QK
                QK_PATH_MFMA16_POINT = 4 } qk_path_t;
 int qk_last_path(void);
 
+/* Per-call timing for benchmarks.  While enabled, every forward / backward-data / backward-weight call (including the
+ * two halves of qk_*_bwd and the fused first-layer calls) is bracketed by a pair of HIP events on the caller's stream;
+ * the records stay in a process-wide list until the next qk_prof_enable(1).  `ms` covers everything the call launched
+ * (kernel re-layout, memsets, the GEMM kernel); rows x n x k is the GEMM view of the layer (rows = output positions,
+ * n = 4 fq, k = taps * 4 cq), so 2 * rows * n * k / ms is the call's algorithmic rate.  qk_prof_get waits for the
+ * record's events (host synchronisation: call it after the region of interest).  Off by default; costs one atomic load
+ * per call when off. */
+typedef struct {
+    int32_t op;        /* QK_OP_FWD, QK_OP_BWD_DATA or QK_OP_BWD_WEIGHT */
+    int32_t dtype;
+    int32_t path;      /* qk_path_t that served it */
+    int64_t rows;
+    int32_t n, k;
+    float ms;
+} qk_prof_rec_t;
+int qk_prof_enable(int on);          /* returns the previous state; enabling clears the list */
+int qk_prof_count(void);
+int qk_prof_get(int index, qk_prof_rec_t *out);
+
 /* Bytes of caller-owned device workspace `op` needs for this descriptor (0 = none). */
 size_t qk_conv_workspace_bytes(const qk_conv_desc_t *desc, int op /* qk_op_t */);
 size_t qk_dense_workspace_bytes(const qk_dense_desc_t *desc, int op /* qk_op_t */);

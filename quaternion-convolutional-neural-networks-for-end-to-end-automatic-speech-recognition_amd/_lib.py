@@ -56,8 +56,17 @@ class PostOp(ctypes.Structure):
 
 _PO = ctypes.POINTER(PostOp)
 
+class ProfRec(ctypes.Structure):
+    """qk_prof_rec_t (include/qk.h)"""
+    _fields_ = [('op', I32), ('dtype', I32), ('path', I32), ('rows', ctypes.c_int64), ('n', I32), ('k', I32),
+                ('ms', ctypes.c_float)]
+
+
 SYMBOLS = {
     'qk_version': (ctypes.c_int, []),
+    'qk_prof_enable': (ctypes.c_int, [ctypes.c_int]),
+    'qk_prof_count': (ctypes.c_int, []),
+    'qk_prof_get': (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ProfRec)]),
     'qk_last_error': (ctypes.c_char_p, []),
     'qk_set_debug_flags': (ctypes.c_uint, [ctypes.c_uint]),
     'qk_get_debug_flags': (ctypes.c_uint, []),
@@ -132,6 +141,31 @@ class debug_flags(object):
     def __exit__(self, *exc):
         lib().qk_set_debug_flags(self.prev)
         return False
+
+
+class profile(object):
+    """`with profile() as p: step()` then `p.records()`: every forward / backward-data / backward-weight call made
+    inside the block (any thread, any stream) with its GEMM view and the milliseconds its launches took on their
+    stream (qk_prof_*, HIP events recorded by the library).  records() synchronises."""
+
+    OPS = {QK_OP_FWD: 'fwd', QK_OP_BWD_DATA: 'bwd_data', QK_OP_BWD_WEIGHT: 'bwd_weight'}
+
+    def __enter__(self):
+        lib().qk_prof_enable(1)
+        return self
+
+    def __exit__(self, *exc):
+        lib().qk_prof_enable(0)
+        return False
+
+    def records(self):
+        out = []
+        rec = ProfRec()
+        for i in range(lib().qk_prof_count()):
+            check(lib().qk_prof_get(i, ctypes.byref(rec)), 'qk_prof_get')
+            out.append(dict(op=self.OPS.get(rec.op, str(rec.op)), dtype=rec.dtype, path=QK_PATH_NAMES.get(rec.path, 'none'),
+                            rows=int(rec.rows), n=int(rec.n), k=int(rec.k), ms=float(rec.ms)))
+        return out
 
 
 def last_path():

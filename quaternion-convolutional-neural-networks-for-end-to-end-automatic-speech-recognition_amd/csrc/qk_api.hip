@@ -8,6 +8,8 @@
 #include "qk_common.h"
 
 #include <atomic>
+#include <mutex>
+#include <vector>
 
 namespace qk {
 
@@ -47,6 +49,41 @@ const ForceCfg &force_cfg()
 }  // namespace
 
 unsigned debug_flags() { return dbg_word().load(std::memory_order_relaxed); }
+
+// ---- per-call timing (qk_prof_*, include/qk.h) ------------------------------------------------------------------
+// Off: one relaxed atomic load per compute call.  On: a pair of HIP events around the call's launches ON THE CALLER'S
+// STREAM, kept in a process-wide list until the next qk_prof_enable(1); qk_prof_get synchronises the pair it reads.
+// This is how bench.py times the kernels INSIDE the training step (autograd runs the backward on another thread and
+// several kernels per C call, so neither Python-side events nor per-kernel wrappers can).
+namespace {
+struct ProfRec { int op, dtype, path; long long rows; int n, k; hipEvent_t e0, e1; };
+struct Prof { std::mutex mu; std::atomic<int> on{0}; std::vector<ProfRec> recs; };
+Prof &prof() { static Prof p; return p; }
+}  // namespace
+struct ProfScope {
+    bool live = false;
+    ProfRec r;
+    hipStream_t stream;
+    ProfScope(int op, const qk_conv_desc_t *d, hipStream_t st) : stream(st)
+    {
+        if (!prof().on.load(std::memory_order_relaxed) || !d) return;
+        r.op = op; r.dtype = d->dtype; r.path = QK_PATH_NONE;
+        r.rows = (long long)d->batch * d->out_spatial[0] * d->out_spatial[1] * d->out_spatial[2];
+        r.n = 4 * d->fq;
+        r.k = 4 * d->cq * d->kernel[0] * d->kernel[1] * d->kernel[2];
+        if (hipEventCreate(&r.e0) != hipSuccess) return;
+        if (hipEventCreate(&r.e1) != hipSuccess) { (void)hipEventDestroy(r.e0); return; }
+        live = hipEventRecord(r.e0, stream) == hipSuccess;
+    }
+    ~ProfScope()
+    {
+        if (!live) return;
+        (void)hipEventRecord(r.e1, stream);
+        r.path = g_path;
+        std::lock_guard<std::mutex> lk(prof().mu);
+        prof().recs.push_back(r);
+    }
+};
 bool debug_force_cfg(int *policy, int *bq)
 {
     const ForceCfg &c = force_cfg();
@@ -237,6 +274,7 @@ int conv_fwd_impl(const qk_conv_desc_t *d, const void *x, const float *w, const 
 {
     if (!x || !w || !y) { set_error("x/w/y must not be NULL"); return QK_ERR_INVALID_ARG; }
     if (d->has_bias && !bias) { set_error("has_bias set but bias is NULL"); return QK_ERR_INVALID_ARG; }
+    ProfScope prof_scope(QK_OP_FWD, d, stream);
     GemmGeom g;
     memset(&g, 0, sizeof(g));
     const Strides xs = act_strides(d->in_spatial, 4 * d->cq, d->layout);
@@ -287,6 +325,7 @@ int conv_bwd_data_impl(const qk_conv_desc_t *d, const void *dy, const void *y, c
         return QK_ERR_WORKSPACE;
     }
     if (need && !aligned(ws, 16)) { set_error("workspace must be 16-byte aligned"); return QK_ERR_WORKSPACE; }
+    ProfScope prof_scope(QK_OP_BWD_DATA, d, stream);
     GemmGeom g;
     memset(&g, 0, sizeof(g));
     const Strides dys = act_strides(d->out_spatial, 4 * d->fq, d->layout);
@@ -340,6 +379,7 @@ int conv_bwd_weight_impl(const qk_conv_desc_t *d, const void *x, const void *dy,
     const bool mask = d->activation == QK_ACT_RELU;
     if (mask && !y) { set_error("activation is RELU: the forward output y is required"); return QK_ERR_INVALID_ARG; }
     if (d->has_bias && !dbias) { set_error("has_bias set but dbias is NULL"); return QK_ERR_INVALID_ARG; }
+    ProfScope prof_scope(QK_OP_BWD_WEIGHT, d, stream);
     WgradGeom g;
     memset(&g, 0, sizeof(g));
     const Strides xs = act_strides(d->in_spatial, 4 * d->cq, d->layout);
@@ -447,6 +487,39 @@ const char *qk_last_error(void) { return g_err; }
 unsigned qk_set_debug_flags(unsigned flags) { return dbg_word().exchange(flags, std::memory_order_relaxed); }
 unsigned qk_get_debug_flags(void) { return debug_flags(); }
 int qk_last_path(void) { return g_path; }
+
+int qk_prof_enable(int on)
+{
+    Prof &p = prof();
+    std::lock_guard<std::mutex> lk(p.mu);
+    const int was = p.on.exchange(on ? 1 : 0, std::memory_order_relaxed);
+    if (on) {                                   // a new recording: drop the previous one
+        for (ProfRec &r : p.recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+        p.recs.clear();
+    }
+    return was;
+}
+int qk_prof_count(void)
+{
+    std::lock_guard<std::mutex> lk(prof().mu);
+    return (int)prof().recs.size();
+}
+int qk_prof_get(int i, qk_prof_rec_t *out)
+{
+    if (!out) { set_error("qk_prof_get: out is NULL"); return QK_ERR_INVALID_ARG; }
+    ProfRec r;
+    {
+        std::lock_guard<std::mutex> lk(prof().mu);
+        if (i < 0 || i >= (int)prof().recs.size()) { set_error("qk_prof_get: record %d of %zu", i, prof().recs.size()); return QK_ERR_INVALID_ARG; }
+        r = prof().recs[i];
+    }
+    float ms = 0.f;
+    if (hipEventSynchronize(r.e1) != hipSuccess || hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) {
+        set_error("qk_prof_get: the events of record %d could not be read", i); return QK_ERR_LAUNCH;
+    }
+    out->op = r.op; out->dtype = r.dtype; out->path = r.path; out->rows = r.rows; out->n = r.n; out->k = r.k; out->ms = ms;
+    return QK_OK;
+}
 
 size_t qk_conv_workspace_bytes(const qk_conv_desc_t *desc, int op)
 {
@@ -638,6 +711,7 @@ int qk_conv_relu_pool_fwd(const qk_conv_desc_t *desc, int32_t pool, const void *
     if (!x || !w || !pooled || (desc->has_bias && !bias)) { set_error("qk_conv_relu_pool_fwd: NULL argument"); return QK_ERR_INVALID_ARG; }
     if (!aligned(x, 8) || !aligned(pooled, 16) || (aux && !aligned(aux, 16))) { set_error("qk_conv_relu_pool_fwd: alignment"); return QK_ERR_INVALID_ARG; }
     note_path(QK_PATH_MFMA16);
+    ProfScope prof_scope(QK_OP_FWD, desc, (hipStream_t)stream);
     return check_launch(launch_conv1_pool(desc->dtype, false, x, w, bias, pooled, aux, nullptr, nullptr, desc->batch, desc->in_spatial[0],
                                           desc->in_spatial[1], desc->fq, desc->has_bias, (hipStream_t)stream), "qk_conv_relu_pool_fwd");
 }
@@ -650,11 +724,12 @@ int qk_conv_relu_pool_bwd(const qk_conv_desc_t *desc, int32_t pool, const void *
     if (!x || !dpooled || !aux || !dw || (desc->has_bias && !dbias)) { set_error("qk_conv_relu_pool_bwd: NULL argument"); return QK_ERR_INVALID_ARG; }
     if (!aligned(x, 8) || !aligned(dpooled, 16) || !aligned(aux, 16)) { set_error("qk_conv_relu_pool_bwd: alignment"); return QK_ERR_INVALID_ARG; }
     hipStream_t st = (hipStream_t)stream;
+    note_path(QK_PATH_MFMA16);
+    ProfScope prof_scope(QK_OP_BWD_WEIGHT, desc, st);
     if (hipMemsetAsync(dw, 0, w_floats(desc) * sizeof(float), st) != hipSuccess ||
         (desc->has_bias && hipMemsetAsync(dbias, 0, 4 * (size_t)desc->fq * sizeof(float), st) != hipSuccess)) {
         set_error("memset dw failed"); return QK_ERR_LAUNCH;
     }
-    note_path(QK_PATH_MFMA16);
     return check_launch(launch_conv1_pool(desc->dtype, true, x, nullptr, nullptr, dpooled, const_cast<void *>(aux), dw, desc->has_bias ? dbias : nullptr,
                                           desc->batch, desc->in_spatial[0], desc->in_spatial[1], desc->fq, desc->has_bias, st), "qk_conv_relu_pool_bwd");
 }

@@ -1004,3 +1004,25 @@ def test_fused_first_layer_conv_relu_pool_matches_oracle(shape, F, dtype):
     assert _rel_err(out.detach().float().cpu().numpy(), pooled) <= tol16
     assert _rel_err(wt.grad.cpu().numpy(), dw) <= tol32
     assert _rel_err(bt.grad.cpu().numpy(), db) <= tol32
+
+
+def test_library_profiler_times_every_call_of_a_backward():
+    """qk_prof_* (include/qk.h): with the recorder on, a layer's forward and its fused backward (backward-weight +
+    backward-data inside ONE C call, on autograd's thread) leave three records carrying the layer's GEMM view, the
+    kernel family that served them and a positive duration; off again, nothing is recorded."""
+    import qcnn_amd
+    from qcnn_amd import _lib
+    F = qcnn_amd.functional
+    dev = _dev()
+    x = torch.randn(4, 14, 40, 128, device=dev).to(torch.bfloat16).requires_grad_(True)
+    w = (torch.randn(3, 5, 32, 128, device=dev) / 20).requires_grad_(True)
+    with _lib.profile() as p:
+        y = F.quaternion_conv(x, w, None, padding='same', activation='relu')
+        y.backward(torch.ones_like(y))
+        torch.cuda.synchronize()
+        recs = p.records()
+    assert sorted(r['op'] for r in recs) == ['bwd_data', 'bwd_weight', 'fwd']
+    for r in recs:
+        assert (r['rows'], r['n'], r['k']) == (4 * 14 * 40, 128, 3 * 5 * 128) and r['ms'] > 0 and r['path'].startswith('mfma16')
+    F.quaternion_conv(x, w, None, padding='same', activation='relu')
+    assert _lib.lib().qk_prof_count() == 3
