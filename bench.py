@@ -492,6 +492,7 @@ def main():
     ap.add_argument('--cpu-seconds', type=float, default=16.0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
+    ap.add_argument('--no-standalone', action='store_true', help='skip the isolated-kernel blocks (hamilton_gemm, layer_kernels, roofline.standalone)')
     ap.add_argument('--no-extras', action='store_true', help='skip the cfg2_layer / layer_kernels blocks of the default line')
     ap.add_argument('--graph', action='store_true',
                     help='layer workloads: replay the step as a hipGraph (measured 3 %% SLOWER than eager back-to-back '
@@ -565,7 +566,21 @@ def main():
             out['in_step_kernels'] = in_step_kernel_times(job, dev, peak)
         except Exception as e:
             out['in_step_kernels'] = {'error': repr(e)}
-    if timing and is_model:
+        top = (out.get('in_step_kernels') or {}).get('calls') or []
+        if top:
+            # the dominant kernel, timed where the metric is: inside the training step (HIP events of the library's
+            # qk_prof_* on the launch stream, activations as the network produces them)
+            t = top[0]
+            wl_of = {(716800, 256, 3840): 'cfg3_body_qconv2d_b256_bf16', (716800, 128, 1920): 'cfg3_stage1_qconv2d_b256_bf16',
+                     (716800, 256, 1920): 'cfg3_32to64_qconv2d_b256_bf16'}
+            kname = {'fwd': 'fwd', 'bwd_weight': 'bwd_weight_chain', 'bwd_data': 'bwd_data_chain'}[t['op']]
+            twl = wl_of.get((t['rows'], t['n'], t['k']))
+            out['roofline'] = {'bound': 'mfma', 'kernel': '%s of the %d x %d x %d layer, in the step (%d calls per step x %.3f ms: largest share)'
+                                                       % (t['op'], t['rows'], t['n'], t['k'], t['calls_per_step'], t['ms']),
+                               'achieved': t['tflops'], 'peak': peak, 'unit': 'TFLOP/s', 'frac': t['frac_of_peak'],
+                               'traffic': pmc_traffic(twl, kname) if twl else None,
+                               'flops_per_launch': 2.0 * t['rows'] * t['n'] * t['k'], 'avg_launch_ms': t['ms']}
+    if timing and is_model and not args.no_standalone:
         # free the model's activations before the layer-level timing runs
         model_job, job = job, None
         del model_job
@@ -595,25 +610,15 @@ def main():
                           'frac': kern['tflops'] / PEAK_TFLOPS['bf16'], 'traffic': kern['hbm_bytes'],
                           'flops_per_launch': dflops, 'avg_launch_ms': kern['ms'],
                           'note': 'the same kernel launched alone, back to back, on dense random operands'}
-            top = (out.get('in_step_kernels') or {}).get('calls') or []
-            if top:
-                # the dominant kernel, timed where the metric is: inside the training step (HIP events of the library's
-                # qk_prof_* on the launch stream, activations as the network produces them)
-                t = top[0]
-                wl_of = {(716800, 256, 3840): 'cfg3_body_qconv2d_b256_bf16', (716800, 128, 1920): 'cfg3_stage1_qconv2d_b256_bf16',
-                         (716800, 256, 1920): 'cfg3_32to64_qconv2d_b256_bf16'}
-                kname = {'fwd': 'fwd', 'bwd_weight': 'bwd_weight_chain', 'bwd_data': 'bwd_data_chain'}[t['op']]
-                twl = wl_of.get((t['rows'], t['n'], t['k']))
-                out['roofline'] = {'bound': 'mfma', 'kernel': '%s of the %d x %d x %d layer, in the step (%d calls per step x %.3f ms: largest share)'
-                                                           % (t['op'], t['rows'], t['n'], t['k'], t['calls_per_step'], t['ms']),
-                                   'achieved': t['tflops'], 'peak': PEAK_TFLOPS['bf16'], 'unit': 'TFLOP/s', 'frac': t['frac_of_peak'],
-                                   'traffic': pmc_traffic(twl, kname) if twl else None,
-                                   'flops_per_launch': 2.0 * t['rows'] * t['n'] * t['k'], 'avg_launch_ms': t['ms'],
-                                   'standalone': standalone}
+            if 'roofline' in out:
+                out['roofline']['standalone'] = standalone
             else:
                 out['roofline'] = standalone
         except Exception as e:
             out['hamilton_gemm'] = {'error': repr(e)}
+    if timing and is_model:
+        job = None
+        torch.cuda.empty_cache()
         if not args.no_extras:
             try:        # the reference's own activation setting: linear layers + PReLU + Dropout(0.3), fused post-ops
                 pcfg = dict(WORKLOADS['cfg3_qcnn_prelu_dropout_b256_bf16'], activation='prelu')
