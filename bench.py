@@ -580,6 +580,16 @@ def main():
                                'achieved': t['tflops'], 'peak': peak, 'unit': 'TFLOP/s', 'frac': t['frac_of_peak'],
                                'traffic': pmc_traffic(twl, kname) if twl else None,
                                'flops_per_launch': 2.0 * t['rows'] * t['n'] * t['k'], 'avg_launch_ms': t['ms']}
+            # a kernel-trace summary averages by kernel NAME: the same instantiation also serves the layers with the same
+            # (operation, output width, kernel family) and another K
+            same = [c for c in top if c is not t and (c['op'], c['rows'], c['n'], c['path']) == (t['op'], t['rows'], t['n'], t['path'])]
+            if same:
+                calls = t['calls_per_step'] + sum(c['calls_per_step'] for c in same)
+                total = t['ms'] * t['calls_per_step'] + sum(c['ms'] * c['calls_per_step'] for c in same)
+                out['roofline']['kernel_trace_note'] = ('a rocprofv3 --stats average by kernel name also contains %s: expect %.3f ms over %d launches per step '
+                                                        '(the calls include the ~5 us kernel re-layout launch that precedes the GEMM kernel)'
+                                                        % (', '.join('%d x the %d-deep layer at %.3f ms' % (c['calls_per_step'], c['k'], c['ms']) for c in same),
+                                                           total / calls, calls))
     if timing and is_model and not args.no_standalone:
         # free the model's activations before the layer-level timing runs
         model_job, job = job, None
