@@ -730,8 +730,12 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
 #pragma unroll
                     for (int b = 0; b < 4; ++b) {
                         constexpr unsigned tbl = TBL;
-                        if ((tbl >> (a * 4 + b)) & 1u) accn[b] = mfma16(T(), A[a], B[a ^ b], accn[b]);
-                        else acc[b] = mfma16(T(), A[a], B[a ^ b], acc[b]);
+                        // kernel fragment as the MFMA's A operand, activation fragment as its B operand (both hold 8
+                        // consecutive K values of line `lr`: the roles swap for free): the accumulator tile comes out
+                        // TRANSPOSED -- lane = output row, register r = channel (r & 3) + 8 (r >> 2) + 4 lh -- so a
+                        // lane's values are contiguous channels of ONE row and the epilogue needs no LDS transpose
+                        if ((tbl >> (a * 4 + b)) & 1u) accn[b] = mfma16(T(), B[a ^ b], A[a], accn[b]);
+                        else acc[b] = mfma16(T(), B[a ^ b], A[a], acc[b]);
                         const int f = ks * 16 + a * 4 + b;
                         if (f % 2 == 1) {
                             const int op = f / 2;                        // staging slot of this sub-step
@@ -751,83 +755,83 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
         a_advance_if_more();
     }
 
-    // ---- epilogue: bias + activation, per-wave LDS transpose, 16-byte stores (see k_hgemm16) --------
+    // ---- epilogue: bias + activation (+ chain mask / post-op), 16-byte stores -----------------------------
+    // A lane owns output row `lr` of the wave tile and, per component, channels 8g + 4lh + (0..3), g = 0..3.  One
+    // v_permlane32_swap per packed dword pairs the lh halves: lanes 0..31 end up with channels 16q .. 16q+7, lanes
+    // 32..63 with 16q+8 .. 16q+15 of their row -- two 16-byte stores per component and no trip through LDS (the
+    // per-wave transpose patches were 8 - 18 % of these kernels by ablation).
     if ((g.ablate & 8) && acc[0][0] != 123.456f) return;              // (ablate 8: profiling, no epilogue)
-    constexpr int EP_PITCH = 80;
-    char *ep = reinterpret_cast<char *>(lds) + wave * (32 * EP_PITCH);
-    const int e_row = lane >> 2, e_chunk = lane & 3;
-    // output rows of this lane's two passes (rows of padded lines -> real rows), and -- for the chain
-    // backward (QK_BWD_MASK_DX) -- the eight 16-byte pieces of the mask tensor it will need, requested
-    // up front so that their latency hides under the transposes (the staging registers are idle here)
-    long long o_row[2];
-    bool o_ok[2];
-    int a_key[2] = {0, 0};                                           // post-op: alpha index of the lane's two rows
     const bool post_on = (EPM || POSTF) && g.post.kind != 0;
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-        const int tr = wm * 32 + e_row + 16 * pass;                  // row inside the tile
+    const int tr = wm * 32 + lr;                                     // row inside the tile
+    bool o_ok;
+    long long o_row;                                                 // element offset of the lane's first piece, component 0
+    int a_key = 0;                                                   // post-op: alpha index of the lane's row
+    {
         const int P = p0 + tr;
         const int line = fastdiv(P, g.dv_mul[0], g.dv_shr[0]);
         const int u = P - line * WP;
-        o_ok[pass] = line < g.b_nlines && u < g.osp[2] && (!TRIM || tr < BMU);
-        o_row[pass] = (long long)(line * g.osp[2] + u) * (int)g.out_ss + j0 + wn * 32 + e_chunk * 8;
-        if ((EPM || POSTF) && post_on && g.post.alpha_sel >= 0 && o_ok[pass]) {
+        o_ok = line < g.b_nlines && u < g.osp[2] && (!TRIM || tr < BMU);
+        o_row = (long long)(line * g.osp[2] + u) * (int)g.out_ss + j0 + wn * 32 + lh * 8;
+        if ((EPM || POSTF) && post_on && g.post.alpha_sel >= 0 && o_ok) {
             const int l2 = fastdiv(line, g.dv_mul[1], g.dv_shr[1]), o1 = line - l2 * g.osp[1];
             const int nn = fastdiv(l2, g.dv_mul[2], g.dv_shr[2]), o0 = l2 - nn * g.osp[0];
-            a_key[pass] = g.post.alpha_sel == 0 ? o0 : g.post.alpha_sel == 1 ? o1 : u;
+            a_key = g.post.alpha_sel == 0 ? o0 : g.post.alpha_sel == 1 ? o1 : u;
         }
     }
-    float a_val[2] = {0.f, 0.f}, dal[2] = {0.f, 0.f};
+    float a_val = 0.f, dal = 0.f;
     float *aslab = reinterpret_cast<float *>(reinterpret_cast<char *>(lds) + 32768);   // 256 d-alpha sums (backward post-op)
-    if ((EPM || POSTF) && post_on) {
-        a_val[0] = g.post.alpha[a_key[0]]; a_val[1] = g.post.alpha[a_key[1]];
-        if (EPM && g.dalpha) {
-            if (tid < 256) aslab[tid] = 0.f;
-            __syncthreads();
-        }
-    }
+    float *bias_s = reinterpret_cast<float *>(reinterpret_cast<char *>(lds) + 34816);  // this tile's 4 x BF bias values
+    if ((EPM || POSTF) && post_on) a_val = g.post.alpha[a_key];
+    // (the K loop's last barrier is behind every wave: the tile buffers are free)
+    if (g.has_bias && tid < 4 * BF) bias_s[tid] = bias[(tid / BF) * g.J + j0 + tid % BF];
+    if (EPM && post_on && g.dalpha && tid < 256) aslab[tid] = 0.f;
+    if (g.has_bias || (EPM && post_on && g.dalpha)) __syncthreads();
     uint4 em[EPM ? 4 : 1][2];
     if (EPM && g.ep_mask) {
 #pragma unroll
         for (int b = 0; b < 4; ++b)
 #pragma unroll
-            for (int pass = 0; pass < 2; ++pass)
-                em[b][pass] = o_ok[pass] ? *reinterpret_cast<const uint4 *>(static_cast<const T *>(g.ep_mask) + o_row[pass] + b * g.J)
-                                         : make_uint4(0u, 0u, 0u, 0u);
+            for (int q = 0; q < 2; ++q)
+                em[b][q] = o_ok ? *reinterpret_cast<const uint4 *>(static_cast<const T *>(g.ep_mask) + o_row + b * g.J + q * 16)
+                                : make_uint4(0u, 0u, 0u, 0u);
     }
-    // all four bias values up front: a load inside the component loop makes every iteration wait for vmcnt(0), i.e.
-    // for the previous iteration's global STORES to be acknowledged as well (~6 us per tile, measured by ablation)
-    float bia4[4];
-#pragma unroll
-    for (int b = 0; b < 4; ++b) bia4[b] = g.has_bias ? bias[b * g.J + j0 + wn * 32 + lr] : 0.f;
+    const float4 *bias_rd = reinterpret_cast<const float4 *>(bias_s) + wn * 8 + lh;
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-        const float bia = bia4[b];
+        unsigned pk[4][2];
 #pragma unroll
-        for (int r = 0; r < 16; r += 2) {                   // registers r, r + 1 hold consecutive rows
-            float v0 = acc[b][r] - accn[b][r] + bia, v1 = acc[b][r + 1] - accn[b][r + 1] + bia;
-            if (g.relu) { v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f; }
-            const unsigned pk = pack2(T(), v0, v1);
-            char *dst = ep + mfma32_row(r, lane) * EP_PITCH + lr * 2;
-            *reinterpret_cast<unsigned short *>(dst) = (unsigned short)pk;
-            *reinterpret_cast<unsigned short *>(dst + EP_PITCH) = (unsigned short)(pk >> 16);
+        for (int gq = 0; gq < 4; ++gq) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[b][4 * gq + e] - accn[b][4 * gq + e];
+            if (g.has_bias) {
+                const float4 bb = bias_rd[b * (BF / 4) + 2 * gq];
+                v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+            }
+            if (g.relu) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+            }
+            pk[gq][0] = pack2(T(), v[0], v[1]);
+            pk[gq][1] = pack2(T(), v[2], v[3]);
         }
 #pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
-            const int row = e_row + 16 * pass;
-            uint4 v = *reinterpret_cast<const uint4 *>(ep + row * EP_PITCH + e_chunk * 16);
-            if (o_ok[pass]) {
-                const long long o = o_row[pass] + b * g.J;
+        for (int q = 0; q < 2; ++q) {
+            const auto s0 = __builtin_amdgcn_permlane32_swap(pk[2 * q][0], pk[2 * q + 1][0], false, false);
+            const auto s1 = __builtin_amdgcn_permlane32_swap(pk[2 * q][1], pk[2 * q + 1][1], false, false);
+            uint4 v = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+            if (o_ok) {
+                const long long o = o_row + b * g.J + q * 16;
                 if constexpr (EPM) {
                     if (g.ep_mask) {
-                        if (post_on) v = post_bwd8<T>(v, em[b][pass], a_val[pass], (unsigned)o, g.post, dal[pass]);
-                        else v = mask8(v, em[b][pass]);
+                        if (post_on) v = post_bwd8<T>(v, em[b][q], a_val, (unsigned)o, g.post, dal);
+                        else v = mask8(v, em[b][q]);
                     }
                 }
                 if constexpr (POSTF) {
                     if (post_on) {
                         *reinterpret_cast<uint4 *>(static_cast<T *>(g.pre_out) + o) = v;
-                        v = post_fwd8<T>(v, a_val[pass], (unsigned)o, g.post);
+                        v = post_fwd8<T>(v, a_val, (unsigned)o, g.post);
                     }
                 }
                 *reinterpret_cast<uint4 *>(out + o) = v;
@@ -836,8 +840,7 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
     }
     if constexpr (EPM) {
         if (post_on && g.dalpha) {                        // d alpha: wave sums by key -> LDS -> one global atomic per key
-            wave_add_by_key(dal[0], a_key[0], aslab, lane);
-            wave_add_by_key(dal[1], a_key[1], aslab, lane);
+            wave_add_by_key(dal, a_key, aslab, lane);
             __syncthreads();
             if (tid < g.post.alpha_len && aslab[tid] != 0.f) atomicAdd(g.dalpha + tid, aslab[tid]);
         }
