@@ -875,7 +875,7 @@ k_hgemm16_point(const T *__restrict__ in, const uint4 *__restrict__ wq, const fl
     constexpr int B_U = NKC * 16 * BF;               // 16-byte units of one (tap, column block) kernel slice
     constexpr unsigned TBL = kSignConj;              // go16 folds the plain table into the kernel
     constexpr int EP_PITCH = 80;
-    __shared__ __attribute__((aligned(16))) uint4 lds[B_U + 4 * BF / 4 + 8 * 32 * EP_PITCH / 16];   // kernel slice, its bias (4 x BF floats), transpose patches
+    __shared__ __attribute__((aligned(16))) uint4 lds[B_U + 4 * BF / 4 + 8 * 32 * EP_PITCH / 16 + 64];   // kernel slice, its bias (4 x BF floats), transpose patches, 256 d-alpha sums
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -913,6 +913,10 @@ k_hgemm16_point(const T *__restrict__ in, const uint4 *__restrict__ wq, const fl
             for (int a = 0; a < 4; ++a) load_frag(v0, a, f);
     }
     int cur_slice = -1;
+    // backward post-op (PReLU / dropout derivative of the tensor whose gradient is produced, see k_hgemm16)
+    const bool post_on = EPM && g.post.kind != 0;
+    float *aslab = reinterpret_cast<float *>(lds + B_U + BF + 8 * 32 * EP_PITCH / 16);
+    if (post_on && g.dalpha && tid < 256) aslab[tid] = 0.f;      // (the first unit's slice load brings the barrier)
     const uint4 *w_rd = lds + wn * 32 + lr;
     const float *bias_rd = reinterpret_cast<const float *>(lds + B_U) + wn * 32 + lr;
     char *ep = reinterpret_cast<char *>(lds + B_U + BF) + wave * (32 * EP_PITCH);
@@ -940,12 +944,19 @@ k_hgemm16_point(const T *__restrict__ in, const uint4 *__restrict__ wq, const fl
         }
         // rows this lane stores (two passes of 16): byte offsets of their component-0 pieces
         unsigned o_off[2];
+        int a_key[2] = {0, 0};
+        float a_val[2] = {0.f, 0.f}, dal[2] = {0.f, 0.f};
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
             const int r = tile * BM + wm * 32 + e_row + 16 * pass;
             const int n = fastdiv(r, g.dv_mul[2], g.dv_shr[2]), sp = r - n * S;
             const unsigned o = (unsigned)(((n * T_ + tap) * S + sp) * (int)g.out_ss + jb * BF + wn * 32 + e_chunk * 8) * 2u;
             o_off[pass] = r < R ? o : kOutOfRange16;
+            if (post_on) {
+                const int o1 = fastdiv(sp, g.dv_mul[0], g.dv_shr[0]);
+                a_key[pass] = g.post.alpha_sel < 0 ? 0 : g.post.alpha_sel == 0 ? tap : g.post.alpha_sel == 1 ? o1 : sp - o1 * g.osp[2];
+                a_val[pass] = g.post.alpha[a_key[pass]];
+            }
         }
         // next unit's rows (same rows when only the tap changes); past the range: nothing is fetched
         const bool more = u + 1 < u_hi;
@@ -1004,10 +1015,21 @@ k_hgemm16_point(const T *__restrict__ in, const uint4 *__restrict__ wq, const fl
 #pragma unroll
             for (int pass = 0; pass < 2; ++pass) {
                 uint4 v = *reinterpret_cast<const uint4 *>(ep + (e_row + 16 * pass) * EP_PITCH + e_chunk * 16);
-                if constexpr (EPM) v = mask8(v, em[b][pass]);
+                if constexpr (EPM) {
+                    if (post_on) v = post_bwd8<T>(v, em[b][pass], a_val[pass], o_off[pass] / 2u + (unsigned)(b * g.J), g.post, dal[pass]);
+                    else v = mask8(v, em[b][pass]);
+                }
                 buf_store16b(rout, o_off[pass], (unsigned)(b * g.J) * 2u, v);
             }
         }
+        if (post_on && g.dalpha) {
+            wave_add_by_key(dal[0], a_key[0], aslab, lane);
+            wave_add_by_key(dal[1], a_key[1], aslab, lane);
+        }
+    }
+    if (post_on && g.dalpha) {                            // one global atomic per slope and workgroup
+        __syncthreads();
+        if (tid < g.post.alpha_len && aslab[tid] != 0.f) atomicAdd(g.dalpha + tid, aslab[tid]);
     }
 }
 
@@ -1016,7 +1038,10 @@ k_hgemm16_point(const T *__restrict__ in, const uint4 *__restrict__ wq, const fl
 // spatial axes.
 inline bool point_geom(const GemmGeom &g, GemmGeom *o)
 {
-    if (g.has_mask || g.post.kind != 0 || (g.Q != 32 && g.Q != 64) || g.J % 64 != 0) return false;
+    if (g.has_mask || (g.Q != 32 && g.Q != 64) || g.J % 64 != 0) return false;
+    if (g.post.kind != 0) {       // only the backward form (derivative in the epilogue, pre-activation in ep_mask)
+        if (!g.ep_mask || g.pre_out || g.post.alpha_len > 256 || (g.taps == 1 && g.post.alpha_sel >= 0)) return false;
+    }
     *o = g;
     if (g.taps == 1) {
         for (int i = 0; i < 3; ++i)

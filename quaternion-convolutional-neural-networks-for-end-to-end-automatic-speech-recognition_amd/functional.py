@@ -589,6 +589,12 @@ class _ConvChainFn(torch.autograd.Function):
             if i > 0 and posts[i - 1] is not None:
                 g, dws[i], dbs[i] = calls[i].bwd_post(acts[i], g, ws[i], ctx.has_bias[i], posts[i - 1], pres[i - 1], das[i - 1])
                 continue
+            if i == 0 and not ctx.needs_input_grad[0]:
+                # the chain's input needs no gradient (a first layer): backward-weight only.  (A relu layer whose dy
+                # arrives masked is masked once more by this call -- idempotent.)
+                dws[0], dbs[0] = calls[0].bwd_weight(acts[0], g, acts[1], ctx.has_bias[0])
+                g = None
+                continue
             flags = 0
             if i > 0 and calls[i - 1].relu:
                 flags |= L.QK_BWD_MASK_DX
