@@ -269,6 +269,17 @@ int qk_conv_relu_pool_fwd(const qk_conv_desc_t *desc, int32_t pool, const void *
 int qk_conv_relu_pool_bwd(const qk_conv_desc_t *desc, int32_t pool, const void *x, const void *dpooled, const void *aux,
                           float *dw, float *dbias, void *stream);
 
+/* The same layer in its PReLU form (the reference's aact == 'prelu'): LINEAR convolution (desc->activation), PReLU with
+ * one slope per row of the conv output (post->alpha_axis 0, alpha_len == in_spatial[0] <= 64: Keras shared_axes=[1,0])
+ * or one slope (alpha_axis -1), then the pooling; post->drop_rate must be 0.  `pre_pooled` (same shape / dtype as
+ * `pooled`) receives the pre-activation of each window's arg-max -- the backward needs it for the derivative and the
+ * slope gradient `dalpha[alpha_len]` (float32, ACCUMULATED into); aux as above (qk_conv_relu_pool_aux_bytes accepts
+ * the LINEAR descriptor as well).  dw / dbias are overwritten. */
+int qk_conv_prelu_pool_fwd(const qk_conv_desc_t *desc, int32_t pool, const qk_postop_t *post, const void *x, const float *w,
+                           const float *bias, void *pooled, void *pre_pooled, void *aux, void *stream);
+int qk_conv_prelu_pool_bwd(const qk_conv_desc_t *desc, int32_t pool, const qk_postop_t *post, const void *x, const void *dpooled,
+                           const void *pre_pooled, const void *aux, float *dw, float *dbias, float *dalpha, void *stream);
+
 /* Tap folding for layers with very few input channels (the first TIMIT layer has cq = 1: K = 4*taps).
  *   xcol[m, a*cq2 + t*cq + c] = x[pos(m, t), a*cq + c]      (0 in the padding and for t*cq + c >= taps*cq)
  * xcol is channels_last (N, *out_spatial, 4*cq2), cq2 a multiple of 8 with cq2 >= taps*cq.  The layer

@@ -228,7 +228,8 @@ struct PoolGeom { int batch, ih, iw, C, wh, ww, oh, ow; };
 int launch_maxpool(int dtype, bool backward, const void *x, const void *dy, void *out, const PoolGeom &g, hipStream_t stream);
 size_t conv1_pool_argbits_bytes(int N, int H, int W, int F);
 int launch_conv1_pool(int dtype, bool backward, const void *x, const float *w, const float *bias, const void *io, void *argbits,
-                      float *dw, float *dbias, int N, int H, int W, int F, int has_bias, hipStream_t stream);
+                      float *dw, float *dbias, int N, int H, int W, int F, int has_bias, hipStream_t stream,
+                      const float *alpha = nullptr, int alpha_len = 0, const void *pre = nullptr, float *dalpha = nullptr);
 int launch_postop(int dtype, bool backward, const void *pre, const void *dy, void *out, float *dalpha, const PostOp &p,
                   long long rows, int channels, int key_div, int key_mod, hipStream_t stream);
 int launch_adam(float *p, float *g, float *m, float *v, size_t n, float lr, float b1,

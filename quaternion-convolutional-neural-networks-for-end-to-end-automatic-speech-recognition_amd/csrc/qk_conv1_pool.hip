@@ -57,6 +57,9 @@ struct C1Geom {
     int n_chunks;              // ceil(W / 224)
     int n_lines;               // N * Ho * n_chunks   (work items)
     int has_bias;
+    // PRELU variants: slopes (one, or one per row f of the conv output: Keras shared_axes=[1,0] on (C, F, T))
+    const float *alpha;
+    int alpha_len;
 };
 
 constexpr int C1_TW = 224;                 // positions per workgroup (7 waves x 32)
@@ -146,10 +149,14 @@ struct C1 {
 };
 
 // ---------------------------------------------------------------------------------------------------------------
-template <typename T, int KH, int KW, int PH>
+// PRELU: the layer is linear + PReLU (interspeech_model.py:97-103 with aact == 'prelu'): the window maximum is taken over
+// prelu(conv + bias) with the slope of each row, and the PRE-activation at the arg-max is written beside the pooled
+// tensor (`pre_out`): the backward needs it for the derivative and the slope gradient (with the Keras initial slope 0
+// it cannot be recovered from the output).
+template <typename T, int KH, int KW, int PH, bool PRELU>
 __global__ void __launch_bounds__(448) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_conv1_pool_fwd(const T *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias, T *__restrict__ out,
-                 uint4 *__restrict__ argbits, const C1Geom g)
+                 T *__restrict__ pre_out, uint4 *__restrict__ argbits, const C1Geom g)
 {
     typedef C1<T, KH, KW, PH> K;
     constexpr int EP_PITCH = 80;
@@ -174,19 +181,30 @@ k_conv1_pool_fwd(const T *__restrict__ x, const float *__restrict__ w, const flo
         const char *lane_base = lds + (wave * 32 + lr) * 8;
         // window maximum and WHICH row tile holds it (first maximum wins, as in TF / torch): 2 bits per element, kept for
         // the backward (argbits: 16 bytes per lane and tile); 3 = nothing flows back (relu: max + bias <= 0)
-        floatx16 pooled[4];
+        floatx16 pooled[4], presel[PRELU ? 4 : 1];
         unsigned argw[4] = {0u, 0u, 0u, 0u};
+        float bia4[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) bia4[b] = g.has_bias ? bias[b * g.F + j0 + lr] : 0.f;
 #pragma unroll
         for (int fi = 0; fi < PH; ++fi) {
             if (PH * ho + fi >= g.H) break;                       // partial last window ('same' pooling: high side only)
             uint4 A[4];
             K::tap_frags(lane_base, toff, fi, A);
+            const float af = PRELU ? g.alpha[g.alpha_len > 1 ? PH * ho + fi : 0] : 0.f;
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
                 const floatx16 acc = K::conv_b(A, B, b);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    if (fi == 0) pooled[b][r] = acc[r];
+                    if constexpr (PRELU) {
+                        const float pre = acc[r] + bia4[b];
+                        const float act = fmaxf(pre, 0.f) + af * fminf(pre, 0.f);
+                        const bool up = fi == 0 || act > pooled[b][r];
+                        pooled[b][r] = up ? act : pooled[b][r];
+                        presel[b][r] = up ? pre : presel[b][r];
+                        if (fi) argw[b] = up ? ((argw[b] & ~(3u << (2 * r))) | ((unsigned)fi << (2 * r))) : argw[b];
+                    } else if (fi == 0) pooled[b][r] = acc[r];
                     else {
                         const bool up = acc[r] > pooled[b][r];
                         pooled[b][r] = up ? acc[r] : pooled[b][r];
@@ -198,47 +216,66 @@ k_conv1_pool_fwd(const T *__restrict__ x, const float *__restrict__ w, const flo
         // relu(max + bias) (== max of relu(conv + bias)), transpose through LDS, 16-byte stores
         char *ep = lds + K::PATCH_BYTES + wave * (32 * EP_PITCH);
         const int e_row = lane >> 2, e_chunk = lane & 3;
-        float bia4[4];
-#pragma unroll
-        for (int b = 0; b < 4; ++b) bia4[b] = g.has_bias ? bias[b * g.F + j0 + lr] : 0.f;
         if (argbits) {
+            if constexpr (!PRELU) {
 #pragma unroll
-            for (int b = 0; b < 4; ++b)
+                for (int b = 0; b < 4; ++b)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) argw[b] |= pooled[b][r] + bia4[b] > 0.f ? 0u : (3u << (2 * r));
+                    for (int r = 0; r < 16; ++r) argw[b] |= pooled[b][r] + bia4[b] > 0.f ? 0u : (3u << (2 * r));
+            }
             argbits[(((long long)blockIdx.y * g.n_lines + item) * 7 + wave) * 64 + lane] = make_uint4(argw[0], argw[1], argw[2], argw[3]);
         }
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
+        for (int which = 0; which < (PRELU ? 2 : 1); ++which) {
+            T *dst_t = which ? pre_out : out;
+            if (which && !pre_out) break;
 #pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                const float v0 = fmaxf(pooled[b][r] + bia4[b], 0.f), v1 = fmaxf(pooled[b][r + 1] + bia4[b], 0.f);
-                const unsigned pk = c1_pack(T(), v0, v1);
-                char *dst = ep + mfma32_row(r, lane) * EP_PITCH + lr * 2;
-                *reinterpret_cast<unsigned short *>(dst) = (unsigned short)pk;
-                *reinterpret_cast<unsigned short *>(dst + EP_PITCH) = (unsigned short)(pk >> 16);
-            }
+            for (int b = 0; b < 4; ++b) {
 #pragma unroll
-            for (int pass = 0; pass < 2; ++pass) {
-                const int row = e_row + 16 * pass;
-                const uint4 v = *reinterpret_cast<const uint4 *>(ep + row * EP_PITCH + e_chunk * 16);
-                const int t = tw + row;
-                if (t < g.W)
-                    *reinterpret_cast<uint4 *>(out + (((long long)n * g.Ho + ho) * g.W + t) * (4 * g.F) + b * g.F + j0 + e_chunk * 8) = v;
+                for (int r = 0; r < 16; r += 2) {
+                    float v0, v1;
+                    if constexpr (PRELU) {
+                        v0 = which ? presel[b][r] : pooled[b][r];
+                        v1 = which ? presel[b][r + 1] : pooled[b][r + 1];
+                    } else {
+                        v0 = fmaxf(pooled[b][r] + bia4[b], 0.f);
+                        v1 = fmaxf(pooled[b][r + 1] + bia4[b], 0.f);
+                    }
+                    const unsigned pk = c1_pack(T(), v0, v1);
+                    char *dst = ep + mfma32_row(r, lane) * EP_PITCH + lr * 2;
+                    *reinterpret_cast<unsigned short *>(dst) = (unsigned short)pk;
+                    *reinterpret_cast<unsigned short *>(dst + EP_PITCH) = (unsigned short)(pk >> 16);
+                }
+#pragma unroll
+                for (int pass = 0; pass < 2; ++pass) {
+                    const int row = e_row + 16 * pass;
+                    const uint4 v = *reinterpret_cast<const uint4 *>(ep + row * EP_PITCH + e_chunk * 16);
+                    const int t = tw + row;
+                    if (t < g.W)
+                        *reinterpret_cast<uint4 *>(dst_t + (((long long)n * g.Ho + ho) * g.W + t) * (4 * g.F) + b * g.F + j0 + e_chunk * 8) = v;
+                }
             }
         }
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-template <typename T, int KH, int KW, int PH>
+// PRELU: dy of the arg-max row = dpool * prelu'(pre) with that row's slope; d alpha[row] += dpool * min(pre, 0).  Both are
+// applied while the pooled gradient is STAGED (the thread that moves a 16-byte unit holds dpool and the pre-activation
+// `pre_sel` of the same 8 elements; which row won comes from the wave's arg-max words, parked in LDS first), so the MFMA
+// part of the loop is the relu variant's, unchanged.
+template <typename T, int KH, int KW, int PH, bool PRELU>
 __global__ void __launch_bounds__(448) __attribute__((amdgpu_waves_per_eu(2, 2)))
-k_conv1_pool_bwd(const T *__restrict__ x, const T *__restrict__ dout, const uint4 *__restrict__ argbits,
-                 float *__restrict__ dw, float *__restrict__ dbias, const C1Geom g)
+k_conv1_pool_bwd(const T *__restrict__ x, const T *__restrict__ dout, const T *__restrict__ pre_sel, const uint4 *__restrict__ argbits,
+                 float *__restrict__ dw, float *__restrict__ dbias, float *__restrict__ dalpha, const C1Geom g)
 {
     typedef C1<T, KH, KW, PH> K;
     constexpr int DP_PITCH = 4 * 32 * 2 + 16;                     // one dpool row of this column tile: 4 components x 32 filters (+ pad)
-    __shared__ __attribute__((aligned(16))) char lds[K::PATCH_BYTES + 7 * 32 * DP_PITCH];
+    constexpr int DP_BYTES = 7 * 32 * DP_PITCH;
+    constexpr int AW_BYTES = PRELU ? 7 * 64 * 16 : 0;             // the waves' arg-max words
+    __shared__ __attribute__((aligned(16))) char lds[K::PATCH_BYTES + DP_BYTES + AW_BYTES + (PRELU ? 256 : 0)];
+    float *dal_s = reinterpret_cast<float *>(lds + K::PATCH_BYTES + DP_BYTES + AW_BYTES);     // PRELU: 64 slope-gradient sums
+    if (PRELU && threadIdx.x < 64) dal_s[threadIdx.x] = 0.f;       // (the loop's first barrier orders it)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 31, lh = lane >> 5;
     const int j0 = blockIdx.y * 32;
@@ -266,6 +303,15 @@ k_conv1_pool_bwd(const T *__restrict__ x, const T *__restrict__ dout, const uint
         // this wave's dpool tile: 32 positions x (4 x 32) channels, rows past W are zero
         char *dp = lds + K::PATCH_BYTES + wave * (32 * DP_PITCH);
         const int tw = t0 + wave * 32;
+        uint4 aw = make_uint4(~0u, ~0u, ~0u, ~0u);                // 3 everywhere: nothing flows
+        if (tw < g.W) aw = argbits[(((long long)blockIdx.y * g.n_lines + item) * 7 + wave) * 64 + lane];
+        float a3[3] = {0.f, 0.f, 0.f}, dal3[3] = {0.f, 0.f, 0.f};
+        if constexpr (PRELU) {
+            // (a wave's own LDS accesses execute in order: the reads below see these writes without a barrier)
+            *reinterpret_cast<uint4 *>(lds + K::PATCH_BYTES + DP_BYTES + (wave * 64 + lane) * 16) = aw;
+#pragma unroll
+            for (int fi = 0; fi < 3; ++fi) a3[fi] = g.alpha[g.alpha_len > 1 ? min(PH * ho + fi, g.alpha_len - 1) : 0];
+        }
 #pragma unroll 2
         for (int u0 = lane; u0 < 32 * 16; u0 += 64) {              // 16-byte units: row u / 16, (component, 8 filters) u % 16
             int u = u0;
@@ -273,12 +319,46 @@ k_conv1_pool_bwd(const T *__restrict__ x, const T *__restrict__ dout, const uint
                                                                    //  of the persistent loop as eight 64-bit values -- they spilled)
             const int row = u >> 4, q = u & 15, b = q >> 2, sub = (q & 3) * 8;
             uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (tw + row < g.W)
-                v = *reinterpret_cast<const uint4 *>(dout + (((long long)n * g.Ho + ho) * g.W + tw + row) * (4 * g.F) + b * g.F + j0 + sub);
+            if (tw + row < g.W) {
+                const long long o = (((long long)n * g.Ho + ho) * g.W + tw + row) * (4 * g.F) + b * g.F + j0 + sub;
+                v = *reinterpret_cast<const uint4 *>(dout + o);
+                if constexpr (PRELU) {
+                    const uint4 pv = *reinterpret_cast<const uint4 *>(pre_sel + o);
+                    // element (row, filter sub + e) sits in lane (sub + e) + 32 lh', register r' of the accumulator layout
+                    const int r2 = 2 * ((row & 3) + 4 * (row >> 3));
+                    const char *awb = lds + K::PATCH_BYTES + DP_BYTES + (wave * 64 + 32 * ((row >> 2) & 1) + sub) * 16 + b * 4;
+                    unsigned dv[4] = {v.x, v.y, v.z, v.w}, pw[4] = {pv.x, pv.y, pv.z, pv.w};
+#pragma unroll
+                    for (int e = 0; e < 8; e += 2) {
+                        float gq[2];
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const unsigned arg = (*reinterpret_cast<const unsigned *>(awb + (e + h) * 16) >> r2) & 3u;
+                            const unsigned short db_ = (unsigned short)(dv[e >> 1] >> (16 * h)), pb_ = (unsigned short)(pw[e >> 1] >> (16 * h));
+                            const float d = to_f32(__builtin_bit_cast(T, db_)), pr = to_f32(__builtin_bit_cast(T, pb_));
+                            const float al = arg == 0 ? a3[0] : arg == 1 ? a3[1] : a3[2];
+                            const float hneg = d * fminf(pr, 0.f);
+                            dal3[0] += arg == 0 ? hneg : 0.f; dal3[1] += arg == 1 ? hneg : 0.f; dal3[2] += arg == 2 ? hneg : 0.f;
+                            gq[h] = d * (pr > 0.f ? 1.f : (pr < 0.f ? al : 0.f));
+                        }
+                        dv[e >> 1] = c1_pack(T(), gq[0], gq[1]);
+                    }
+                    v = make_uint4(dv[0], dv[1], dv[2], dv[3]);
+                }
+            }
             *reinterpret_cast<uint4 *>(dp + row * DP_PITCH + (b * 32 + sub) * 2) = v;
         }
-        uint4 aw = make_uint4(~0u, ~0u, ~0u, ~0u);                // 3 everywhere: nothing flows
-        if (tw < g.W) aw = argbits[(((long long)blockIdx.y * g.n_lines + item) * 7 + wave) * 64 + lane];
+        if constexpr (PRELU) {
+            if (dalpha) {                                          // wave sums -> one LDS atomic per (wave, window row)
+#pragma unroll
+                for (int fi = 0; fi < 3; ++fi) {
+                    float t = dal3[fi];
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+                    if (lane == 0 && PH * ho + fi < g.H) atomicAdd(dal_s + (g.alpha_len > 1 ? PH * ho + fi : 0), t);
+                }
+            }
+        }
         const unsigned argw[4] = {aw.x, aw.y, aw.z, aw.w};
         __syncthreads();
         const int n_fi = tw < g.W ? min(PH, g.H - PH * ho) : 0;
@@ -328,6 +408,12 @@ k_conv1_pool_bwd(const T *__restrict__ x, const T *__restrict__ dout, const uint
             }
         }
     }
+    if constexpr (PRELU) {
+        if (dalpha) {
+            __syncthreads();
+            if (tid < g.alpha_len && tid < 64 && dal_s[tid] != 0.f) atomicAdd(dalpha + tid, dal_s[tid]);
+        }
+    }
     // ---- flush: every wave parks its gradients in its own LDS slab (taps = accumulator rows 0 .. 15 = registers 0 .. 7,
     // columns = filters), the workgroup sums the seven slabs and issues one atomic per element
     __syncthreads();
@@ -357,19 +443,20 @@ k_conv1_pool_bwd(const T *__restrict__ x, const T *__restrict__ dout, const uint
     }
 }
 
-template <typename T>
-int run_conv1_pool(bool backward, const void *x, const float *w, const float *bias, const void *io, void *argbits, float *dw,
-                   float *dbias, const C1Geom &g, hipStream_t stream)
+template <typename T, bool PRELU>
+int run_conv1_pool(bool backward, const void *x, const float *w, const float *bias, const void *io, const void *pre, void *argbits, float *dw,
+                   float *dbias, float *dalpha, const C1Geom &g, hipStream_t stream)
 {
     if (!backward) {
         dim3 grid((unsigned)g.n_lines, (unsigned)(g.F / 32), 1);
-        hipLaunchKernelGGL((k_conv1_pool_fwd<T, 3, 5, 3>), grid, dim3(448), 0, stream, (const T *)x, w, bias, (T *)const_cast<void *>(io),
-                           (uint4 *)argbits, g);
+        hipLaunchKernelGGL((k_conv1_pool_fwd<T, 3, 5, 3, PRELU>), grid, dim3(448), 0, stream, (const T *)x, w, bias, (T *)const_cast<void *>(io),
+                           (T *)const_cast<void *>(pre), (uint4 *)argbits, g);
     } else {
-        int blocks = 2 * device_cu_count();                        // 70 KB of LDS: two workgroups per CU
+        int blocks = 2 * device_cu_count();                        // 70 - 78 KB of LDS: two workgroups per CU
         if (blocks > g.n_lines) blocks = g.n_lines;
         dim3 grid((unsigned)blocks, (unsigned)(g.F / 32), 1);
-        hipLaunchKernelGGL((k_conv1_pool_bwd<T, 3, 5, 3>), grid, dim3(448), 0, stream, (const T *)x, (const T *)io, (const uint4 *)argbits, dw, dbias, g);
+        hipLaunchKernelGGL((k_conv1_pool_bwd<T, 3, 5, 3, PRELU>), grid, dim3(448), 0, stream, (const T *)x, (const T *)io, (const T *)pre,
+                           (const uint4 *)argbits, dw, dbias, dalpha, g);
     }
     return hipGetLastError() == hipSuccess ? 0 : QK_ERR_LAUNCH;
 }
@@ -378,6 +465,8 @@ int run_conv1_pool(bool backward, const void *x, const float *w, const float *bi
 
 // conv (3,5) 'same' on one quaternion channel + relu + max-pool (3,1) 'same' over H.  `argbits`: the arg-max side tensor
 // (conv1_pool_argbits_bytes), written by the forward (may be NULL there: inference), read by the backward.
+// alpha != NULL: the PReLU form (linear conv, slopes `alpha`, pre-activation of the arg-max in `pre`, slope gradient
+// accumulated into `dalpha`).
 size_t conv1_pool_argbits_bytes(int N, int H, int W, int F)
 {
     const long long lines = (long long)N * ((H + 2) / 3) * ((W + C1_TW - 1) / C1_TW);
@@ -385,15 +474,22 @@ size_t conv1_pool_argbits_bytes(int N, int H, int W, int F)
 }
 
 int launch_conv1_pool(int dtype, bool backward, const void *x, const float *w, const float *bias, const void *io, void *argbits,
-                      float *dw, float *dbias, int N, int H, int W, int F, int has_bias, hipStream_t stream)
+                      float *dw, float *dbias, int N, int H, int W, int F, int has_bias, hipStream_t stream,
+                      const float *alpha, int alpha_len, const void *pre, float *dalpha)
 {
     C1Geom g;
     g.N = N; g.H = H; g.W = W; g.F = F; g.has_bias = has_bias;
     g.Ho = (H + 2) / 3;
     g.n_chunks = (W + C1_TW - 1) / C1_TW;
     g.n_lines = N * g.Ho * g.n_chunks;
-    if (dtype == QK_BF16) return run_conv1_pool<bf16>(backward, x, w, bias, io, argbits, dw, dbias, g, stream);
-    if (dtype == QK_F16) return run_conv1_pool<f16>(backward, x, w, bias, io, argbits, dw, dbias, g, stream);
+    g.alpha = alpha; g.alpha_len = alpha_len;
+    if (alpha) {
+        if (dtype == QK_BF16) return run_conv1_pool<bf16, true>(backward, x, w, bias, io, pre, argbits, dw, dbias, dalpha, g, stream);
+        if (dtype == QK_F16) return run_conv1_pool<f16, true>(backward, x, w, bias, io, pre, argbits, dw, dbias, dalpha, g, stream);
+        return QK_ERR_UNSUPPORTED;
+    }
+    if (dtype == QK_BF16) return run_conv1_pool<bf16, false>(backward, x, w, bias, io, nullptr, argbits, dw, dbias, nullptr, g, stream);
+    if (dtype == QK_F16) return run_conv1_pool<f16, false>(backward, x, w, bias, io, nullptr, argbits, dw, dbias, nullptr, g, stream);
     return QK_ERR_UNSUPPORTED;
 }
 

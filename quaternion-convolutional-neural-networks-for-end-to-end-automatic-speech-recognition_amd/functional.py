@@ -539,6 +539,61 @@ def conv_relu_pool(x, kernel, bias=None, pool=3):
     return _ConvReluPoolFn.apply(xc, kernel.contiguous(), bias, call, pool)
 
 
+class _ConvPreluPoolFn(torch.autograd.Function):
+    """qk_conv_prelu_pool_fwd / _bwd: linear conv (3,5) 'same' + PReLU (slope per row, or one) + max-pool over the first
+    spatial axis as one launch per direction; the input gets no gradient."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, alpha, call, pool, post):
+        n, h, wd, _ = x.shape
+        out = torch.empty((n, -(-h // pool), wd, w.shape[-1]), dtype=x.dtype, device=x.device)
+        nb = int(L.lib().qk_conv_relu_pool_aux_bytes(ctypes.byref(call.desc), pool))
+        keep = any(ctx.needs_input_grad[1:4])
+        aux = torch.empty(nb, dtype=torch.uint8, device=x.device) if keep else None
+        pre = torch.empty_like(out) if keep else None
+        with _on_device(x.device):
+            rc = L.lib().qk_conv_prelu_pool_fwd(ctypes.byref(call.desc), pool, ctypes.byref(post.struct), _ptr(x), _ptr(w), _ptr(bias),
+                                                _ptr(out), _ptr(pre), _ptr(aux), _stream(x))
+        L.check(rc, 'qk_conv_prelu_pool_fwd')
+        ctx.call, ctx.pool, ctx.post, ctx.has_bias = call, pool, post, bias is not None
+        ctx.w_shape = tuple(w.shape)
+        ctx.save_for_backward(x, aux, pre)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, aux, pre = ctx.saved_tensors
+        dout = dout.contiguous()
+        post = ctx.post
+        dw = torch.empty(ctx.w_shape, dtype=torch.float32, device=x.device)
+        db = torch.empty((ctx.w_shape[-1],), dtype=torch.float32, device=x.device) if ctx.has_bias else None
+        da = torch.zeros(post.flat.numel(), dtype=torch.float32, device=x.device)
+        with _on_device(x.device):
+            rc = L.lib().qk_conv_prelu_pool_bwd(ctypes.byref(ctx.call.desc), ctx.pool, ctypes.byref(post.struct), _ptr(x), _ptr(dout),
+                                                _ptr(pre), _ptr(aux), _ptr(dw), _ptr(db), _ptr(da), _stream(x))
+        L.check(rc, 'qk_conv_prelu_pool_bwd')
+        return None, dw, db, da.reshape(post.alpha.shape), None, None, None
+
+
+def conv_prelu_pool_supported(x, kernel, alpha, alpha_axis, pool):
+    """conv_relu_pool_supported for the PReLU form: float32 device slopes, one (alpha_axis -1) or one per position of
+    the first spatial axis (alpha_axis 0, at most 64)."""
+    n = alpha.numel()
+    return (conv_relu_pool_supported(x, kernel, pool) and alpha.is_cuda and alpha.dtype == torch.float32 and
+            ((alpha_axis == -1 and n == 1) or (alpha_axis == 0 and n == x.shape[1] and n <= 64)))
+
+
+def conv_prelu_pool(x, kernel, bias, alpha, alpha_axis=0, pool=3):
+    """(N, H, W, 4) -> (N, ceil(H / pool), W, 4F): linear first layer + PReLU + frequency pooling in one kernel
+    (include/qk.h: qk_conv_prelu_pool_*).  Check conv_prelu_pool_supported first."""
+    _require_device(x, 'conv_prelu_pool')
+    _check_weights(kernel, bias, kernel.shape[-1])
+    xc = x.contiguous()
+    call = conv_call(tuple(xc.shape), tuple(kernel.shape), xc.dtype, 2, 1, 'same', 'channels_last', 1, None, bias is not None, False)
+    post = PostOp(alpha, alpha_axis, 0.0, 0)
+    return _ConvPreluPoolFn.apply(xc, kernel.contiguous(), bias, alpha, call, pool, post)
+
+
 class _ConvChainFn(torch.autograd.Function):
     """A run of quaternion convolutions applied back to back as ONE autograd node, so that the backward knows the
     structure.  Each layer ends in a fused relu (y_i = relu(W_i (x) y_{i-1} + b_i)), is linear, or carries a POST-OP

@@ -133,9 +133,19 @@ class TimitQCNN(torch.nn.Module):
             c._build_device = x.device
             c.build(tuple(x.shape))
         shape = c.compute_output_shape(tuple(x.shape))
-        o = Fq.quaternion_conv(x, c.kernel, c.bias, strides=c.strides, padding=c.padding, data_format='channels_first',
-                               dilation_rate=c.dilation_rate, activation=None, post=self._post(0, shape, dropout=False))
-        o = self.pool(o)
+        post0 = self._post(0, shape, dropout=False)
+        pl = self.pool
+        xl = x.movedim(1, -1)                                        # (B, F, T, 4): the channels-last buffer
+        fused_first = (not os.environ.get('QK_NO_FUSED_FIRST') and x.dim() == 4 and c.padding == 'same' and c.strides == (1, 1) and
+                       c.dilation_rate == (1, 1) and c.internal_layout == 'channels_last' and pl.pool_size == (1, 3) and
+                       pl.strides == (1, 3) and pl.padding == 'same' and pl.data_format == 'channels_last' and
+                       Fq.conv_prelu_pool_supported(xl, c.kernel, post0['alpha'], post0['alpha_axis'], 3))
+        if fused_first:      # linear conv + PReLU + frequency pooling as ONE kernel per direction (qk_conv_prelu_pool_*)
+            o = Fq.conv_prelu_pool(xl, c.kernel, c.bias, post0['alpha'], post0['alpha_axis'], 3).movedim(-1, 1)
+        else:
+            o = Fq.quaternion_conv(x, c.kernel, c.bias, strides=c.strides, padding=c.padding, data_format='channels_first',
+                                   dilation_rate=c.dilation_rate, activation=None, post=post0)
+            o = self.pool(o)
         shape = tuple(o.shape)
         layers = []
         for i, cv in enumerate(self.convs):

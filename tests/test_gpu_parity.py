@@ -1006,6 +1006,56 @@ def test_fused_first_layer_conv_relu_pool_matches_oracle(shape, F, dtype):
     assert _rel_err(bt.grad.cpu().numpy(), db) <= tol32
 
 
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16], ids=['bf16', 'fp16'])
+@pytest.mark.parametrize('shape,F,per_row', [((3, 41, 50, 4), 32, True), ((2, 7, 230, 4), 64, True), ((2, 10, 33, 4), 32, False)],
+                         ids=['41x50_f32', '7x230_f64', '10x33_scalar'])
+def test_fused_first_layer_conv_prelu_pool_matches_oracle(shape, F, per_row, dtype):
+    """qk_conv_prelu_pool_fwd / _bwd (linear conv (3,5) 'same' + PReLU with one slope per frequency row, or one slope +
+    max-pool (3,1) 'same' over H, one kernel per direction) against oracle conv + numpy PReLU / pooling: pooled values,
+    d kernel, d bias, d alpha.  Slopes of both signs (a negative slope makes PReLU non-monotonic: the maximum must be
+    taken AFTER the activation)."""
+    import qcnn_amd
+    from oracle import oracle
+    Fq = qcnn_amd.functional
+    dev = _dev()
+    rng = np.random.RandomState(61)
+    rnd = lambda a: torch.tensor(a).to(dtype).double().numpy()
+    x = rnd(rng.randn(*shape))
+    w = rnd(rng.randn(3, 5, 1, 4 * F) / np.sqrt(60.0))
+    b = (0.1 * rng.randn(4 * F)).astype(np.float32).astype(np.float64)
+    H = shape[1]
+    alpha = (0.5 * rng.randn(H if per_row else 1)).astype(np.float32).astype(np.float64)
+    pre = oracle.forward(x, w, b, 2, padding='same', activation=None)
+    a_b = alpha.reshape(1, -1, 1, 1) if per_row else alpha.reshape(1, 1, 1, 1)
+    act = np.maximum(pre, 0) + a_b * np.minimum(pre, 0)
+    pooled, arg = _np_pool_h_same(act)
+    dp = rnd(rng.randn(*pooled.shape))
+    dact = np.zeros_like(act)
+    n, ho, wd, c = pooled.shape
+    ii = np.meshgrid(np.arange(n), np.arange(ho), np.arange(wd), np.arange(c), indexing='ij')
+    np.add.at(dact, (ii[0], arg, ii[2], ii[3]), dp)
+    dpre = dact * np.where(pre > 0, 1.0, np.where(pre < 0, a_b, 0.0))
+    dalpha = (dact * np.minimum(pre, 0)).sum(axis=(0, 2, 3)) if per_row else (dact * np.minimum(pre, 0)).sum().reshape(1)
+    _, dw, db = oracle.backward(x, w, b, dpre, 2, padding='same', activation=None)
+    xt = torch.tensor(x, device=dev).to(dtype)
+    wt = torch.tensor(w, device=dev, dtype=torch.float32, requires_grad=True)
+    bt = torch.tensor(b, device=dev, dtype=torch.float32, requires_grad=True)
+    at = torch.tensor(alpha.reshape((1, H, 1) if per_row else (1, 1, 1)), device=dev, dtype=torch.float32, requires_grad=True)
+    axis = 0 if per_row else -1
+    assert Fq.conv_prelu_pool_supported(xt, wt, at, axis, 3)
+    out = Fq.conv_prelu_pool(xt, wt, bt, at, axis, 3)
+    out.backward(torch.tensor(dp, device=dev).to(dtype))
+    tol16, tol32 = (1e-2, 5e-3) if dtype == torch.bfloat16 else (2e-3, 2e-3)
+    assert tuple(out.shape) == pooled.shape
+    assert _rel_err(out.detach().float().cpu().numpy(), pooled) <= tol16
+    assert _rel_err(wt.grad.cpu().numpy(), dw) <= tol32
+    assert _rel_err(bt.grad.cpu().numpy(), db) <= tol32
+    # slope gradients are sums of terms of both signs: the error is measured against the sum of their magnitudes
+    mag = np.abs(dact * np.minimum(pre, 0))
+    scale = float(mag.sum(axis=(0, 2, 3)).max() if per_row else mag.sum())
+    assert float(np.abs(at.grad.reshape(-1).cpu().numpy() - dalpha).max()) <= tol32 * scale
+
+
 def test_library_profiler_times_every_call_of_a_backward():
     """qk_prof_* (include/qk.h): with the recorder on, a layer's forward and its fused backward (backward-weight +
     backward-data inside ONE C call, on autograd's thread) leave three records carrying the layer's GEMM view, the
