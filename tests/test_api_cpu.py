@@ -290,3 +290,21 @@ def test_debug_flags_are_a_process_wide_mask_set_through_the_c_abi():
     finally:
         lib.qk_set_debug_flags(prev)
     assert _lib.last_path() in _lib.QK_PATH_NAMES.values()
+
+
+def test_profiler_entry_points_without_a_gpu():
+    """qk_prof_* (include/qk.h): enabling clears the record list and returns the previous state; reading a record that
+    does not exist is an argument error, not a fault."""
+    lib = _lib.lib()
+    was = lib.qk_prof_enable(1)
+    try:
+        assert lib.qk_prof_enable(1) == 1 and lib.qk_prof_count() == 0
+        rec = _lib.ProfRec()
+        assert lib.qk_prof_get(0, ctypes.byref(rec)) != 0
+        assert b'record' in lib.qk_last_error()
+        assert lib.qk_prof_get(0, None) != 0
+    finally:
+        lib.qk_prof_enable(was)
+    with _lib.profile() as p:
+        assert p.records() == []
+    assert lib.qk_prof_enable(0) == 0
