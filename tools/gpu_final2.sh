@@ -10,8 +10,8 @@ python tools/trace_step.py gpurun_out/final2/ks_qcnn_kernel_trace.csv --all > gp
 rm -rf gpurun_out/traffic
 ./tools/gpu_traffic.sh cfg2_qconv1d_timit_b64_fp32 cfg3_body_qconv2d_b256_bf16 cfg3_stage1_qconv2d_b256_bf16 cfg3_32to64_qconv2d_b256_bf16 > gpurun_out/final2/traffic_stdout.txt 2>&1
 cp gpurun_out/traffic/pmc_traffic.json gpurun_out/final2/
-rm -rf gpurun_out/pmc
 for K in fwd bwd_weight_chain bwd_data_chain; do
+rm -rf gpurun_out/pmc
 ./tools/gpu_pmc.sh cfg3_body_qconv2d_b256_bf16 $K "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY" "GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_ANY SQ_WAVES SQ_INSTS_SALU" > gpurun_out/final2/pmc_cfg3body_$K.txt 2>&1
 done
 rm -f gpurun_out/final2/*agent_info.csv gpurun_out/final2/*domain_stats.csv
