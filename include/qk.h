@@ -210,6 +210,7 @@ int qk_conv_bwd(const qk_conv_desc_t *desc, const void *x, const void *dy, const
  * omitting QK_BWD_DY_PREMASKED is therefore always safe, setting it on an unmasked dy is not. */
 #define QK_BWD_MASK_DX 1
 #define QK_BWD_DY_PREMASKED 2
+#define QK_BWD_ACCUMULATE 4   /* dw / dbias are ADDED to (as qk_*_bwd_weight_acc): gradients land in a caller-zeroed buffer */
 int qk_conv_bwd_chain(const qk_conv_desc_t *desc, const void *x, const void *dy, const void *y, const float *w,
                       void *dx, float *dw, float *dbias, int32_t flags, void *workspace, size_t workspace_bytes,
                       void *stream);

@@ -14,7 +14,7 @@ QK_F32, QK_BF16, QK_F16 = 0, 1, 2
 QK_CH_LAST, QK_CH_FIRST = 0, 1
 QK_ACT_LINEAR, QK_ACT_RELU = 0, 1
 QK_OP_FWD, QK_OP_BWD_DATA, QK_OP_BWD_WEIGHT, QK_OP_BWD = 0, 1, 2, 3
-QK_BWD_MASK_DX, QK_BWD_DY_PREMASKED = 1, 2      # flags of qk_*_bwd_chain
+QK_BWD_MASK_DX, QK_BWD_DY_PREMASKED, QK_BWD_ACCUMULATE = 1, 2, 4      # flags of qk_*_bwd_chain
 QK_DBG_NO_MFMA16, QK_DBG_NO_BAND16, QK_DBG_NO_BAND32, QK_DBG_WGRAD16_ONE_TAP, QK_DBG_BAND16_8WAVES = 1, 2, 4, 8, 16   # qk_set_debug_flags
 QK_DBG_NO_WGRAD_BAND = 32
 QK_DBG_NO_POINT16 = 64

@@ -431,7 +431,8 @@ int conv_bwd_impl(const qk_conv_desc_t *d, const void *x, const void *dy, const 
                   void *dx, float *dw, float *dbias, void *ws, size_t wsb, hipStream_t stream, int flags = 0)
 {
     if (!dx) { set_error("dx must not be NULL (use qk_*_bwd_weight when d(input) is not needed)"); return QK_ERR_INVALID_ARG; }
-    if (flags & ~(QK_BWD_MASK_DX | QK_BWD_DY_PREMASKED)) { set_error("unknown backward flags 0x%x", flags); return QK_ERR_INVALID_ARG; }
+    if (flags & ~(QK_BWD_MASK_DX | QK_BWD_DY_PREMASKED | QK_BWD_ACCUMULATE)) { set_error("unknown backward flags 0x%x", flags); return QK_ERR_INVALID_ARG; }
+    const bool acc = (flags & QK_BWD_ACCUMULATE) != 0;
     const void *dx_mask = (flags & QK_BWD_MASK_DX) ? x : nullptr;
     const bool relu = d->activation == QK_ACT_RELU && !(flags & QK_BWD_DY_PREMASKED);
     const size_t bd = ws_bytes_impl(d, QK_OP_BWD_DATA);
@@ -440,14 +441,14 @@ int conv_bwd_impl(const qk_conv_desc_t *d, const void *x, const void *dy, const 
         if (bd && (!ws || wsb < bd)) { set_error("bwd needs %zu workspace bytes, got %zu", bd, wsb); return QK_ERR_WORKSPACE; }
         qk_conv_desc_t lin = *d;
         lin.activation = QK_ACT_LINEAR;
-        if (int rc = conv_bwd_weight_impl(&lin, x, dy, nullptr, dw, dbias, nullptr, stream)) return rc;
+        if (int rc = conv_bwd_weight_impl(&lin, x, dy, nullptr, dw, dbias, nullptr, stream, acc)) return rc;
         return conv_bwd_data_impl(&lin, dy, nullptr, w, dx, ws, bd, stream, dx_mask);
     }
     const size_t need = ws_bytes_impl(d, QK_OP_BWD);
     if (need && (!ws || wsb < need)) { set_error("bwd needs %zu workspace bytes, got %zu", need, wsb); return QK_ERR_WORKSPACE; }
     void *dym = static_cast<char *>(ws) + (bd + 255) / 256 * 256;
     if ((bd + 255) / 256 * 256 + dy_bytes(d) > wsb + 255) { set_error("workspace too small for the masked dy"); return QK_ERR_WORKSPACE; }
-    if (int rc = conv_bwd_weight_impl(d, x, dy, y, dw, dbias, dym, stream)) return rc;
+    if (int rc = conv_bwd_weight_impl(d, x, dy, y, dw, dbias, dym, stream, acc)) return rc;
     qk_conv_desc_t lin = *d;
     lin.activation = QK_ACT_LINEAR;
     return conv_bwd_data_impl(&lin, dym, nullptr, w, dx, ws, bd, stream, dx_mask);

@@ -72,6 +72,9 @@ class FlatParams(object):
                 self.param[o:o + n].copy_(p.detach().reshape(-1).float())
                 p.data = self.param[o:o + n].view(p.shape)
                 p.grad = self.grad[o:o + n].view(p.shape)
+                # the engine's backward nodes add their kernel / bias gradients straight into these views (no
+                # temporary, no memset, no AccumulateGrad add): functional._direct_grad
+                p._qk_direct_grad = True
 
     def grad_view(self, i):
         p, o = self.params[i], self.offsets[i]
@@ -131,6 +134,7 @@ class BucketedAllReduce(object):
             for p in flat.params:
                 if p.requires_grad:
                     self.handles.append(p.register_post_accumulate_grad_hook(self._hook))
+                    p._qk_grad_ready = self._hook       # called by the engine when it wrote the gradient itself
 
     def _close(self, lo, hi, params):
         b = len(self.buckets)
@@ -168,6 +172,9 @@ class BucketedAllReduce(object):
         for h in self.handles:
             h.remove()
         self.handles = []
+        for p in self.flat.params:
+            if getattr(p, '_qk_grad_ready', None) == self._hook:
+                del p._qk_grad_ready
 
 
 def world_size(group=None):

@@ -237,12 +237,36 @@ def prelu_dropout(x, alpha, alpha_axis=-1, rate=0.0, seed=0):
     return _PostOpFn.apply(xc, alpha, PostOp(alpha, alpha_axis, rate, seed))
 
 
+def _direct_grad(w, b, want_w, want_b):
+    """(dw, db) buffers to ACCUMULATE into, or None.  Parameters re-homed by dp.FlatParams carry `.grad` views of one
+    flat, zeroed-after-the-step gradient buffer: the backward kernels add into them directly (qk_*_bwd_weight_acc /
+    QK_BWD_ACCUMULATE) instead of filling a temporary that autograd then adds -- one memset and one elementwise pass
+    less per parameter and step.  The caller returns None as these parameters' gradients and calls _grad_ready."""
+    if not (want_w and getattr(w, '_qk_direct_grad', False) and w.grad is not None and w.grad.is_contiguous()
+            and w.grad.dtype == torch.float32):
+        return None
+    if b is None:
+        return w.grad, None
+    if not (want_b and getattr(b, '_qk_direct_grad', False) and b.grad is not None and b.grad.is_contiguous()
+            and b.grad.dtype == torch.float32):
+        return None
+    return w.grad, b.grad
+
+
+def _grad_ready(*params):
+    for p in params:
+        cb = getattr(p, '_qk_grad_ready', None) if p is not None else None
+        if cb is not None:
+            cb(p)                         # dp.BucketedAllReduce counts its bucket down (autograd's hook will not fire)
+
+
 class _HamiltonFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, bias, call):
         y = call.fwd(x, w, bias)
         ctx.call = call
         ctx.has_bias = bias is not None
+        ctx.params = (w, bias)
         ctx.save_for_backward(x, w, y if call.relu else None)
         return y
 
@@ -253,12 +277,22 @@ class _HamiltonFn(torch.autograd.Function):
         dy = dy.contiguous()
         dx = dw = db = None
         want_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
+        direct = _direct_grad(ctx.params[0], ctx.params[1], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2])
         if ctx.needs_input_grad[0] and want_w:
-            dx, dw, db = call.bwd(x, dy, y, w, ctx.has_bias)        # fused: one pass over (dy, y)
+            if direct is not None:
+                dx = torch.empty(call.x_shape, dtype=dy.dtype, device=dy.device)
+                call.bwd(x, dy, y, w, ctx.has_bias, out=(dx,) + direct, flags=L.QK_BWD_ACCUMULATE)
+            else:
+                dx, dw, db = call.bwd(x, dy, y, w, ctx.has_bias)        # fused: one pass over (dy, y)
         elif ctx.needs_input_grad[0]:
             dx = call.bwd_data(dy, y, w)
         elif want_w:
-            dw, db = call.bwd_weight(x, dy, y, ctx.has_bias)
+            if direct is not None:
+                call.bwd_weight(x, dy, y, ctx.has_bias, out=direct, accumulate=True)
+            else:
+                dw, db = call.bwd_weight(x, dy, y, ctx.has_bias)
+        if direct is not None and want_w:
+            _grad_ready(*ctx.params)
         return dx, dw, db, None
 
 
@@ -620,6 +654,7 @@ class _ConvChainFn(torch.autograd.Function):
                 acts.append(y)
                 pres.append(pre)
         ctx.calls, ctx.posts = calls, posts
+        ctx.param_refs = (ws, bs)
         ctx.has_bias = [b is not None for b in bs]
         ctx.n_pre = [p is not None for p in pres]
         ctx.save_for_backward(*acts, *ws, *[p for p in pres if p is not None])
@@ -644,10 +679,16 @@ class _ConvChainFn(torch.autograd.Function):
             if i > 0 and posts[i - 1] is not None:
                 g, dws[i], dbs[i] = calls[i].bwd_post(acts[i], g, ws[i], ctx.has_bias[i], posts[i - 1], pres[i - 1], das[i - 1])
                 continue
+            pw, pb = ctx.param_refs[0][i], ctx.param_refs[1][i]
+            direct = _direct_grad(pw, pb, ctx.needs_input_grad[3 + i], ctx.has_bias[i] and ctx.needs_input_grad[3 + n + i])
             if i == 0 and not ctx.needs_input_grad[0]:
                 # the chain's input needs no gradient (a first layer): backward-weight only.  (A relu layer whose dy
                 # arrives masked is masked once more by this call -- idempotent.)
-                dws[0], dbs[0] = calls[0].bwd_weight(acts[0], g, acts[1], ctx.has_bias[0])
+                if direct is not None:
+                    calls[0].bwd_weight(acts[0], g, acts[1], ctx.has_bias[0], out=direct, accumulate=True)
+                    _grad_ready(pw, pb)
+                else:
+                    dws[0], dbs[0] = calls[0].bwd_weight(acts[0], g, acts[1], ctx.has_bias[0])
                 g = None
                 continue
             flags = 0
@@ -655,7 +696,13 @@ class _ConvChainFn(torch.autograd.Function):
                 flags |= L.QK_BWD_MASK_DX
             if i < n - 1 and calls[i].relu:
                 flags |= L.QK_BWD_DY_PREMASKED
-            g, dws[i], dbs[i] = calls[i].bwd(acts[i], g, acts[i + 1], ws[i], ctx.has_bias[i], flags=flags)
+            if direct is not None:
+                dx = torch.empty(calls[i].x_shape, dtype=g.dtype, device=g.device)
+                calls[i].bwd(acts[i], g, acts[i + 1], ws[i], ctx.has_bias[i], out=(dx,) + direct, flags=flags | L.QK_BWD_ACCUMULATE)
+                _grad_ready(pw, pb)
+                g = dx
+            else:
+                g, dws[i], dbs[i] = calls[i].bwd(acts[i], g, acts[i + 1], ws[i], ctx.has_bias[i], flags=flags)
         das = [None if d is None else d.reshape(p.alpha.shape) for d, p in zip(das, posts)]
         return (g, None, None) + tuple(dws) + tuple(dbs) + tuple(das)
 
