@@ -385,6 +385,45 @@ def test_full_size_16bit_mfma_kernels_agree_with_exact_fp32_kernels(case):
         assert ssum <= 1e-4, '%s: checksum drift %.3g' % (name, ssum)
 
 
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16], ids=['bf16', 'fp16'])
+def test_full_size_head_convolution_backward_agrees_with_exact_fp32_kernels(dtype):
+    """The TimeDistributed head of the B = 256 model as the (14, 1) 'valid' conj convolution the chain runs, with the
+    chain's QK_BWD_MASK_DX flag: forward (k_hgemm16, 14 taps), backward-weight (k_wgrad16) and the backward-data in its
+    streaming point form with the epilogue mask (k_hgemm16_point), against the exact fp32-MFMA kernels on the same
+    16-bit operands."""
+    import qcnn_amd
+    from qcnn_amd import _lib
+    F = qcnn_amd.functional
+    dev = _dev()
+    g = torch.Generator(device=dev).manual_seed(77)
+    xs, ws = (256, 14, 200, 256), (14, 1, 64, 256)
+    x = torch.relu(torch.randn(xs, device=dev, generator=g)).to(dtype)           # a relu layer's output (it is also the mask)
+    w = (torch.randn(ws, device=dev, generator=g) / (4.0 * (64 * 14) ** 0.5)).to(dtype).float()
+    b = (torch.randn(256, device=dev, generator=g) / 10).to(dtype).float()
+    call = F.conv_call(xs, ws, dtype, 2, 1, 'valid', 'channels_last', 1, 'relu', True, True)
+    dy = torch.randn(call.y_shape, device=dev, generator=g).to(dtype)
+
+    def run(y_mask):
+        y = call.fwd(x, w, b)
+        dx, dw, db = call.bwd(x, dy, y if y_mask is None else y_mask, w, True, flags=_lib.QK_BWD_MASK_DX)
+        torch.cuda.synchronize()
+        return y, dx, dw, db
+
+    fast = run(None)
+    assert _lib.last_path() == 'mfma16_point'
+    with _lib.debug_flags(_lib.QK_DBG_NO_MFMA16):
+        exact = run(fast[0])
+        assert _lib.last_path() == 'fp32_mfma'
+    assert float((fast[1].float() * (x.float() <= 0)).abs().max()) == 0.0          # the mask is applied
+    tol16 = 1e-2 if dtype == torch.bfloat16 else 2e-3
+    for name, a, e in zip(('y', 'dx', 'dkernel', 'dbias'), fast, exact):
+        a, e = a.float(), e.float()
+        err = float((a - e).abs().max()) / float(e.abs().max())
+        assert err <= (tol16 if name in ('y', 'dx') else 2e-3), '%s: rel err %.3g' % (name, err)
+        ssum = abs(float(a.double().sum()) - float(e.double().sum())) / float(e.double().abs().sum())
+        assert ssum <= 1e-4, '%s: checksum drift %.3g' % (name, ssum)
+
+
 def test_masked_dy_side_output_and_fused_backward_agree():
     """bwd_weight can leave dy*(y>0) for bwd_data (the DP step's ordering); the fused qk_conv_bwd and the
     two-call sequence must give the same gradients as the separate masked calls."""
