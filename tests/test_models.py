@@ -334,3 +334,31 @@ def test_bench_model_step_trains_through_the_flat_buffers(aact, dropout):
     assert float(job.flat.grad.abs().max()) == 0.0                    # Adam left the buffer zeroed
     assert all(torch.isfinite(p).all() for p in job.flat.params)
     assert loss() < l0 - 1e-3 * abs(l0), (l0, loss())
+
+
+@pytest.mark.gpu
+def test_tall_dense_split_reduction_matches_plain_autograd():
+    """layers.Dense on many 16-bit rows (the Dense(62) behind the TIMIT head) takes _TallDenseFn: same output as the
+    plain matmul, gradients equal to an fp32 autograd reference (the kernel gradient is a 32-way split reduction with
+    fp32 partial sums)."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from qcnn_amd.layers import Dense
+    dev = torch.device('cuda:0')
+    torch.manual_seed(3)
+    x = torch.randn(64, 200, 256, device=dev).to(torch.bfloat16).requires_grad_(True)
+    d = Dense(62)
+    y = d(x)
+    d.to(dev)
+    y = d(x)
+    dy = torch.randn_like(y)
+    y.backward(dy)
+    xr = x.detach().float().requires_grad_(True)
+    wr = d.kernel.detach().to(torch.bfloat16).float().requires_grad_(True)
+    br = d.bias.detach().clone().requires_grad_(True)
+    yr = xr @ wr + br
+    yr.backward(dy.float())
+    rel = lambda a, b: float((a.float() - b).abs().max() / b.abs().max())
+    assert rel(y.detach(), yr.detach()) <= 1e-2 and rel(x.grad, xr.grad) <= 1e-2
+    assert d.kernel.grad.dtype == torch.float32 and rel(d.kernel.grad, wr.grad) <= 1e-4
+    assert rel(d.bias.grad, br.grad) <= 1e-4
