@@ -681,7 +681,7 @@ def main():
         out['cpu_baseline'] = cpu_baseline(cfg, args.cpu_seconds)
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 
