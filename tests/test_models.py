@@ -362,3 +362,47 @@ def test_tall_dense_split_reduction_matches_plain_autograd():
     assert rel(y.detach(), yr.detach()) <= 1e-2 and rel(x.grad, xr.grad) <= 1e-2
     assert d.kernel.grad.dtype == torch.float32 and rel(d.kernel.grad, wr.grad) <= 1e-4
     assert rel(d.bias.grad, br.grad) <= 1e-4
+
+
+# ---- bench.py: the driver's contract ----------------------------------------------------------------------------
+def test_bench_defaults_name_the_headline_workload():
+    """`python bench.py` with no flags = the full TIMIT QCNN step, per-GPU batch 256, bf16 (BASELINE configs[2]/[3]) for
+    every N; the FLOP count of that step is the sum of its quaternion layers' 2MNK."""
+    import bench
+    assert bench.DEFAULT_WORKLOAD == 'cfg3_qcnn_timit_b256_bf16'
+    cfg = bench.WORKLOADS[bench.DEFAULT_WORKLOAD]
+    assert (cfg['kind'], cfg['batch'], cfg['dtype'], cfg['layers'], cfg['sf'], cfg['frames']) == ('model', 256, 'bf16', 10, 32, 200)
+    m0, m1, mt = 256 * 41 * 200, 256 * 14 * 200, 256 * 200
+    want = 2.0 * m0 * 128 * 60
+    want += 2.0 * m1 * (5 * 128 * 1920 + 256 * 1920 + 4 * 256 * 3840)
+    want += 2.0 * mt * 256 * 3584 + 2 * 2.0 * mt * 256 * 256
+    assert abs(bench.qcnn_flops(32, 10, 256, 200) - want) <= 1e-6 * want
+    assert set(bench.PEAK_TFLOPS) >= {'fp32', 'bf16', 'fp16'} and bench.PEAK_TFLOPS['bf16'] == 2500.0
+
+
+@pytest.mark.gpu
+def test_bench_prints_one_contract_line():
+    """The default bench command (shortened) on the GPU: exactly one JSON line on stdout with the contract's fields, the
+    in-step per-call table and a roofline block taken from it."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--steps', '3', '--warmup', '1', '--no-cpu-baseline',
+                          '--no-extras', '--no-standalone'], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+              'dtype', 'data', 'config', 'roofline', 'pre_warmup_steps'):
+        assert k in d, k
+    assert (d['n_gpus'], d['steps'], d['warmup'], d['unit'], d['dtype'], d['data'], d['scaling']) == (1, 3, 1, 'samples/s', 'bf16', 'synthetic', 'weak')
+    assert d['config']['workload'] == 'cfg3_qcnn_timit_b256_bf16' and d['vs_baseline'] is None and d['higher_is_better'] is True
+    assert abs(d['value'] - 256 * 1e3 / d['ms_per_step']) <= 1e-6 * d['value']
+    calls = d['in_step_kernels']['calls']
+    assert {(c['rows'], c['n'], c['k']) for c in calls} >= {(716800, 256, 3840), (716800, 128, 1920), (716800, 256, 1920)}
+    r = d['roofline']
+    assert r['bound'] == 'mfma' and r['peak'] == 2500.0 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9
+    assert abs(r['achieved'] - r['flops_per_launch'] / (r['avg_launch_ms'] * 1e-3) / 1e12) <= 1e-6 * r['achieved']
