@@ -1,15 +1,25 @@
 #!/usr/bin/env python
 """Benchmark of the Hamilton-product hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: one process per GPU over RCCL.  Under a launcher (torch.distributed.run sets RANK / LOCAL_RANK / WORLD_SIZE /
+MASTER_*) this process is one rank; started plainly, `python bench.py --gpus N` starts the N ranks ITSELF
+(qcnn_amd.dp.spawn_ranks: LOCAL_RANK-pinned devices, 127.0.0.1, a free port) and fails if fewer than N devices are
+visible.  Either way rank 0 prints the line, and for N > 1 it carries the proof: `config.rccl_ranks` (an all-reduce of
+ones), per-rank step times, the bucket sizes and the EXPOSED collective time (step with - step without all-reduces).
 
 Default workload (every N) = BASELINE.json configs[2] / [3]: the FULL TIMIT quaternion CNN of
 models/interspeech_model.py (n=10, sf=32: conv 1->32, pool, 5 x conv 32, 5 x conv 64, 3 x TimeDistributed
-QuaternionDense(256), Dense(62) softmax), bf16, 256 samples PER GPU (weak scaling: global batch 256 N, 2048 on
-8 GPUs), forward + backward of every layer + the Keras-Adam update of all 1.68 M parameters.  A "step" is one such
-pass over one synthetic batch already resident in HBM.  Data-parallel: every rank holds a replica; gradients are
-summed with bucketed RCCL all-reduces launched from autograd hooks while the backward is still running
-(qcnn_amd/dp.py), 1/N folded into the fused Adam kernel.
+QuaternionDense(256), Dense(62) softmax) AS THE REFERENCE BUILDS IT for aact='none': relu layers, Dropout(d.dropout)
+behind every body convolution and the first two dense layers (:117-121,131-137,150-154; d.dropout = 0.3), an l2
+kernel regulariser on every layer (:63,68,173; d.l2 = 1e-5), channels_first input (:81); bf16, 256 samples PER GPU
+(weak scaling: global batch 256 N, 2048 on 8 GPUs), forward + backward of every layer + the Keras-Adam update (with
+the l2 term) of all 1.70 M parameters.  A "step" is one such pass over one synthetic (B, 4, 41, 200) batch already
+resident in HBM -- the channels_first -> channels_last re-layout of the input is part of the step.  `--loss ctc`
+swaps the sum loss for the model's CTC cost (:37-39,178).  Data-parallel: every rank holds a replica; gradients are
+summed with bucketed RCCL all-reduces launched while the backward is still running (qcnn_amd/dp.py), 1/N folded into
+the fused Adam kernel.
 
 Prints ONE JSON line on rank 0.  `value` = whole-job samples/s of that step.  At N = 1 the line also carries
   roofline       the kernel that takes the largest share of the step (one of the Hamilton GEMM kernels of the
@@ -59,12 +69,16 @@ WORKLOADS = {
     # TimeDistributed(QuaternionDense(256)) head (in_q = 3584), fp16, 32 samples per GPU
     'cfg5_stack_b32_fp16': dict(kind='stack', batch=32, frames=200, freq=14, width=256, body=9, dtype='fp16'),
     # BASELINE.json configs[2]: the full TIMIT QCNN (models/interspeech_model.py:45-185), n=10, sf=32
+    #   ... as the reference builds it (aact='none'): relu, Dropout(0.3) behind every body conv / dense, l2 regulariser
+    'cfg3_qcnn_relu_dropout_b256_bf16': dict(kind='model', batch=256, frames=200, sf=32, layers=10, dtype='bf16',
+                                             dropout=0.3, l2=1e-5),
+    #   ... without dropout and l2 (the round-1/2 headline; kept for comparison)
     'cfg3_qcnn_timit_b256_bf16': dict(kind='model', batch=256, frames=200, sf=32, layers=10, dtype='bf16'),
     'cfg3_qcnn_timit_b64_fp32': dict(kind='model', batch=64, frames=200, sf=32, layers=10, dtype='fp32'),
     # the reference's own activation / regularisation setting (interspeech_model.py:55-56,99-137: aact='prelu' makes
     # every layer linear + PReLU(shared_axes=[1,0]) + Dropout): PReLU and dropout fused into the kernel epilogues
     'cfg3_qcnn_prelu_dropout_b256_bf16': dict(kind='model', batch=256, frames=200, sf=32, layers=10, dtype='bf16',
-                                              aact='prelu', dropout=0.3),
+                                              aact='prelu', dropout=0.3, l2=1e-5),
 }
 
 
@@ -86,34 +100,43 @@ def qcnn_flops(sf, n, batch, frames):
 
 
 class ModelTrainStep(object):
-    """Full TIMIT QCNN: forward + backward (autograd through the C-ABI kernels) + bucketed all-reduce + Adam."""
+    """Full TIMIT QCNN: forward + backward (autograd through the C-ABI kernels) + bucketed all-reduce + Adam (+ l2)."""
 
-    def __init__(self, cfg, dev, rank, world):
+    def __init__(self, cfg, dev, rank, world, loss='sum'):
         import qcnn_amd
         from qcnn_amd import dp, functional as F
         from qcnn_amd.models import TimitQCNN
-        self.F, self.dp, self.world, self.cfg = F, dp, world, cfg
+        self.F, self.dp, self.world, self.cfg, self.loss = F, dp, world, cfg, loss
         dt = TORCH_DT[cfg['dtype']]
         gen = torch.Generator(device=dev).manual_seed(1234 + rank)
         B, T = cfg['batch'], cfg['frames']
-        # channels_first quaternion features, physically channels-last (DESIGN.md section 2)
-        self.x = torch.randn(B, 41, T, 4, device=dev, generator=gen).to(dt).permute(0, 3, 1, 2)
+        # the reference's input: Input(shape=(4, 41, None)), channels_first (interspeech_model.py:81) -- a plain
+        # contiguous NCHW buffer; the model's one re-layout to channels-last (DESIGN.md section 2) runs inside the step
+        self.x = torch.randn(B, 4, 41, T, device=dev, generator=gen).to(dt)
         np.random.seed(0)
         torch.manual_seed(0)
         self.model = TimitQCNN(num_layers=cfg['layers'], start_filter=cfg['sf'], act='relu',
-                               aact=cfg.get('aact', 'none'), dropout=cfg.get('dropout', 0.0))
+                               aact=cfg.get('aact', 'none'), dropout=cfg.get('dropout', 0.0), l2=cfg.get('l2', 0.0))
         self.model.train()
         with torch.no_grad():
             self.model(self.x[:2])
         self.model.to(dev)
         params = [p for p in self.model.parameters() if p.requires_grad]
-        self.flat = dp.FlatParams(params)
+        # direct=True: the backward kernels are the ONLY writers of the gradient buffer -- the l2 regularisers are not
+        # differentiated through autograd (model.regularization_loss()) but folded into the Adam kernel (decay)
+        self.flat = dp.FlatParams(params, direct=True)
+        self.decay = self.flat.l2_decay()
         dp.broadcast_params(self.flat)
-        # one message per >= 1 MB of gradients, launched from autograd hooks as the backward produces them
+        # one message per >= 1 MB of gradients, launched as the backward produces them
         self.reducer = dp.BucketedAllReduce(self.flat, bucket_bytes=cfg.get('bucket_bytes', 1 << 20))
         self.m = torch.zeros_like(self.flat.param)
         self.v = torch.zeros_like(self.flat.param)
         self.target = torch.randn(B, T, 62, device=dev, generator=gen)
+        if loss == 'ctc':        # K.ctc_batch_cost inputs (interspeech_model.py:37-39,83-85): 61 phone labels + blank
+            cg = torch.Generator().manual_seed(99 + rank)
+            self.label_length = torch.randint(20, 51, (B, 1), generator=cg)
+            self.labels = torch.randint(0, 61, (B, 50), generator=cg).to(dev)
+            self.input_length = torch.full((B, 1), T, dtype=torch.long)
         self.t = 0
         self.flops_per_kernel = qcnn_flops(cfg['sf'], cfg['layers'], B, T)      # forward; step = 3x
         self.gemm = dict(layers='conv 1->%d, %dx conv, 3x TD-dense' % (cfg['sf'], cfg['layers']),
@@ -122,12 +145,15 @@ class ModelTrainStep(object):
 
     def step(self):
         self.t += 1
-        pred = self.model(self.x)
-        loss = (pred.float() * self.target).sum()       # (CTC is a "next" row: SURVEY.md 8d asks for a sum loss here)
+        if self.loss == 'ctc':
+            loss = self.model.ctc_loss(self.x, self.labels, self.input_length, self.label_length).mean()
+        else:
+            pred = self.model(self.x)
+            loss = (pred.float() * self.target).sum()
         loss.backward()                                 # gradients accumulate into the zeroed flat buffer; the
         self.reducer.finish()                           # buckets go out while the backward is still running
         self.F.adam_step(self.flat.param, self.flat.grad, self.m, self.v, self.t, lr=5e-4,
-                         grad_scale=1.0 / self.world, zero_grad=True)
+                         grad_scale=1.0 / self.world, zero_grad=True, decay=self.decay)
 
     def capture(self):
         raise RuntimeError('model workloads run eagerly (launch overhead is negligible at this size)')
@@ -431,7 +457,7 @@ def cpu_baseline(cfg, seconds):
                       'no optimizer step)' % (n, what, sample_b)}
 
 
-DEFAULT_WORKLOAD = 'cfg3_qcnn_timit_b256_bf16'
+DEFAULT_WORKLOAD = 'cfg3_qcnn_relu_dropout_b256_bf16'
 # (kernel, launches per QCNN step) of the three conv shapes: used to name the kernel with the largest share of a step
 QCNN_LAYER_COUNTS = {'cfg3_body_qconv2d_b256_bf16': 4, 'cfg3_stage1_qconv2d_b256_bf16': 5, 'cfg3_32to64_qconv2d_b256_bf16': 1}
 
@@ -464,7 +490,9 @@ def in_step_kernel_times(job, dev, peak, steps=3):
                       'mean over %d steps taken right after the timed region' % steps}
 
 
-def timed_steps(job, steps, warmup, pre, barrier, world, dev, dist):
+def timed_steps(job, steps, warmup, pre, barrier, world, dev, dist, per_rank=None):
+    """W untimed warm-up steps, then exactly `steps` steps between two (barrier + device synchronize) pairs; returns the
+    MAX over ranks of the elapsed seconds.  per_rank (a list) receives every rank's own elapsed time."""
     for _ in range(pre):
         job.step()
     torch.cuda.synchronize()
@@ -474,13 +502,47 @@ def timed_steps(job, steps, warmup, pre, barrier, world, dev, dist):
     t0 = time.perf_counter()
     for _ in range(steps):
         job.step()
+    torch.cuda.synchronize()
+    own = time.perf_counter() - t0                     # this rank's work, before it waits for the others
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist.is_initialized():
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+        if per_rank is not None:
+            mine = torch.tensor([own], device=dev, dtype=torch.float64)
+            allr = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+            dist.all_gather(allr, mine)
+            per_rank[:] = [float(t.item()) for t in allr]
+    elif per_rank is not None:
+        per_rank[:] = [own]
     return elapsed
+
+
+def dp_proof(job, steps, ms_per_step, per_rank, barrier, world, dev, dist):
+    """What shows that `world` RCCL ranks really ran the step together (N > 1, or a forced one-rank group): the rank
+    count as an all-reduce of ones sees it, every rank's own step time, the gradient buckets, and the EXPOSED cost of
+    the collectives = this step's time minus the same step with the all-reduces switched off (hooks still count, nothing
+    is sent: BucketedAllReduce.enabled = False; replicas drift apart during those steps, which no longer matters)."""
+    ones = torch.ones(1, device=dev)
+    dist.all_reduce(ones)
+    out = {'rccl_ranks': int(ones.item()), 'backend': dist.get_backend(), 'world_size': dist.get_world_size(),
+           'rank_ms_per_step': {'min': 1e3 * min(per_rank) / steps, 'max': 1e3 * max(per_rank) / steps,
+                                'all': [round(1e3 * t / steps, 4) for t in per_rank]}}
+    red = getattr(job, 'reducer', None)
+    if red is not None:
+        nb = red.bucket_bytes()
+        out['allreduce'] = {'buckets': len(nb), 'bucket_bytes': nb, 'bytes_per_step': int(sum(nb)), 'dtype': 'fp32',
+                            'launch': 'per bucket, from the backward (autograd hook / kernel-side notification)'}
+        k = max(3, min(steps, 20))
+        red.enabled = False
+        el = timed_steps(job, k, 2, 0, barrier, world, dev, dist)
+        red.enabled = True
+        off = 1e3 * el / k
+        out['allreduce']['ms_per_step_without_collectives'] = off
+        out['allreduce']['exposed_ms_per_step'] = ms_per_step - off
+    return out
 
 
 def main():
@@ -501,16 +563,32 @@ def main():
                     help='with --graph and N > 1: hipGraph segments around the RCCL all-reduce')
     ap.add_argument('--no-hamilton-gemm', action='store_true', help='skip the batch-256 bf16 Hamilton GEMM kernel timing')
     ap.add_argument('--activation', default='relu', choices=['relu', 'linear'], help='layer workloads, diagnostic: linear drops the relu mask')
+    ap.add_argument('--loss', default='sum', choices=['sum', 'ctc'],
+                    help='model workloads: sum = <prediction, fixed random tensor> (SURVEY.md 8d); ctc = the CTC cost the '
+                         'reference model outputs (interspeech_model.py:37-39,178), mean over the batch')
     args = ap.parse_args()
 
-    import qcnn_amd  # noqa: F401  (fails loudly if libqk_hip.so is missing)
+    import qcnn_amd  # noqa: F401  (fails loudly if libqk_hip.so is missing; never builds anything)
     from qcnn_amd import dp
     import torch.distributed as dist
 
-    rank, world, local = dp.init_from_env()
-    if world != args.gpus and rank == 0:
-        sys.stderr.write('warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE\n' % (args.gpus, world))
+    if args.gpus < 1:
+        sys.exit('bench.py: --gpus must be >= 1')
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        # started plainly: this process becomes the launcher of N ranks (one per GPU) and relays rank 0's line
+        n_dev = torch.cuda.device_count()
+        if n_dev < args.gpus:
+            sys.exit('bench.py: --gpus %d but only %d GPU(s) are visible on this node' % (args.gpus, n_dev))
+        sys.exit(dp.spawn_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+                                env=dict(os.environ, QK_BENCH_SELF_LAUNCHED='1')))
+
     assert torch.cuda.is_available(), 'bench.py needs a GPU'
+    world_env, local_env = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('LOCAL_RANK', '0'))
+    if world_env != args.gpus:
+        sys.exit('bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks' % (args.gpus, world_env))
+    if local_env >= torch.cuda.device_count():
+        sys.exit('bench.py: LOCAL_RANK %d but only %d GPU(s) are visible' % (local_env, torch.cuda.device_count()))
+    rank, world, local = dp.init_from_env()
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
     cfg = dict(WORKLOADS[args.workload], activation=args.activation)
@@ -518,7 +596,12 @@ def main():
     is_model = cfg.get('kind') == 'model' or is_stack
     steps = args.steps if args.steps is not None else (30 if is_stack else 100 if is_model else 300)
     warmup = args.warmup if args.warmup is not None else (3 if is_stack else 10 if is_model else 30)
-    job = (StackTrainStep if is_stack else ModelTrainStep if is_model else LayerTrainStep)(cfg, dev, rank, world)
+    if is_stack:
+        job = StackTrainStep(cfg, dev, rank, world)
+    elif is_model:
+        job = ModelTrainStep(cfg, dev, rank, world, loss=args.loss)
+    else:
+        job = LayerTrainStep(cfg, dev, rank, world)
 
     def barrier():
         if world > 1 or dist.is_initialized():
@@ -536,21 +619,38 @@ def main():
     # `pre_warmup_steps`: one-off initialisation in front of the contract's W warm-up steps -- the first launches load
     # the code objects, size the workspaces and settle the allocator.  Reported in the JSON; never timed.
     pre = 2 if is_model else 8
-    elapsed = timed_steps(job, steps, warmup, pre, barrier, world, dev, dist)
+    per_rank = []
+    elapsed = timed_steps(job, steps, warmup, pre, barrier, world, dev, dist, per_rank)
     ms_per_step = 1e3 * elapsed / steps
     samples_per_s = world * cfg['batch'] * steps / elapsed
 
     out = {
         'metric': 'quaternion-conv samples/sec (fwd+bwd+Adam of %s)' % ('the config-5 stack, per-GPU batch %d' % cfg['batch'] if is_stack else 'the full TIMIT QCNN, per-GPU batch %d' % cfg['batch'] if is_model else 'one QuaternionConv layer'),
+        'ranks': 'one process per GPU (%s)' % ('launched by bench.py itself: qcnn_amd.dp.spawn_ranks' if os.environ.get('QK_BENCH_SELF_LAUNCHED') else
+                                               'started by an external launcher' if 'WORLD_SIZE' in os.environ else 'single process'),
         'value': samples_per_s, 'unit': 'samples/s', 'n_gpus': world, 'steps': steps,
         'warmup': warmup, 'pre_warmup_steps': pre, 'ms_per_step': ms_per_step, 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': cfg['dtype'], 'data': 'synthetic',
         'config': {'workload': args.workload, 'per_gpu_batch': cfg['batch'],
                    'global_batch': cfg['batch'] * world, 'input': list(job.x.shape),
                    'filters': cfg.get('filters', cfg.get('sf')), 'kernel_size': list(cfg.get('kernel', (3, 5))), 'padding': 'same',
-                   'activation': cfg['activation'], 'gemm_view': job.gemm, 'parallelism': 'dp%d' % world,
-                   'optimizer': 'adam(5e-4)', 'launch': 'hipgraph' if use_graph else 'eager'},
+                   'activation': cfg.get('aact', 'none') if cfg.get('aact', 'none') != 'none' else cfg['activation'],
+                   'dropout': cfg.get('dropout', 0.0), 'l2': cfg.get('l2', 0.0),
+                   'loss': args.loss if is_model and not is_stack else 'sum',
+                   'input_layout': 'channels_first (B, 4, 41, T) contiguous; re-laid out to channels-last inside the step' if is_model and not is_stack else 'channels_last',
+                   'gemm_view': job.gemm, 'parallelism': 'dp%d' % world,
+                   'optimizer': 'adam(5e-4)' + (' + l2 term folded into the update' if cfg.get('l2') else ''),
+                   'launch': 'hipgraph' if use_graph else 'eager'},
     }
+    if dist.is_initialized():
+        try:
+            proof = dp_proof(job, steps, ms_per_step, per_rank, barrier, world, dev, dist)
+            out['config']['rccl_ranks'] = proof.pop('rccl_ranks')
+            out['dp'] = proof
+        except Exception as e:
+            out['dp'] = {'error': repr(e)}
+    else:
+        out['config']['rccl_ranks'] = None
     peak = PEAK_TFLOPS[cfg['dtype']]
     stream = torch.cuda.current_stream(dev)
     timing = rank == 0 and world == 1 and not args.no_kernel_timing and not is_stack
@@ -630,21 +730,27 @@ def main():
         job = None
         torch.cuda.empty_cache()
         if not args.no_extras:
-            try:        # the reference's own activation setting: linear layers + PReLU + Dropout(0.3), fused post-ops
-                pcfg = dict(WORKLOADS['cfg3_qcnn_prelu_dropout_b256_bf16'], activation='prelu')
-                pj = ModelTrainStep(pcfg, dev, 0, 1)
-                el = timed_steps(pj, 30, 5, 2, barrier, 1, dev, dist)
-                ptf = 3 * pj.flops_per_kernel / (el / 30) / 1e12
-                out['qcnn_prelu_dropout_step'] = {'workload': 'cfg3_qcnn_prelu_dropout_b256_bf16', 'steps': 30, 'warmup': 5,
-                                                  'pre_warmup_steps': 2, 'ms_per_step': 1e3 * el / 30,
-                                                  'samples_per_s': pcfg['batch'] * 30 / el, 'tflops': ptf,
-                                                  'frac_of_peak': ptf / PEAK_TFLOPS['bf16'],
-                                                  'note': 'aact=prelu, dropout=0.3 (interspeech_model.py:99-137): dense (no exact zeros) '
-                                                          'activations and gradients -- the chip clocks lower than on the relu variant'}
-                del pj
-                torch.cuda.empty_cache()
-            except Exception as e:
-                out['qcnn_prelu_dropout_step'] = {'error': repr(e)}
+            # the other forms of the same model: the reference's aact='prelu' setting (linear layers + PReLU + Dropout(0.3),
+            # fused post-ops), the dropout-free / l2-free step (the round-1/2 headline) and the CTC cost as the loss
+            variants = (('qcnn_prelu_dropout_step', 'cfg3_qcnn_prelu_dropout_b256_bf16', 'sum',
+                         'aact=prelu, dropout=0.3 (interspeech_model.py:99-137): dense (no exact zeros) activations and gradients'),
+                        ('qcnn_nodropout_step', 'cfg3_qcnn_timit_b256_bf16', 'sum', 'relu, dropout=0, no l2 term (the headline of rounds 1-2)'),
+                        ('qcnn_ctc_step', DEFAULT_WORKLOAD, 'ctc', 'the default workload with K.ctc_batch_cost (interspeech_model.py:37-39,178), '
+                                                                    'mean over the batch, as the loss'))
+            for key, wl, loss, note in variants:
+                if wl == args.workload and loss == args.loss:
+                    continue
+                try:
+                    pcfg = dict(WORKLOADS[wl], activation='relu')
+                    pj = ModelTrainStep(pcfg, dev, 0, 1, loss=loss)
+                    el = timed_steps(pj, 30, 5, 2, barrier, 1, dev, dist)
+                    ptf = 3 * pj.flops_per_kernel / (el / 30) / 1e12
+                    out[key] = {'workload': wl, 'loss': loss, 'steps': 30, 'warmup': 5, 'pre_warmup_steps': 2, 'ms_per_step': 1e3 * el / 30,
+                                'samples_per_s': pcfg['batch'] * 30 / el, 'tflops': ptf, 'frac_of_peak': ptf / PEAK_TFLOPS['bf16'], 'note': note}
+                    del pj
+                    torch.cuda.empty_cache()
+                except Exception as e:
+                    out[key] = {'error': repr(e)}
             try:        # BASELINE configs[1]: the single QuaternionConv1D layer, step + kernels
                 c2 = dict(WORKLOADS['cfg2_qconv1d_timit_b64_fp32'], activation='relu')
                 j2 = LayerTrainStep(c2, dev, 0, 1)

@@ -57,7 +57,7 @@
 extern "C" {
 #endif
 
-#define QK_VERSION 100 /* major*10000 + minor*100 + patch */
+#define QK_VERSION 101 /* major*10000 + minor*100 + patch */
 
 typedef enum {
     QK_OK = 0,
@@ -227,30 +227,40 @@ int qk_dense_bwd_chain(const qk_dense_desc_t *desc, const void *x, const void *d
  * activation is (1, F, 1): alpha_axis = 0, alpha_len = F.  The dropout mask is never stored: keep(e) is a hash of
  * (drop_seed, flat element index of y in its channels_last buffer), identical in forward and backward; pass a new
  * seed every step.  Each element gets 8 random bits: the rate applied is round(drop_rate * 256) / 256 (the kept
- * elements are scaled by the reciprocal of THAT keep probability).  drop_rate = 0 disables dropout. */
+ * elements are scaled by the reciprocal of THAT keep probability).  drop_rate = 0 disables dropout.
+ *
+ * alpha == NULL selects the relu form,  y = drop(relu(pre)),  the model's `aact == 'none'` setting (relu layers with
+ * `Dropout(d.dropout)` behind every body convolution, interspeech_model.py:117-121,131-137).  There the slope is 0 by
+ * definition, so ONE tensor is written (y; `pre` arguments may be NULL) and the backward needs nothing but y:
+ * d pre = dy / (1 - rate) where y > 0  (y > 0 <=> pre > 0 and kept) -- no mask regeneration, no slope gradient
+ * (alpha_axis / alpha_len are ignored, dalpha arguments may be NULL). */
 typedef struct {
     int32_t alpha_axis;      /* -1: scalar; 0..2: spatial axis of the activation that indexes alpha       */
     int32_t alpha_len;       /* 1 for a scalar, else the extent of that axis                                */
-    const float *alpha;      /* device pointer, float32                                                     */
+    const float *alpha;      /* device pointer, float32; NULL: relu (+ dropout), see above                  */
     float drop_rate;         /* in [0, 1)                                                                   */
     uint32_t drop_seed;
 } qk_postop_t;
 
 /* y = post(W (x) x + b): the convolution must be LINEAR (desc->activation); `pre` receives W (x) x + b (same
- * shape / dtype as y; needed by the backward of the post-op), `y` the activated / dropped tensor. */
+ * shape / dtype as y; needed by the backward of the post-op; NULL for the relu form), `y` the activated / dropped
+ * tensor. */
 int qk_conv_fwd_post(const qk_conv_desc_t *desc, const qk_postop_t *post, const void *x, const float *w,
                      const float *bias, void *pre, void *y, void *workspace, size_t workspace_bytes, void *stream);
 
 /* Fused backward of a LINEAR layer (dy = d loss / d pre of THIS layer) whose input x = post_x(x_pre) was produced by
  * a post-op: dw, dbias as qk_conv_bwd; dx receives d loss / d x_pre (the post-op's derivative is applied in the
- * epilogue of backward-data), dalpha_x[alpha_len] (float32) is ACCUMULATED into (zero it once per step). */
+ * epilogue of backward-data), dalpha_x[alpha_len] (float32) is ACCUMULATED into (zero it once per step).  For the
+ * relu form (post_x->alpha == NULL) x_pre and dalpha_x are not used (may be NULL): x is its own mask.
+ * flags: 0 or QK_BWD_ACCUMULATE (dw / dbias are added to, as qk_conv_bwd_weight_acc). */
 int qk_conv_bwd_post(const qk_conv_desc_t *desc, const void *x, const void *dy, const float *w, void *dx, float *dw,
-                     float *dbias, const qk_postop_t *post_x, const void *x_pre, float *dalpha_x, void *workspace,
-                     size_t workspace_bytes, void *stream);
+                     float *dbias, const qk_postop_t *post_x, const void *x_pre, float *dalpha_x, int32_t flags,
+                     void *workspace, size_t workspace_bytes, void *stream);
 
 /* The post-op on its own (any dtype / shape, HBM-bound): `t` describes the channels_last activation
  * (batch, spatial[0..rank-1], channels) -- only batch, rank, out_spatial, fq (channels = 4 * fq) and dtype of a
- * qk_conv_desc_t are read.  bwd: dpre = d loss / d pre, dalpha accumulated. */
+ * qk_conv_desc_t are read.  bwd: dpre = d loss / d pre, dalpha accumulated.  Relu form (alpha == NULL): the
+ * backward takes the forward OUTPUT y in place of `pre`, dalpha may be NULL. */
 int qk_postop_fwd(const qk_conv_desc_t *t, const qk_postop_t *post, const void *pre, void *y, void *stream);
 int qk_postop_bwd(const qk_conv_desc_t *t, const qk_postop_t *post, const void *pre, const void *dy, void *dpre,
                   float *dalpha, void *stream);
@@ -262,7 +272,9 @@ int qk_postop_bwd(const qk_conv_desc_t *t, const qk_postop_t *post, const void *
  * (N, ceil(H / pool), W, 4F) plus `aux` (2 bits per pooled element: which window row held the maximum, or "relu
  * killed it"), the backward reads x, the pooled gradient and aux and returns dw / dbias (overwritten) -- the 537 MB
  * pre-pool activation of the B = 256 model never exists.  Supported: rank 2, QK_CH_LAST, bf16 / fp16, cq == 1, kernel
- * (3,5), unit stride / dilation, pad_lo (1,2), activation RELU, conj 0, fq % 32 == 0, pool == 3; anything else returns
+ * (3,5), unit stride / dilation, pad_lo (1,2), activation RELU, conj 0, fq % 32 == 0, pool == 3, H % 3 != 1 (the
+ * kernel's windows are rows [3o, 3o + 2]; TensorFlow's 'same' rule pads one row on the LOW side when H % 3 == 1, so
+ * for those heights the windows would start at row -1: not this kernel's -- 41 bins are fine); anything else returns
  * QK_ERR_UNSUPPORTED (qk_conv_relu_pool_aux_bytes: 0) and the caller runs qk_conv_fwd + qk_maxpool2d_* instead.
  * `aux` may be NULL in the forward (inference). */
 size_t qk_conv_relu_pool_aux_bytes(const qk_conv_desc_t *desc, int32_t pool);
@@ -334,6 +346,16 @@ int qk_adam_step(float *param, const float *grad, float *m, float *v, size_t n, 
 int qk_adam_step_zero_grad(float *param, float *grad, float *m, float *v, size_t n, float lr,
                            float beta1, float beta2, float eps, int32_t step, float grad_scale,
                            void *stream);
+
+/* qk_adam_step(_zero_grad) with the model's l2 kernel regularisers folded in.  Keras adds  l2 * sum(w^2)  of every
+ * regularised kernel to the loss (models/interspeech_model.py:63,68,173: kernel_regularizer=l2(d.l2)); its gradient
+ * 2 * l2 * w is applied here as  g = grad * grad_scale + decay[i] * param[i]  (decay: one coefficient per element,
+ * 2 * l2 on regularised kernels and 0 on biases / slopes; NULL = no term).  The backward kernels then remain the
+ * only writers of the gradient buffer, which is what lets them add into it directly (QK_BWD_ACCUMULATE) and lets a
+ * data-parallel caller send a bucket the moment its last kernel has finished.  zero_grad != 0 clears grad. */
+int qk_adam_step_l2(float *param, float *grad, float *m, float *v, const float *decay, size_t n, float lr,
+                    float beta1, float beta2, float eps, int32_t step, float grad_scale, int32_t zero_grad,
+                    void *stream);
 
 #ifdef __cplusplus
 }

@@ -77,7 +77,7 @@ SYMBOLS = {
     'qk_conv_fwd': (ctypes.c_int, [_CD, _VP, _FP, _FP, _VP, _VP, _SZ, _VP]),
     'qk_conv_bwd_data': (ctypes.c_int, [_CD, _VP, _VP, _FP, _VP, _VP, _SZ, _VP]),
     'qk_conv_fwd_post': (ctypes.c_int, [_CD, _PO, _VP, _FP, _FP, _VP, _VP, _VP, _SZ, _VP]),
-    'qk_conv_bwd_post': (ctypes.c_int, [_CD, _VP, _VP, _FP, _VP, _FP, _FP, _PO, _VP, _FP, _VP, _SZ, _VP]),
+    'qk_conv_bwd_post': (ctypes.c_int, [_CD, _VP, _VP, _FP, _VP, _FP, _FP, _PO, _VP, _FP, I32, _VP, _SZ, _VP]),
     'qk_postop_fwd': (ctypes.c_int, [_CD, _PO, _VP, _VP, _VP]),
     'qk_postop_bwd': (ctypes.c_int, [_CD, _PO, _VP, _VP, _VP, _FP, _VP]),
     'qk_conv_bwd_weight': (ctypes.c_int, [_CD, _VP, _VP, _VP, _FP, _FP, _VP, _SZ, _VP]),
@@ -98,6 +98,8 @@ SYMBOLS = {
     'qk_dense_bwd_weight': (ctypes.c_int, [_DD, _VP, _VP, _VP, _FP, _FP, _VP, _SZ, _VP]),
     'qk_adam_step_zero_grad': (ctypes.c_int, [_FP, _FP, _FP, _FP, _SZ, ctypes.c_float, ctypes.c_float,
                                               ctypes.c_float, ctypes.c_float, I32, ctypes.c_float, _VP]),
+    'qk_adam_step_l2': (ctypes.c_int, [_FP, _FP, _FP, _FP, _FP, _SZ, ctypes.c_float, ctypes.c_float,
+                                       ctypes.c_float, ctypes.c_float, I32, ctypes.c_float, I32, _VP]),
     'qk_maxpool2d_fwd': (ctypes.c_int, [_PD, _VP, _VP, _VP]),
     'qk_maxpool2d_bwd': (ctypes.c_int, [_PD, _VP, _VP, _VP, _VP]),
     'qk_adam_step': (ctypes.c_int, [_FP, _FP, _FP, _FP, _SZ, ctypes.c_float, ctypes.c_float,

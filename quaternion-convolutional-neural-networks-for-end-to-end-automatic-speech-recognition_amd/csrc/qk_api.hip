@@ -219,13 +219,18 @@ int to_postop(const qk_postop_t *q, int rank, const int32_t *sp, PostOp *p)
 {
     memset(p, 0, sizeof(*p));
     if (!q) return 0;
-    if (!q->alpha) { set_error("post-op: alpha is NULL"); return QK_ERR_INVALID_ARG; }
-    if (q->alpha_axis < -1 || q->alpha_axis >= (rank > 0 ? rank : 1) || !(q->drop_rate >= 0.f && q->drop_rate < 1.f)) {
-        set_error("post-op: alpha_axis %d / drop_rate %g out of range", q->alpha_axis, (double)q->drop_rate); return QK_ERR_INVALID_ARG;
+    if (!(q->drop_rate >= 0.f && q->drop_rate < 1.f)) { set_error("post-op: drop_rate %g out of range", (double)q->drop_rate); return QK_ERR_INVALID_ARG; }
+    if (!q->alpha) {
+        // relu + dropout: y = drop(relu(pre)), one output tensor, the backward reads y only (qk_postop.h, kind 2)
+        p->kind = 2; p->alpha_sel = -1; p->alpha_len = 0; p->alpha = nullptr;
+    } else {
+        if (q->alpha_axis < -1 || q->alpha_axis >= (rank > 0 ? rank : 1)) {
+            set_error("post-op: alpha_axis %d out of range", q->alpha_axis); return QK_ERR_INVALID_ARG;
+        }
+        const int want = q->alpha_axis < 0 ? 1 : sp[q->alpha_axis];
+        if (q->alpha_len != want) { set_error("post-op: alpha_len %d, expected %d", q->alpha_len, want); return QK_ERR_INVALID_ARG; }
+        p->kind = 1; p->alpha_sel = q->alpha_axis; p->alpha_len = q->alpha_len; p->alpha = q->alpha;
     }
-    const int want = q->alpha_axis < 0 ? 1 : sp[q->alpha_axis];
-    if (q->alpha_len != want) { set_error("post-op: alpha_len %d, expected %d", q->alpha_len, want); return QK_ERR_INVALID_ARG; }
-    p->kind = 1; p->alpha_sel = q->alpha_axis; p->alpha_len = q->alpha_len; p->alpha = q->alpha;
     p->drop_scale = 1.f / (1.f - q->drop_rate);
     unsigned thr = (unsigned)(q->drop_rate * 256.f + 0.5f);      // 8 random bits per element: rates are multiples of 1/256
     p->drop_thr = thr > 255u ? 255u : thr;
@@ -296,26 +301,30 @@ int conv_fwd_impl(const qk_conv_desc_t *d, const void *x, const float *w, const 
     g.has_mask = 0;
     const bool with_post = post && post->kind;
     if (d->dtype != QK_F32) {
-        if (with_post && d->layout == QK_CH_LAST && aligned(pre, 16) && aligned(y, 16)) { g.post = *post; g.pre_out = pre; }
+        if (with_post && d->layout == QK_CH_LAST && aligned(pre, 16) && aligned(y, 16) &&
+            (long long)g.M * 4 * d->fq < (1ll << 32)) {                 // the dropout hash indexes elements with 32 bits
+            g.post = *post; g.post_fwd = 1; g.pre_out = post->kind == 1 ? pre : nullptr;
+        }
         const int r = try_hgemm_16(d->dtype, x, nullptr, w, bias, y, g, false, ws, wsb, stream);
         if (r != 0) return r < 0 ? r : 0;
-        g.post.kind = 0; g.pre_out = nullptr;
+        g.post.kind = 0; g.post_fwd = 0; g.pre_out = nullptr;
     }
     const bool vec = d->layout == QK_CH_LAST && d->cq % 4 == 0 && d->fq % 4 == 0 &&
                      vec_aligned(x, d->dtype) && aligned(w, 16);
     note_path(QK_PATH_FP32_MFMA);
     if (!with_post) return launch_hgemm(d->dtype, x, nullptr, w, bias, y, g, vec, stream);
-    // general path: the convolution writes pre, the post-op runs as its own pass
+    // general path: the convolution writes pre (kind 2: into y, in place), the post-op runs as its own pass
     if (d->layout != QK_CH_LAST) { set_error("post-op needs channels_last buffers"); return QK_ERR_UNSUPPORTED; }
-    if (int rc = launch_hgemm(d->dtype, x, nullptr, w, bias, pre, g, vec, stream)) return rc;
-    return postop_pass(d->dtype, false, *post, d->batch, d->out_spatial, 4 * d->fq, pre, nullptr, y, nullptr, stream);
+    void *lin = post->kind == 1 ? pre : y;
+    if (int rc = launch_hgemm(d->dtype, x, nullptr, w, bias, lin, g, vec, stream)) return rc;
+    return postop_pass(d->dtype, false, *post, d->batch, d->out_spatial, 4 * d->fq, lin, nullptr, y, nullptr, stream);
 }
 
 int conv_bwd_data_impl(const qk_conv_desc_t *d, const void *dy, const void *y, const float *w, void *dx,
                        void *ws, size_t wsb, hipStream_t stream, const void *dx_mask = nullptr,
                        const PostOp *post = nullptr, float *dalpha = nullptr)
 {
-    // post != NULL: dx_mask holds the PRE-activation of x (x = post(x_pre)); dx returns d loss / d x_pre
+    // post != NULL: dx_mask holds the PRE-activation of x (x = post(x_pre); kind 2: x itself); dx returns d loss / d x_pre
     const bool with_post = post && post->kind;
     if (!dy || !w || !dx) { set_error("dy/w/dx must not be NULL"); return QK_ERR_INVALID_ARG; }
     const bool mask = d->activation == QK_ACT_RELU;
@@ -548,7 +557,7 @@ int qk_conv_fwd_post(const qk_conv_desc_t *desc, const qk_postop_t *post, const 
                      const float *bias, void *pre, void *y, void *workspace, size_t workspace_bytes, void *stream)
 {
     if (int rc = validate(desc, false)) return rc;
-    if (!post || !pre) { set_error("qk_conv_fwd_post: post / pre must not be NULL"); return QK_ERR_INVALID_ARG; }
+    if (!post || (!pre && post->alpha)) { set_error("qk_conv_fwd_post: post must not be NULL, pre only for a relu post-op (alpha == NULL)"); return QK_ERR_INVALID_ARG; }
     if (desc->activation != QK_ACT_LINEAR) { set_error("qk_conv_fwd_post: the convolution must be LINEAR (the post-op is the activation)"); return QK_ERR_INVALID_ARG; }
     PostOp p;
     if (int rc = to_postop(post, desc->rank, desc->out_spatial, &p)) return rc;
@@ -556,24 +565,28 @@ int qk_conv_fwd_post(const qk_conv_desc_t *desc, const qk_postop_t *post, const 
 }
 
 int qk_conv_bwd_post(const qk_conv_desc_t *desc, const void *x, const void *dy, const float *w, void *dx, float *dw,
-                     float *dbias, const qk_postop_t *post_x, const void *x_pre, float *dalpha_x, void *workspace,
-                     size_t workspace_bytes, void *stream)
+                     float *dbias, const qk_postop_t *post_x, const void *x_pre, float *dalpha_x, int32_t flags,
+                     void *workspace, size_t workspace_bytes, void *stream)
 {
     if (int rc = validate(desc, false)) return rc;
-    if (!dx || !post_x || !x_pre || !dalpha_x) { set_error("qk_conv_bwd_post: dx / post_x / x_pre / dalpha_x must not be NULL"); return QK_ERR_INVALID_ARG; }
+    if (!dx || !post_x) { set_error("qk_conv_bwd_post: dx / post_x must not be NULL"); return QK_ERR_INVALID_ARG; }
+    if (post_x->alpha && (!x_pre || !dalpha_x)) { set_error("qk_conv_bwd_post: a PReLU post-op needs x_pre and dalpha_x"); return QK_ERR_INVALID_ARG; }
+    if (flags & ~QK_BWD_ACCUMULATE) { set_error("qk_conv_bwd_post: only QK_BWD_ACCUMULATE is a valid flag here (0x%x)", flags); return QK_ERR_INVALID_ARG; }
     if (desc->activation != QK_ACT_LINEAR) { set_error("qk_conv_bwd_post: the layer must be LINEAR"); return QK_ERR_INVALID_ARG; }
     PostOp p;
     if (int rc = to_postop(post_x, desc->rank, desc->in_spatial, &p)) return rc;
     const size_t bd = ws_bytes_impl(desc, QK_OP_BWD_DATA);
     if (bd && (!workspace || workspace_bytes < bd)) { set_error("bwd needs %zu workspace bytes, got %zu", bd, workspace_bytes); return QK_ERR_WORKSPACE; }
-    if (int rc = conv_bwd_weight_impl(desc, x, dy, nullptr, dw, dbias, nullptr, (hipStream_t)stream)) return check_launch(rc, "qk_conv_bwd_post");
-    return check_launch(conv_bwd_data_impl(desc, dy, nullptr, w, dx, workspace, bd, (hipStream_t)stream, x_pre, &p, dalpha_x), "qk_conv_bwd_post");
+    if (int rc = conv_bwd_weight_impl(desc, x, dy, nullptr, dw, dbias, nullptr, (hipStream_t)stream, (flags & QK_BWD_ACCUMULATE) != 0)) return check_launch(rc, "qk_conv_bwd_post");
+    // relu post-op: x = drop(relu(x_pre)) is its own mask (x > 0 <=> x_pre > 0 and kept)
+    const void *mask_src = p.kind == 2 ? x : x_pre;
+    return check_launch(conv_bwd_data_impl(desc, dy, nullptr, w, dx, workspace, bd, (hipStream_t)stream, mask_src, &p, p.kind == 2 ? nullptr : dalpha_x), "qk_conv_bwd_post");
 }
 
 static int postop_entry(const qk_conv_desc_t *t, const qk_postop_t *post, bool backward, const void *pre, const void *dy,
                         void *out, float *dalpha, void *stream)
 {
-    if (!t || !post || !pre || !out || (backward && (!dy || !dalpha))) { set_error("post-op: NULL argument"); return QK_ERR_INVALID_ARG; }
+    if (!t || !post || !pre || !out || (backward && (!dy || (!dalpha && post->alpha)))) { set_error("post-op: NULL argument"); return QK_ERR_INVALID_ARG; }
     if (t->rank < 0 || t->rank > 3 || t->batch <= 0 || t->fq <= 0) { set_error("post-op: bad tensor description"); return QK_ERR_INVALID_ARG; }
     int32_t sp[3] = {1, 1, 1};
     for (int i = 0; i < t->rank; ++i) { if (t->out_spatial[i] <= 0) { set_error("post-op: bad extent"); return QK_ERR_INVALID_ARG; } sp[i] = t->out_spatial[i]; }
@@ -696,6 +709,9 @@ static bool conv1_pool_ok(const qk_conv_desc_t *d, int32_t pool, int act = QK_AC
            d->kernel[0] == 3 && d->kernel[1] == 5 && d->stride[0] == 1 && d->stride[1] == 1 && d->dilation[0] == 1 &&
            d->dilation[1] == 1 && d->pad_lo[0] == 1 && d->pad_lo[1] == 2 && d->out_spatial[0] == d->in_spatial[0] &&
            d->out_spatial[1] == d->in_spatial[1] && d->activation == act && d->conj == 0 && d->fq % 32 == 0 && pool == 3 &&
+           // the kernel's windows are rows [3o, 3o + 2]: TensorFlow's 'same' pooling (window = stride = 3) pads one row
+           // on the LOW side when H % 3 == 1 (total pad 2 -> 1 + 1), so those heights are not this kernel's
+           d->in_spatial[0] % 3 != 1 &&
            (long long)d->batch * ((d->in_spatial[0] + 2) / 3) * d->in_spatial[1] * 4 * d->fq < INT_MAX;
 }
 
@@ -856,7 +872,7 @@ int qk_adam_step(float *param, const float *grad, float *m, float *v, size_t n, 
 {
     if (!param || !grad || !m || !v) { set_error("adam: NULL buffer"); return QK_ERR_INVALID_ARG; }
     if (step < 1) { set_error("adam: step must be >= 1"); return QK_ERR_INVALID_ARG; }
-    return check_launch(launch_adam(param, const_cast<float *>(grad), m, v, n, lr, beta1, beta2, eps, step, grad_scale, false, (hipStream_t)stream), "qk_adam_step");
+    return check_launch(launch_adam(param, const_cast<float *>(grad), m, v, nullptr, n, lr, beta1, beta2, eps, step, grad_scale, false, (hipStream_t)stream), "qk_adam_step");
 }
 
 int qk_adam_step_zero_grad(float *param, float *grad, float *m, float *v, size_t n, float lr, float beta1,
@@ -864,7 +880,15 @@ int qk_adam_step_zero_grad(float *param, float *grad, float *m, float *v, size_t
 {
     if (!param || !grad || !m || !v) { set_error("adam: NULL buffer"); return QK_ERR_INVALID_ARG; }
     if (step < 1) { set_error("adam: step must be >= 1"); return QK_ERR_INVALID_ARG; }
-    return check_launch(launch_adam(param, grad, m, v, n, lr, beta1, beta2, eps, step, grad_scale, true, (hipStream_t)stream), "qk_adam_step_zero_grad");
+    return check_launch(launch_adam(param, grad, m, v, nullptr, n, lr, beta1, beta2, eps, step, grad_scale, true, (hipStream_t)stream), "qk_adam_step_zero_grad");
+}
+
+int qk_adam_step_l2(float *param, float *grad, float *m, float *v, const float *decay, size_t n, float lr, float beta1,
+                    float beta2, float eps, int32_t step, float grad_scale, int32_t zero_grad, void *stream)
+{
+    if (!param || !grad || !m || !v) { set_error("adam: NULL buffer"); return QK_ERR_INVALID_ARG; }
+    if (step < 1) { set_error("adam: step must be >= 1"); return QK_ERR_INVALID_ARG; }
+    return check_launch(launch_adam(param, grad, m, v, decay, n, lr, beta1, beta2, eps, step, grad_scale, zero_grad != 0, (hipStream_t)stream), "qk_adam_step_l2");
 }
 
 }  // extern "C"

@@ -6,15 +6,18 @@ namespace qk {
 namespace {
 
 // Keras-2 Adam (keras/optimizers.py Adam.get_updates), the optimiser of working_example.py:106.
-template <bool ZERO>
+// DECAY: the l2 kernel regularisers of the model (interspeech_model.py:63,68,173: loss += l2 * sum w^2) enter as
+// g += decay[i] * p[i] with decay = 2 * l2 on regularised parameters, 0 elsewhere -- the term Keras' autodiff adds.
+template <bool ZERO, bool DECAY>
 __global__ void __launch_bounds__(256)
 k_adam(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m,
-       float *__restrict__ v, size_t n, float lr_t, float b1, float b2, float eps, float gscale)
+       float *__restrict__ v, const float *__restrict__ decay, size_t n, float lr_t, float b1, float b2, float eps, float gscale)
 {
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * 256;
     for (; i < n; i += stride) {
-        const float gi = g[i] * gscale;
+        float gi = g[i] * gscale;
+        if constexpr (DECAY) gi = fmaf(decay[i], p[i], gi);
         const float mi = b1 * m[i] + (1.f - b1) * gi;
         const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
         m[i] = mi;
@@ -185,7 +188,7 @@ k_postop(const T *__restrict__ pre, const T *__restrict__ dy, T *__restrict__ ou
         if (ok) {
             const long long row = u / d.upr;
             if (p.alpha_sel >= 0) key = (int)((row / d.key_div) % d.key_mod);
-            const float alpha = p.alpha[key];
+            const float alpha = p.alpha ? p.alpha[key] : 0.f;
             const long long e0 = u * VEC;
             if constexpr (sizeof(T) == 2) {
                 const uint4 q = *reinterpret_cast<const uint4 *>(pre + e0);
@@ -263,7 +266,7 @@ int launch_fold_taps(int dtype, const void *x, void *xcol, const GemmGeom &g, in
     return hipGetLastError() == hipSuccess ? 0 : QK_ERR_LAUNCH;
 }
 
-int launch_adam(float *p, float *g, float *m, float *v, size_t n, float lr, float b1,
+int launch_adam(float *p, float *g, float *m, float *v, const float *decay, size_t n, float lr, float b1,
                 float b2, float eps, int step, float gscale, bool zero_grad, hipStream_t stream)
 {
     if (n == 0) return 0;
@@ -271,10 +274,10 @@ int launch_adam(float *p, float *g, float *m, float *v, size_t n, float lr, floa
     const float lr_t = (float)((double)lr * sqrt(1.0 - pow((double)b2, t)) / (1.0 - pow((double)b1, t)));
     size_t blocks = (n + 255) / 256;
     if (blocks > 2048) blocks = 2048;
-    if (zero_grad)
-        hipLaunchKernelGGL(k_adam<true>, dim3((unsigned)blocks), dim3(256), 0, stream, p, g, m, v, n, lr_t, b1, b2, eps, gscale);
-    else
-        hipLaunchKernelGGL(k_adam<false>, dim3((unsigned)blocks), dim3(256), 0, stream, p, g, m, v, n, lr_t, b1, b2, eps, gscale);
+#define QK_ADAM(Z, D) hipLaunchKernelGGL((k_adam<Z, D>), dim3((unsigned)blocks), dim3(256), 0, stream, p, g, m, v, decay, n, lr_t, b1, b2, eps, gscale)
+    if (zero_grad) { if (decay) QK_ADAM(true, true); else QK_ADAM(true, false); }
+    else { if (decay) QK_ADAM(false, true); else QK_ADAM(false, false); }
+#undef QK_ADAM
     return hipGetLastError() == hipSuccess ? 0 : QK_ERR_LAUNCH;
 }
 

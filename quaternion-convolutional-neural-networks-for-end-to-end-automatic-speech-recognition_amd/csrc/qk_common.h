@@ -35,7 +35,8 @@ constexpr unsigned kSignConj = 0x284Eu;   // transpose: (0,1) (0,2) (0,3) (1,2) 
 // ---------------------------------------------------------------------------------------
 // PReLU (+ Dropout) attached to a layer output, see qk_postop.h and qk_postop_t (include/qk.h)
 struct PostOp {
-    int kind;               // 0: none, 1: y = drop(prelu(pre))
+    int kind;               // 0: none, 1: y = drop(prelu(pre)) (pre and y are both kept), 2: y = drop(relu(pre)): alpha is
+                            // NULL, only y is written and the backward needs only y (y > 0 <=> pre > 0 and kept)
     int alpha_sel;          // -1: scalar alpha[0]; 0 / 1 / 2: alpha indexed by the row's o0 / o1 / o2 (the kernel's axes)
     int alpha_len;          // entries of alpha (<= 256 on the fused paths)
     const float *alpha;     // device, float32
@@ -73,7 +74,8 @@ struct GemmGeom {
     // backward-data: ep_mask holds the pre-activation of the tensor whose gradient is produced, out = d pre,
     // d alpha is accumulated into dalpha
     PostOp post;
-    void *pre_out;
+    int post_fwd;                        // the post-op is applied to THIS kernel's output (forward); else (ep_mask set) its derivative
+    void *pre_out;                       // forward, kind 1: where the pre-activation goes (kind 2 writes y only)
     float *dalpha;
     int b_wp, b_nlines, b_cshift, b_rev;
     // k_hgemm16 row order: 0 = rows run over (n, o0, o1, o2); batch = rows run over (o0, n, o1, o2) (dv_*[2] then divides
@@ -232,7 +234,7 @@ int launch_conv1_pool(int dtype, bool backward, const void *x, const float *w, c
                       const float *alpha = nullptr, int alpha_len = 0, const void *pre = nullptr, float *dalpha = nullptr);
 int launch_postop(int dtype, bool backward, const void *pre, const void *dy, void *out, float *dalpha, const PostOp &p,
                   long long rows, int channels, int key_div, int key_mod, hipStream_t stream);
-int launch_adam(float *p, float *g, float *m, float *v, size_t n, float lr, float b1,
+int launch_adam(float *p, float *g, float *m, float *v, const float *decay, size_t n, float lr, float b1,
                 float b2, float eps, int step, float gscale, bool zero_grad, hipStream_t stream);
 
 void set_error(const char *fmt, ...);

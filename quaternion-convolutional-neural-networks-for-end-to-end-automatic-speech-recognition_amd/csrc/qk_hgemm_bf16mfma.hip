@@ -382,7 +382,7 @@ k_hgemm16(const T *__restrict__ in, const T *__restrict__ mask, const uint4 *__r
     for (int b = 0; b < 4; ++b) bia4[b] = g.has_bias ? bias[b * g.J + j0 + wn * 32 + lr] : 0.f;
     // post-op (PReLU / dropout, qk_postop.h): forward writes pre and y; backward-data applies the derivative
     const bool post_on = g.post.kind != 0;
-    const bool post_bwd = post_on && g.ep_mask != nullptr, post_fwd = post_on && g.pre_out != nullptr;
+    const bool post_bwd = post_on && g.ep_mask != nullptr, post_fwd = post_on && g.post_fwd != 0;
     float *aslab = reinterpret_cast<float *>(reinterpret_cast<char *>(lds) + 32768);
     if (post_bwd && g.dalpha) {
         if (tid < 256) aslab[tid] = 0.f;
@@ -401,7 +401,7 @@ k_hgemm16(const T *__restrict__ in, const T *__restrict__ mask, const uint4 *__r
                     const int o0 = rp.o0, o1 = rp.o1, o2 = rp.o2;
                     a_key[pass] = g.post.alpha_sel == 0 ? o0 : g.post.alpha_sel == 1 ? o1 : o2;
                 }
-                a_val[pass] = g.post.alpha[a_key[pass]];
+                a_val[pass] = g.post.alpha ? g.post.alpha[a_key[pass]] : 0.f;
             }
         }
 #pragma unroll
@@ -437,7 +437,7 @@ k_hgemm16(const T *__restrict__ in, const T *__restrict__ mask, const uint4 *__r
                         else v = mask8(v, mk);
                     }
                     if (post_fwd) {
-                        *reinterpret_cast<uint4 *>(static_cast<T *>(g.pre_out) + o) = v;
+                        if (g.pre_out) *reinterpret_cast<uint4 *>(static_cast<T *>(g.pre_out) + o) = v;
                         v = post_fwd8<T>(v, a_val[pass], (unsigned)o, g.post);
                     }
                     *reinterpret_cast<uint4 *>(out + o) = v;
@@ -848,7 +848,7 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
     float a_val = 0.f, dal = 0.f;
     float *aslab = reinterpret_cast<float *>(reinterpret_cast<char *>(lds) + 32768);   // 256 d-alpha sums (backward post-op)
     float *bias_s = reinterpret_cast<float *>(reinterpret_cast<char *>(lds) + 34816);  // this tile's 4 x BF bias values
-    if ((EPM || POSTF) && post_on) a_val = g.post.alpha[a_key];
+    if ((EPM || POSTF) && post_on && g.post.alpha) a_val = g.post.alpha[a_key];
     // (the K loop's last barrier is behind every wave: the tile buffers are free)
     if (g.has_bias && tid < 4 * BF) bias_s[tid] = bias[(tid / BF) * g.J + j0 + tid % BF];
     if (EPM && post_on && g.dalpha && tid < 256) aslab[tid] = 0.f;
@@ -897,7 +897,7 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
                 }
                 if constexpr (POSTF) {
                     if (post_on) {
-                        *reinterpret_cast<uint4 *>(static_cast<T *>(g.pre_out) + o) = v;
+                        if (g.pre_out) *reinterpret_cast<uint4 *>(static_cast<T *>(g.pre_out) + o) = v;
                         v = post_fwd8<T>(v, a_val, (unsigned)o, g.post);
                     }
                 }
@@ -1022,7 +1022,7 @@ k_hgemm16_point(const T *__restrict__ in, const uint4 *__restrict__ wq, const fl
             if (post_on) {
                 const int o1 = fastdiv(sp, g.dv_mul[0], g.dv_shr[0]);
                 a_key[pass] = g.post.alpha_sel < 0 ? 0 : g.post.alpha_sel == 0 ? tap : g.post.alpha_sel == 1 ? o1 : sp - o1 * g.osp[2];
-                a_val[pass] = g.post.alpha[a_key[pass]];
+                a_val[pass] = g.post.alpha ? g.post.alpha[a_key[pass]] : 0.f;
             }
         }
         // next unit's rows (same rows when only the tap changes); past the range: nothing is fetched
@@ -1107,7 +1107,7 @@ inline bool point_geom(const GemmGeom &g, GemmGeom *o)
 {
     if (g.has_mask || (g.Q != 32 && g.Q != 64) || g.J % 64 != 0) return false;
     if (g.post.kind != 0) {       // only the backward form (derivative in the epilogue, pre-activation in ep_mask)
-        if (!g.ep_mask || g.pre_out || g.post.alpha_len > 256 || (g.taps == 1 && g.post.alpha_sel >= 0)) return false;
+        if (!g.ep_mask || g.post_fwd || g.post.alpha_len > 256 || (g.taps == 1 && g.post.alpha_sel >= 0)) return false;
     }
     *o = g;
     if (g.taps == 1) {
@@ -1158,7 +1158,7 @@ int run16_band(const T *in, const uint4 *wq, const T *zero_line, const float *bi
     // EPM (epilogue mask, QK_BWD_MASK_DX) is its own instantiation: its eight prefetched mask pieces cost 32 VGPRs
     // ... and so is POSTF (forward post-op: PReLU / dropout, pre-activation written beside y)
 #define QK_GO(C, E, P) hipLaunchKernelGGL((k_hgemm16_band<T, WM, WN, KIN, C, TRIM, E, P>), grid, dim3(NTHR), 0, stream, in, wq, zero_line, bias, out, g)
-    const bool epm = g.ep_mask != nullptr, pf = g.post.kind != 0 && g.pre_out != nullptr;
+    const bool epm = g.ep_mask != nullptr, pf = g.post.kind != 0 && g.post_fwd != 0;
     if (g.sign_tbl != kSignConj) return QK_ERR_LAUNCH;                 // go16 folds the plain table into the kernel
     if constexpr (!TRIM && WM * WN == 4) {
         if (debug_flags() & kDbgBand16Dma) {                           // LDS-DMA staging (experimental, A/B switch)

@@ -3,6 +3,10 @@
 //
 //     y = drop(prelu(pre)),   prelu(v) = v > 0 ? v : alpha * v,   drop(v) = keep ? v / (1 - rate) : 0
 //
+// and, for the `aact == 'none'` setting of the same model (relu layers, `O = Dropout(d.dropout)(O)` behind every body
+// convolution, :117-121,131-137), kind 2:  y = drop(relu(pre))  -- alpha == 0 by definition, ONE output tensor, and
+// the backward reads nothing but y:  d pre = dy / (1 - rate) where y > 0  (y > 0  <=>  pre > 0 and kept).
+//
 // fused into the epilogue of the kernel that produces `pre` (forward: both `pre` and `y` are written) and, in the
 // backward, into the epilogue of the NEXT layer's backward-data kernel, whose output IS the gradient w.r.t. y:
 //
@@ -87,9 +91,25 @@ __device__ __forceinline__ uint4 post_fwd8(const uint4 &pre, float alpha, unsign
     return make_uint4(out[0], out[1], out[2], out[3]);
 }
 
+// kind 2 (y = drop(relu(pre)), `y` in the mask operand): d pre = dy * scale where y > 0 -- no hash, no pre
+template <typename T>
+__device__ __forceinline__ uint4 post_bwd8_relu(const uint4 &dy, const uint4 &y, float scale)
+{
+    unsigned g[4] = {dy.x, dy.y, dy.z, dy.w}, q[4] = {y.x, y.y, y.z, y.w}, out[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float ga, gb, ya, yb;
+        unpack2<T>(g[k], ga, gb);
+        unpack2<T>(q[k], ya, yb);
+        out[k] = repack2(T(), ya > 0.f ? ga * scale : 0.f, yb > 0.f ? gb * scale : 0.f);
+    }
+    return make_uint4(out[0], out[1], out[2], out[3]);
+}
+
 template <typename T>
 __device__ __forceinline__ uint4 post_bwd8(const uint4 &dy, const uint4 &pre, float alpha, unsigned idx, const PostOp &p, float &dal)
 {
+    if (p.kind == 2) return post_bwd8_relu<T>(dy, pre, p.drop_scale);
     unsigned g[4] = {dy.x, dy.y, dy.z, dy.w}, q[4] = {pre.x, pre.y, pre.z, pre.w}, out[4], rb[2] = {0u, 0u};
     if (p.drop_thr) drop_bits8(idx >> 3, p.drop_seed, rb[0], rb[1]);
 #pragma unroll

@@ -15,6 +15,10 @@ step is ONE sum all-reduce of the flat fp32 compact-gradient buffer:
   * `torch.distributed` backend "nccl" IS RCCL on ROCm; "gloo" is used by the CPU tests.
 """
 import os
+import socket
+import subprocess
+import sys
+import time
 
 import torch
 import torch.distributed as dist
@@ -23,6 +27,57 @@ import torch.distributed as dist
 # the collectives (a one-rank RCCL communicator).  That is how the 1-GPU test box exercises the exact
 # init / all-reduce / barrier calls the 8-GPU run makes.
 _FORCE = bool(os.environ.get('QK_DP_FORCE_COLLECTIVES'))
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(nproc, argv, env=None, timeout=None, quiet_ranks=True):
+    """One process per GPU on this node: start `nproc` copies of the command `argv` with the environment
+    torch.distributed.run would give them (RANK, LOCAL_RANK, WORLD_SIZE, LOCAL_WORLD_SIZE, MASTER_ADDR = 127.0.0.1,
+    a free MASTER_PORT) and wait for all of them.  This is what `python bench.py --gpus N` does when it is NOT already
+    running under a launcher.  Rank 0 inherits stdout (it prints the result line); the other ranks' stdout is dropped
+    when `quiet_ranks`; stderr always passes through.  If a rank fails, the others are terminated (by their own
+    PIDs) and its exit code is returned; 0 when every rank exited cleanly."""
+    if nproc < 1:
+        raise ValueError('nproc must be >= 1')
+    base = dict(os.environ if env is None else env)
+    base.update(WORLD_SIZE=str(nproc), LOCAL_WORLD_SIZE=str(nproc), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(free_port()))
+    base.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC: RCCL's intra-node transport needs it here
+    procs = []
+    for r in range(nproc):
+        e = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        out = subprocess.DEVNULL if (r > 0 and quiet_ranks) else None
+        procs.append(subprocess.Popen(list(argv), env=e, stdout=out))
+    t0, rc = time.time(), 0
+    live = list(procs)
+    while live:
+        for pr in list(live):
+            code = pr.poll()
+            if code is None:
+                continue
+            live.remove(pr)
+            if code != 0 and rc == 0:
+                rc = code
+        if rc != 0 or (timeout is not None and time.time() - t0 > timeout):
+            for pr in live:                    # a rank died (or time is up): the others would hang in a collective
+                pr.terminate()
+            for pr in live:
+                try:
+                    pr.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    pr.kill()
+            if rc == 0:
+                rc = 124
+            break
+        if live:
+            time.sleep(0.05)
+    return rc
 
 
 def init_from_env(backend=None):
@@ -52,10 +107,18 @@ class FlatParams(object):
     After construction every parameter's `.data` is a view into `self.param` and `.grad` a view
     into `self.grad`, so an optimizer step / all-reduce touches two tensors, not 2*len(params)."""
 
-    def __init__(self, params):
+    def __init__(self, params, direct='auto'):
+        """direct: which parameters the engine's backward kernels may write their gradient into WITHOUT going through
+        autograd's AccumulateGrad (functional._direct_grad).  That is only sound for a parameter whose gradient has no
+        second source in the graph: 'auto' (default) excludes every parameter that carries a Keras regulariser
+        (`p._qk_regularized`, set by keras_like.Layer.add_weight -- `model.regularization_loss()` differentiates
+        through autograd and would add to the same buffer later); True takes all (the caller folds the regulariser
+        into the optimiser step instead: `l2_decay()` + functional.adam_step(decay=)); False none."""
         self.params = [p for p in params]
         if not self.params:
             raise ValueError('no parameters')
+        if direct not in ('auto', True, False):
+            raise ValueError("direct must be 'auto', True or False")
         dev = self.params[0].device
         sizes = [p.numel() for p in self.params]
         # 64-element (256 B) alignment keeps every view usable for 16-byte vector access
@@ -74,7 +137,7 @@ class FlatParams(object):
                 p.grad = self.grad[o:o + n].view(p.shape)
                 # the engine's backward nodes add their kernel / bias gradients straight into these views (no
                 # temporary, no memset, no AccumulateGrad add): functional._direct_grad
-                p._qk_direct_grad = True
+                p._qk_direct_grad = bool(direct is True or (direct == 'auto' and not getattr(p, '_qk_regularized', None)))
 
     def grad_view(self, i):
         p, o = self.params[i], self.offsets[i]
@@ -82,6 +145,25 @@ class FlatParams(object):
 
     def zero_grad(self):
         self.grad.zero_()
+
+    def l2_decay(self):
+        """Per-element coefficient c with  d(sum of the parameters' l2 regularisers)/dw = c * w : 2 * l2 on the
+        elements of a parameter created with `kernel_regularizer=l2(...)` (interspeech_model.py:63,68,173), 0 elsewhere.
+        functional.adam_step(decay=...) adds c * w to the (averaged) gradient inside the fused Adam kernel, which is
+        what Keras' loss term contributes -- without a second gradient source in the autograd graph.  Returns None
+        when no parameter is regularised.  l1 terms cannot be folded this way and raise."""
+        dec = torch.zeros_like(self.param)
+        any_reg = False
+        for p, o in zip(self.params, self.offsets):
+            reg = getattr(p, '_qk_regularized', None)
+            if reg is None:
+                continue
+            if getattr(reg, 'l1', 0.0) or not hasattr(reg, 'l2'):
+                raise ValueError('only l2 regularisers fold into the optimiser step, got %r' % (reg,))
+            if reg.l2:
+                dec[o:o + p.numel()] = 2.0 * reg.l2
+                any_reg = True
+        return dec if any_reg else None
 
 
 def broadcast_params(flat, src=0, group=None):
@@ -127,9 +209,11 @@ class BucketedAllReduce(object):
         if cur:
             self._close(lo, flat.numel, cur)
         self.pending = list(self.sizes)
+        self.fired = set()                # id(param) of the parameters that reported their gradient this step
         self.works = []
         self.launch_order = []
         self.handles = []
+        self.enabled = True               # False: hooks count but nothing is launched (bench: exposed-collective time)
         if self.active:
             for p in flat.params:
                 if p.requires_grad:
@@ -146,7 +230,20 @@ class BucketedAllReduce(object):
         self.sizes.append(n)
 
     def _hook(self, p):
+        """One event per parameter and backward pass: its gradient is complete.  autograd's post-accumulate hook
+        satisfies that by construction (all contributions are summed before AccumulateGrad runs); the engine's direct
+        writes (functional._grad_ready) satisfy it only when nothing else in the graph produces a gradient for the
+        same parameter.  A second event means exactly that -- a regulariser differentiated through autograd, a tied
+        weight -- and the bucket may already be on the wire with a partial sum: refuse loudly."""
         b = self.bucket_of[id(p)]
+        if id(p) in self.fired:
+            raise RuntimeError(
+                'BucketedAllReduce: a parameter of bucket %d reported its gradient twice in one backward pass (%s). '
+                'It is written directly by the backward kernels AND receives an autograd gradient (regulariser term, '
+                'tied weight): build FlatParams(direct="auto"/False) for such parameters, or fold the regulariser into '
+                'the optimiser step (FlatParams.l2_decay + adam_step(decay=)).'
+                % (b, 'its bucket was already launched' if b in self.launch_order else 'bucket not launched yet'))
+        self.fired.add(id(p))
         self.pending[b] -= 1
         if self.pending[b] == 0:
             self._launch(b)
@@ -154,6 +251,8 @@ class BucketedAllReduce(object):
     def _launch(self, b):
         lo, hi = self.buckets[b]
         self.launch_order.append(b)
+        if not self.enabled:
+            return
         self.works.append(dist.all_reduce(self.flat.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self):
@@ -167,6 +266,10 @@ class BucketedAllReduce(object):
             w.wait()
         self.works, self.launch_order = [], []
         self.pending = list(self.sizes)
+        self.fired = set()
+
+    def bucket_bytes(self):
+        return [4 * (hi - lo) for lo, hi in self.buckets]
 
     def remove(self):
         for h in self.handles:

@@ -123,8 +123,9 @@ class _Call(object):
 
 
     def fwd_post(self, x, w, bias, post):
-        """(pre, y) = qk_conv_fwd_post: the LINEAR convolution and post(pre) (PReLU / dropout) from one launch."""
-        pre = torch.empty(self.y_shape, dtype=x.dtype, device=x.device)
+        """(pre, y) = qk_conv_fwd_post: the LINEAR convolution and post(pre) (PReLU / dropout) from one launch.  The relu
+        form of the post-op (post.alpha is None) writes y only: pre is None."""
+        pre = torch.empty(self.y_shape, dtype=x.dtype, device=x.device) if post.alpha is not None else None
         y = torch.empty(self.y_shape, dtype=x.dtype, device=x.device)
         ws, n = self._ws(L.QK_OP_FWD, x)
         with _on_device(x.device):
@@ -133,18 +134,23 @@ class _Call(object):
         L.check(rc, 'qk_conv_fwd_post')
         return pre, y
 
-    def bwd_post(self, x, dy, w, has_bias, post_x, x_pre, dalpha_x):
+    def bwd_post(self, x, dy, w, has_bias, post_x, x_pre, dalpha_x, direct=None):
         """Fused backward of a LINEAR layer whose input x = post_x(x_pre): returns (d x_pre, dw, db) and accumulates
-        the slope gradient of post_x into dalpha_x (qk_conv_bwd_post)."""
+        the slope gradient of post_x into dalpha_x (qk_conv_bwd_post).  direct = (dw, db) buffers to ADD into
+        (QK_BWD_ACCUMULATE; the returned dw / db are then None).  Relu form of post_x: x_pre / dalpha_x are None."""
         dx = torch.empty(self.x_shape, dtype=dy.dtype, device=dy.device)
-        dw = torch.empty(self.w_shape, dtype=torch.float32, device=x.device)
-        db = torch.empty((self.w_shape[-1],), dtype=torch.float32, device=x.device) if has_bias else None
+        if direct is not None:
+            dw, db = direct
+        else:
+            dw = torch.empty(self.w_shape, dtype=torch.float32, device=x.device)
+            db = torch.empty((self.w_shape[-1],), dtype=torch.float32, device=x.device) if has_bias else None
         ws, n = self._ws(L.QK_OP_BWD, x)
         with _on_device(x.device):
             rc = L.lib().qk_conv_bwd_post(ctypes.byref(self.desc), _ptr(x), _ptr(dy), _ptr(w), _ptr(dx), _ptr(dw), _ptr(db),
-                                          ctypes.byref(post_x.struct), _ptr(x_pre), _ptr(dalpha_x), _ptr(ws), n, _stream(x))
+                                          ctypes.byref(post_x.struct), _ptr(x_pre), _ptr(dalpha_x),
+                                          L.QK_BWD_ACCUMULATE if direct is not None else 0, _ptr(ws), n, _stream(x))
         L.check(rc, 'qk_conv_bwd_post')
-        return dx, dw, db
+        return (dx, None, None) if direct is not None else (dx, dw, db)
 
     def bwd(self, x, dy, y, w, has_bias, out=None, flags=0):
         """Fused backward (qk_*_bwd, or qk_*_bwd_chain with L.QK_BWD_* flags): returns (dx, dw, db)."""
@@ -171,14 +177,20 @@ class _Call(object):
 class PostOp(object):
     """PReLU (+ Dropout) behind a quaternion layer (include/qk.h: qk_postop_t).  `alpha`: float32 device tensor, one
     slope (alpha_axis = -1) or one per position along spatial axis `alpha_axis` of the channels_last activation;
-    `rate`: dropout rate (0 = off); `seed`: 32-bit seed of the counter-based mask (a new one every step)."""
+    `rate`: dropout rate (0 = off); `seed`: 32-bit seed of the counter-based mask (a new one every step).
+    alpha=None is the relu form y = dropout(relu(pre)): one output tensor, the backward reads only y.
+    The rate the kernels apply is round(rate * 256) / 256 (8 random bits per element): `applied_rate`."""
 
     def __init__(self, alpha, alpha_axis=-1, rate=0.0, seed=0):
-        if alpha.dtype != torch.float32 or not alpha.is_cuda:
+        if alpha is not None and (alpha.dtype != torch.float32 or not alpha.is_cuda):
             raise TypeError('PReLU slopes must be float32 device tensors')
+        if not 0.0 <= float(rate) < 1.0:
+            raise ValueError('dropout rate must be in [0, 1), got %r' % (rate,))
         self.alpha, self.alpha_axis, self.rate, self.seed = alpha, int(alpha_axis), float(rate), int(seed) & 0xffffffff
-        self.flat = alpha.detach().reshape(-1).contiguous()
-        self.struct = L.PostOp(self.alpha_axis, self.flat.numel(), self.flat.data_ptr(), self.rate, self.seed)
+        self.applied_rate = min(255, int(self.rate * 256.0 + 0.5)) / 256.0
+        self.flat = alpha.detach().reshape(-1).contiguous() if alpha is not None else None
+        self.struct = L.PostOp(self.alpha_axis if alpha is not None else -1, self.flat.numel() if alpha is not None else 0,
+                               self.flat.data_ptr() if alpha is not None else None, self.rate, self.seed)
 
 
 def _tensor_desc(t):
@@ -200,7 +212,8 @@ def postop_fwd(pre, post):
 
 
 def postop_bwd(pre, dy, post, dalpha):
-    """d pre (returned) and the slope gradient (accumulated into the float32 buffer `dalpha`)."""
+    """d pre (returned) and the slope gradient (accumulated into the float32 buffer `dalpha`).  Relu form of the
+    post-op: pass the forward OUTPUT y as `pre`, dalpha=None."""
     dpre = torch.empty_like(pre)
     d = _tensor_desc(pre)
     with _on_device(pre.device):
@@ -214,13 +227,16 @@ class _PostOpFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pre, alpha, post):
         ctx.post = post
-        ctx.save_for_backward(pre)
-        return postop_fwd(pre, post)
+        y = postop_fwd(pre, post)
+        ctx.save_for_backward(pre if post.alpha is not None else y)      # relu form: the output is its own mask
+        return y
 
     @staticmethod
     def backward(ctx, dy):
         pre, = ctx.saved_tensors
         post = ctx.post
+        if post.alpha is None:
+            return postop_bwd(pre, dy.contiguous(), post, None), None, None
         dalpha = torch.zeros(post.flat.numel(), dtype=torch.float32, device=pre.device)
         dpre = postop_bwd(pre, dy.contiguous(), post, dalpha)
         return dpre, dalpha.reshape(post.alpha.shape), None
@@ -235,6 +251,11 @@ def prelu_dropout(x, alpha, alpha_axis=-1, rate=0.0, seed=0):
     if xc.shape[-1] % (4 if xc.dtype == torch.float32 else 8) or xc.dim() < 2 or xc.dim() > 5:
         raise ValueError('prelu_dropout: unsupported shape %s' % (tuple(x.shape),))
     return _PostOpFn.apply(xc, alpha, PostOp(alpha, alpha_axis, rate, seed))
+
+
+def relu_dropout(x, rate=0.0, seed=0):
+    """y = dropout(relu(x)) in one pass (the relu form of prelu_dropout: no slopes; the backward reads y only)."""
+    return prelu_dropout(x, None, -1, rate, seed)
 
 
 def _direct_grad(w, b, want_w, want_b):
@@ -470,16 +491,25 @@ def quaternion_dense(x, kernel, bias=None, activation=None):
     return _HamiltonFn.apply(xp, kernel.contiguous(), bias, call)
 
 
-def adam_step(param, grad, m, v, step, lr=0.001, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0, zero_grad=False):
+def adam_step(param, grad, m, v, step, lr=0.001, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0, zero_grad=False,
+              decay=None):
     """Fused Keras-Adam update of a flat float32 buffer (qk_adam_step); zero_grad=True also clears `grad`
-    once it has been consumed (qk_adam_step_zero_grad), ready for accumulating backward calls."""
-    for t in (param, grad, m, v):
+    once it has been consumed (qk_adam_step_zero_grad), ready for accumulating backward calls.
+    decay: per-element coefficients of the l2 kernel regularisers (dp.FlatParams.l2_decay): g += decay * param inside
+    the kernel (qk_adam_step_l2) -- the gradient of the term Keras adds to the loss."""
+    for t in (param, grad, m, v) + ((decay,) if decay is not None else ()):
         if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
             raise RuntimeError('adam_step needs contiguous float32 device buffers')
     n = param.numel()
     with _on_device(param.device):
-        fn = L.lib().qk_adam_step_zero_grad if zero_grad else L.lib().qk_adam_step
-        rc = fn(_ptr(param), _ptr(grad), _ptr(m), _ptr(v), n, lr, beta1, beta2, eps, int(step), grad_scale, _stream(param))
+        if decay is not None:
+            if decay.numel() != n:
+                raise ValueError('decay must have one coefficient per parameter element')
+            rc = L.lib().qk_adam_step_l2(_ptr(param), _ptr(grad), _ptr(m), _ptr(v), _ptr(decay), n, lr, beta1, beta2, eps,
+                                         int(step), grad_scale, int(bool(zero_grad)), _stream(param))
+        else:
+            fn = L.lib().qk_adam_step_zero_grad if zero_grad else L.lib().qk_adam_step
+            rc = fn(_ptr(param), _ptr(grad), _ptr(m), _ptr(v), n, lr, beta1, beta2, eps, int(step), grad_scale, _stream(param))
     L.check(rc, 'qk_adam_step')
 
 
@@ -556,9 +586,20 @@ class _ConvReluPoolFn(torch.autograd.Function):
 def conv_relu_pool_supported(x, kernel, pool):
     """True when relu(QuaternionConv2D(kernel, 'same')(x)) followed by MaxPooling over the first spatial axis (window =
     stride = pool, 'same') can run as the fused first-layer kernels: x a contiguous channels_last (N, H, W, 4) 16-bit
-    device tensor that needs no gradient, kernel (3, 5, 1, 4F) with F % 32 == 0, pool == 3."""
-    return (x.is_cuda and x.dtype in (torch.bfloat16, torch.float16) and x.dim() == 4 and x.shape[-1] == 4 and not x.requires_grad
-            and tuple(kernel.shape[:3]) == (3, 5, 1) and kernel.shape[-1] % 128 == 0 and pool == 3 and x.shape[0] > 0)
+    device tensor that needs no gradient, kernel (3, 5, 1, 4F) with F % 32 == 0, pool == 3, and a height whose
+    TensorFlow 'same' pooling pads on the high side only (H % 3 != 1: the kernel's windows start at row 0).  The
+    answer is the C side's (qk_conv_relu_pool_aux_bytes is non-zero exactly for the geometries it takes), so the
+    two predicates cannot drift apart."""
+    if not (x.is_cuda and x.dtype in (torch.bfloat16, torch.float16) and x.dim() == 4 and x.shape[-1] == 4 and not x.requires_grad
+            and kernel.dim() == 4 and tuple(kernel.shape[:3]) == (3, 5, 1) and kernel.shape[-1] % 4 == 0 and x.shape[0] > 0):
+        return False
+    if tf_pads(x.shape[1], pool, pool, 1, 'same')[0] != 0:
+        return False
+    try:
+        call = conv_call(tuple(x.shape), tuple(kernel.shape), x.dtype, 2, 1, 'same', 'channels_last', 1, 'relu', True, False)
+    except ValueError:
+        return False
+    return int(L.lib().qk_conv_relu_pool_aux_bytes(ctypes.byref(call.desc), pool)) > 0
 
 
 def conv_relu_pool(x, kernel, bias=None, pool=3):
@@ -671,16 +712,20 @@ class _ConvChainFn(torch.autograd.Function):
         g = dy.contiguous()
         dws, dbs, das = [None] * n, [None] * n, [None] * n
         for i, post in enumerate(posts):
-            if post is not None:
+            if post is not None and post.alpha is not None:
                 das[i] = torch.zeros(post.flat.numel(), dtype=torch.float32, device=g.device)
         if posts[n - 1] is not None:                      # the last post-op has no consumer inside the chain
-            g = postop_bwd(pres[n - 1], g, posts[n - 1], das[n - 1])
+            last = posts[n - 1]                           # (relu form: the output y is its own mask)
+            g = postop_bwd(pres[n - 1] if last.alpha is not None else acts[n], g, last, das[n - 1])
         for i in range(n - 1, -1, -1):
-            if i > 0 and posts[i - 1] is not None:
-                g, dws[i], dbs[i] = calls[i].bwd_post(acts[i], g, ws[i], ctx.has_bias[i], posts[i - 1], pres[i - 1], das[i - 1])
-                continue
             pw, pb = ctx.param_refs[0][i], ctx.param_refs[1][i]
             direct = _direct_grad(pw, pb, ctx.needs_input_grad[3 + i], ctx.has_bias[i] and ctx.needs_input_grad[3 + n + i])
+            if i > 0 and posts[i - 1] is not None:
+                g, dws[i], dbs[i] = calls[i].bwd_post(acts[i], g, ws[i], ctx.has_bias[i], posts[i - 1], pres[i - 1], das[i - 1],
+                                                      direct=direct)
+                if direct is not None:
+                    _grad_ready(pw, pb)
+                continue
             if i == 0 and not ctx.needs_input_grad[0]:
                 # the chain's input needs no gradient (a first layer): backward-weight only.  (A relu layer whose dy
                 # arrives masked is masked once more by this call -- idempotent.)
@@ -703,7 +748,7 @@ class _ConvChainFn(torch.autograd.Function):
                 g = dx
             else:
                 g, dws[i], dbs[i] = calls[i].bwd(acts[i], g, acts[i + 1], ws[i], ctx.has_bias[i], flags=flags)
-        das = [None if d is None else d.reshape(p.alpha.shape) for d, p in zip(das, posts)]
+        das = [None if d is None else d.reshape(p.alpha.shape) for d, p in zip(das, posts)]      # (relu form: no slopes)
         return (g, None, None) + tuple(dws) + tuple(dbs) + tuple(das)
 
 
@@ -712,7 +757,8 @@ def quaternion_conv_chain(x, layers):
     `layers`: sequence of (kernel, bias, kwargs) with the keyword arguments of quaternion_conv
     (strides, padding, dilation_rate, activation ('relu' / 'linear' / None), conj) and optionally
     post=dict(alpha=<float32 tensor>, alpha_axis=-1|0|1|2, rate=<dropout rate>, seed=<int>): PReLU (+ dropout) behind
-    a LINEAR layer; x and every layer are channels_last here -- channels_first callers pass the channels-last view
+    a LINEAR layer (alpha=None: relu + dropout, the reference's aact='none' setting -- one output tensor per layer);
+    x and every layer are channels_last here -- channels_first callers pass the channels-last view
     and move the axis back."""
     _require_device(x, 'quaternion_conv_chain')
     xp = x.contiguous()

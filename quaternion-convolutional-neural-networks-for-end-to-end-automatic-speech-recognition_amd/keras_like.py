@@ -289,6 +289,7 @@ class Layer(torch.nn.Module):
         self._weight_names.append(name)
         if regularizer is not None:
             self._regularizers[name] = regularizer
+            p._qk_regularized = regularizer     # dp.FlatParams: this gradient has a second source (or folds into Adam)
         if constraint is not None:
             self._constraints[name] = constraint
         return p

@@ -29,7 +29,7 @@ class TimitQCNN(torch.nn.Module):
                          internal_layout=internal_layout)
         dense_args = dict(activation=act, kernel_regularizer=reg, kernel_initializer='random_uniform',
                           bias_initializer='zeros', use_bias=True)
-        self.aact, self.rate = aact, dropout
+        self.aact, self.rate, self.act = aact, dropout, act
         self.fuse_head = fuse_head          # first TimeDistributed dense as an (F, 1) convolution (no transpose copy)
         self.chain_convs = (chain_convs and internal_layout == 'channels_last'      # body convs as one autograd node
                             and not os.environ.get('QK_NO_CONV_CHAIN'))
@@ -42,7 +42,7 @@ class TimitQCNN(torch.nn.Module):
         n_act = 1 + len(widths) + 3
         self.prelu = torch.nn.ModuleList([PReLU(shared_axes=[1, 0]) for _ in range(n_act)]) if aact == 'prelu' else None
         self.drop = Dropout(dropout)
-        self._drop_seed, self._drop_calls, self._zero_alpha, self._dev = 0x5EED, 0, None, None
+        self._drop_base, self._drop_calls, self._dev = 0, 0, None
         self.pred = TimeDistributed(Dense(62, activation='softmax', kernel_regularizer=reg, use_bias=True,
                                           bias_initializer='zeros', kernel_initializer='random_uniform'))
 
@@ -50,14 +50,27 @@ class TimitQCNN(torch.nn.Module):
         return self.prelu[i](x) if self.prelu is not None else x
 
     # ---- PReLU / Dropout fused into the kernels (functional.quaternion_conv_chain post-ops) ----------------------
+    def _new_drop_base(self):
+        """Base seed of this forward pass's dropout masks: drawn from torch's (CPU) generator, so `torch.manual_seed`
+        controls the masks as it controls torch's own dropout, and mixed with the data-parallel rank -- replicas seeded
+        alike must not drop the same units.  (The fused kernels apply round(rate * 256) / 256: 8 random bits per
+        element, functional.PostOp.applied_rate; 0.3 -> 0.30078.)"""
+        base = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if (self.training and self.rate > 0) else 0
+        rank = 0
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            rank = torch.distributed.get_rank()
+        self._drop_base, self._drop_calls = (base ^ (rank * 0x9E3779B1)) & 0xffffffff, 0
+
     def _post(self, k, out_shape, dropout=True):
         """Post-op spec of activation slot k behind a quaternion layer whose (channels_first / TimeDistributed) output
         shape is `out_shape`: the PReLU slopes of self.prelu[k] (built here: (1, F, 1) behind a convolution, i.e. one
-        per position of spatial axis 0 of the channels-last buffer; (1, 1) behind a dense layer) and the dropout rate
-        while training, with a fresh mask seed per call."""
+        per position of spatial axis 0 of the channels-last buffer; (1, 1) behind a dense layer) -- or alpha=None, the
+        relu form, for the aact='none' model -- and the dropout rate while training, with a fresh mask seed per call."""
         rate = self.rate if (dropout and self.training) else 0.0
         self._drop_calls += 1
-        seed = (self._drop_seed + 7919 * self._drop_calls) & 0xffffffff
+        seed = (self._drop_base + 7919 * self._drop_calls) & 0xffffffff
+        if self.prelu is None:
+            return dict(alpha=None, alpha_axis=-1, rate=rate, seed=seed)
         pl = self.prelu[k]
         if not pl.built:
             pl._build_device = self._dev
@@ -67,10 +80,14 @@ class TimitQCNN(torch.nn.Module):
 
     def forward(self, x):
         self._dev = x.device
-        fused_post = (self.prelu is not None and self.chain_convs and x.is_cuda and x.dtype in (torch.bfloat16, torch.float16, torch.float32)
-                      and not os.environ.get('QK_NO_FUSED_PRELU'))
-        if fused_post:
-            return self._forward_fused_prelu(x)
+        fusable = self.chain_convs and x.is_cuda and x.dtype in (torch.bfloat16, torch.float16, torch.float32)
+        if self.prelu is not None and fusable and not os.environ.get('QK_NO_FUSED_PRELU'):
+            return self._forward_fused_post(x)
+        # aact == 'none': relu layers with Dropout(d.dropout) behind every body convolution and the first two dense
+        # layers (interspeech_model.py:117-121,131-137,150-154) -- relu + dropout fused into the producing kernels
+        if (self.prelu is None and self.act == 'relu' and self.training and self.rate > 0 and fusable
+                and not os.environ.get('QK_NO_FUSED_DROPOUT')):
+            return self._forward_fused_post(x)
         o = self._first_layer_fused(x) if self.prelu is None else None
         if o is None:
             o = self._act(self.conv(x), 0)
@@ -122,25 +139,37 @@ class TimitQCNN(torch.nn.Module):
             return None
         return Fq.conv_relu_pool(xl, c.kernel, c.bias, 3).movedim(-1, 1)
 
-    def _forward_fused_prelu(self, x):
-        """aact == 'prelu' (interspeech_model.py:55-56,99-101,117-121: linear layers, PReLU(shared_axes=[1,0]) and
-        Dropout behind each) with both fused into the quaternion kernels: the producing kernel writes the
-        pre-activation and the activated / dropped tensor, the next layer's backward-data applies the derivative."""
+    def _forward_fused_post(self, x):
+        """The activation + Dropout behind every layer fused into the quaternion kernels.
+        aact == 'prelu' (interspeech_model.py:55-56,99-101,117-121: linear layers, PReLU(shared_axes=[1,0]) and Dropout
+        behind each): the producing kernel writes the pre-activation and the activated / dropped tensor, the next
+        layer's backward-data applies the derivative.
+        aact == 'none' with relu layers and an active Dropout (:117-121,131-137): the producing kernel writes ONLY
+        y = dropout(relu(pre)) and the next layer's backward-data multiplies its output by (y > 0) / (1 - rate) --
+        the same tensors and traffic as the dropout-free relu chain."""
         from .. import functional as Fq
         from ..keras_like import activations
+        self._new_drop_base()
         c = self.conv
         if not c.built:
             c._build_device = x.device
             c.build(tuple(x.shape))
         shape = c.compute_output_shape(tuple(x.shape))
+        relu_form = self.prelu is None
         post0 = self._post(0, shape, dropout=False)
         pl = self.pool
         xl = x.movedim(1, -1)                                        # (B, F, T, 4): the channels-last buffer
-        fused_first = (not os.environ.get('QK_NO_FUSED_FIRST') and x.dim() == 4 and c.padding == 'same' and c.strides == (1, 1) and
+        o = self._first_layer_fused(x) if relu_form else None
+        fused_first = (not relu_form and
+                       not os.environ.get('QK_NO_FUSED_FIRST') and x.dim() == 4 and c.padding == 'same' and c.strides == (1, 1) and
                        c.dilation_rate == (1, 1) and c.internal_layout == 'channels_last' and pl.pool_size == (1, 3) and
                        pl.strides == (1, 3) and pl.padding == 'same' and pl.data_format == 'channels_last' and
                        Fq.conv_prelu_pool_supported(xl, c.kernel, post0['alpha'], post0['alpha_axis'], 3))
-        if fused_first:      # linear conv + PReLU + frequency pooling as ONE kernel per direction (qk_conv_prelu_pool_*)
+        if o is not None:
+            pass             # conv + relu + frequency pooling ran as one kernel per direction (qk_conv_relu_pool_*)
+        elif relu_form:
+            o = self.pool(c(x))
+        elif fused_first:    # linear conv + PReLU + frequency pooling as ONE kernel per direction (qk_conv_prelu_pool_*)
             o = Fq.conv_prelu_pool(xl, c.kernel, c.bias, post0['alpha'], post0['alpha_axis'], 3).movedim(-1, 1)
         else:
             o = Fq.quaternion_conv(x, c.kernel, c.bias, strides=c.strides, padding=c.padding, data_format='channels_first',
@@ -169,9 +198,12 @@ class TimitQCNN(torch.nn.Module):
             if not dn.built:
                 dn._build_device = x.device
                 dn.build((None, o.shape[2]))
-            h = Fq.quaternion_dense(o.reshape(b * t, o.shape[2]), dn.r, dn.bias, activation=None).reshape(b, t, -1)
-            po = self._post(k, (b, t, h.shape[-1]), dropout=(i < 2))
-            o = Fq.prelu_dropout(h, po['alpha'], po['alpha_axis'], po['rate'], po['seed'])
+            po = self._post(k, (b, t, dn.r.shape[-1]), dropout=(i < 2))
+            if relu_form and po['rate'] == 0.0:
+                o = Fq.quaternion_dense(o.reshape(b * t, o.shape[2]), dn.r, dn.bias, activation='relu').reshape(b, t, -1)
+            else:
+                h = Fq.quaternion_dense(o.reshape(b * t, o.shape[2]), dn.r, dn.bias, activation=None).reshape(b, t, -1)
+                o = Fq.prelu_dropout(h, po['alpha'], po['alpha_axis'], po['rate'], po['seed'])
             k += 1
         return self.pred(o)
 

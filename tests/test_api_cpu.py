@@ -34,7 +34,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert declared == set(_lib.SYMBOLS), (declared ^ set(_lib.SYMBOLS))
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.qk_version() == 100
+    assert lib.qk_version() == 101
 
 
 def test_descriptor_struct_matches_header_field_order():

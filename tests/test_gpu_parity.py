@@ -995,20 +995,158 @@ def test_conv_chain_with_prelu_dropout_matches_oracle_composition(dtype, rate):
     assert _rel_err(xt.grad.float().cpu().numpy(), g) <= tol_g
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16], ids=['fp32', 'bf16', 'fp16'])
+def test_relu_dropout_op_matches_numpy(dtype):
+    """The relu form of the post-op on its own (qk_postop_* with alpha == NULL): y = dropout(relu(x)); the backward is
+    handed y only (d x = dy / (1 - rate) where y > 0)."""
+    import qcnn_amd
+    F = qcnn_amd.functional
+    dev = _dev()
+    rng = np.random.RandomState(44)
+    rnd = lambda a: torch.tensor(a).to(dtype).double().numpy()
+    for shape in ((3, 5, 7, 16), (50, 64)):
+        x = rnd(rng.randn(*shape))
+        dy = rnd(rng.randn(*shape))
+        for rate, seed in ((0.0, 0), (0.3, 777)):
+            keep = _np_drop_factor(shape, seed, rate)
+            xt = torch.tensor(x, device=dev).to(dtype).requires_grad_(True)
+            y = F.relu_dropout(xt, rate, seed)
+            y.backward(torch.tensor(dy, device=dev).to(dtype))
+            tol = 1e-6 if dtype == torch.float32 else (1e-2 if dtype == torch.bfloat16 else 2e-3)
+            assert _rel_err(y.detach().float().cpu().numpy(), np.maximum(x, 0) * keep) <= tol
+            assert _rel_err(xt.grad.float().cpu().numpy(), dy * keep * (x > 0)) <= tol
+
+
+@pytest.mark.parametrize('flat', [False, True], ids=['autograd_grads', 'direct_flat_grads'])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['fp32', 'bf16'])
+@pytest.mark.parametrize('rate', [0.0, 0.25], ids=['nodrop', 'drop'])
+def test_conv_chain_with_relu_dropout_matches_oracle_composition(dtype, rate, flat):
+    """The aact='none' setting of the TIMIT model (relu + Dropout behind every body convolution,
+    interspeech_model.py:117-121,131-137) as fused post-ops in their RELU form: each forward launch writes ONLY
+    y = dropout(relu(W (x) x + b)); the next layer's backward-data epilogue multiplies by (y > 0) / (1 - rate).  Checked
+    against the oracle's LINEAR layers + numpy relu / hash-mask: values, d input, every kernel / bias gradient.
+    32 -> 32 -> 64 (band kernels), then a conj 'valid' head.  `flat`: the gradients are ADDED into dp.FlatParams views by
+    the kernels (QK_BWD_ACCUMULATE through qk_conv_bwd_post) instead of returned to autograd."""
+    import qcnn_amd
+    from oracle import oracle
+    F = qcnn_amd.functional
+    dev = _dev()
+    rng = np.random.RandomState(49)
+    rnd = (lambda a: a) if dtype == torch.float32 else (lambda a: torch.tensor(a).to(dtype).double().numpy())
+    specs = [((3, 5, 32, 128), dict(padding='same', activation=None)),
+             ((3, 5, 32, 256), dict(padding='same', activation=None)),
+             ((6, 1, 64, 128), dict(padding='valid', activation=None, conj=True))]
+    x = rnd(rng.randn(2, 6, 40, 128).astype(np.float32).astype(np.float64))
+    ws = [rnd((rng.randn(*s) / np.sqrt(np.prod(s[:-1]) * 4)).astype(np.float32).astype(np.float64)) for s, _ in specs]
+    bs = [(0.1 * rng.randn(s[-1])).astype(np.float32).astype(np.float64) for s, _ in specs]
+    seeds = [111, 222, 333]
+    acts, pres, keeps = [x], [], []
+    for w, b, (_, kw), sd in zip(ws, bs, specs, seeds):
+        pre = oracle.forward(acts[-1], w, b, 2, **kw)
+        keep = _np_drop_factor(pre.shape, sd, rate)
+        pres.append(pre); keeps.append(keep)
+        acts.append(rnd(np.maximum(pre, 0) * keep))
+    dy = rnd(rng.randn(*acts[-1].shape).astype(np.float32).astype(np.float64))
+    xt = torch.tensor(x, device=dev).to(dtype).requires_grad_(True)
+    wt = [torch.nn.Parameter(torch.tensor(w, device=dev, dtype=torch.float32)) for w in ws]
+    bt = [torch.nn.Parameter(torch.tensor(b, device=dev, dtype=torch.float32)) for b in bs]
+    if flat:
+        fp = qcnn_amd.dp.FlatParams([p for pair in zip(wt, bt) for p in pair], direct=True)
+    layers = [(wt[i], bt[i], dict(specs[i][1], post=dict(alpha=None, rate=rate, seed=seeds[i]))) for i in range(3)]
+    y = F.quaternion_conv_chain(xt, layers)
+    y.backward(torch.tensor(dy, device=dev).to(dtype))
+    if flat:
+        assert all(p.grad.data_ptr() >= fp.grad.data_ptr() for p in wt + bt)
+    tol_y, tol_g = (1e-4, 2e-4) if dtype == torch.float32 else (1e-2, 3e-2)
+    got_y = y.detach().float().cpu().numpy()
+    assert _rel_err(got_y, acts[-1]) <= tol_y
+    # gradients on the GPU's own mask (a 16-bit pre-activation within rounding of 0 may flip): y_gpu > 0
+    g = dy
+    for i in reversed(range(3)):
+        mask = (acts[i + 1] > 0) if i < 2 else (got_y > 0)
+        dpre = g * keeps[i] * mask
+        g, dw, db = oracle.backward(acts[i], ws[i], bs[i], dpre, 2, **specs[i][1])
+        assert _rel_err(wt[i].grad.cpu().numpy(), dw) <= tol_g, 'dkernel %d' % i
+        assert _rel_err(bt[i].grad.cpu().numpy(), db) <= tol_g, 'dbias %d' % i
+    assert _rel_err(xt.grad.float().cpu().numpy(), g) <= tol_g
+
+
+def test_adam_step_folds_the_l2_term():
+    """qk_adam_step_l2: g = grad * grad_scale + decay * param, then the Keras Adam update; zero_grad clears grad."""
+    import qcnn_amd
+    F = qcnn_amd.functional
+    dev = _dev()
+    rng = np.random.RandomState(5)
+    n = 1000
+    p0, g0 = rng.randn(n).astype(np.float32), rng.randn(n).astype(np.float32)
+    dec = np.where(np.arange(n) < 600, 2 * 0.05, 0.0).astype(np.float32)
+    p, g = torch.tensor(p0, device=dev), torch.tensor(g0, device=dev)
+    m, v = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    F.adam_step(p, g, m, v, 1, lr=1e-2, grad_scale=0.5, zero_grad=True, decay=torch.tensor(dec, device=dev))
+    ge = g0.astype(np.float64) * 0.5 + dec.astype(np.float64) * p0
+    me, ve = 0.1 * ge, 0.001 * ge * ge
+    lr_t = 1e-2 * np.sqrt(1 - 0.999) / (1 - 0.9)
+    want = p0 - lr_t * me / (np.sqrt(ve) + 1e-7)
+    assert np.abs(p.cpu().numpy() - want).max() <= 1e-5 * np.abs(want).max()
+    assert float(g.abs().max()) == 0.0 and _rel_err(m.cpu().numpy(), me) <= 1e-5
+
+
+def test_fused_first_layer_declines_heights_whose_same_pooling_pads_low():
+    """Round-2 advisor finding: TensorFlow's 'same' pooling with window = stride = 3 pads one row on the LOW side when
+    H % 3 == 1 (e.g. 40 mel bins); the fused conv + pool kernels pool rows [3o, 3o + 2] and must decline those heights
+    (C predicate and Python predicate agree), while the model's layer-by-layer path gives Keras' answer."""
+    import qcnn_amd
+    from qcnn_amd import _lib
+    from qcnn_amd.models import TimitQCNN
+    Fq = qcnn_amd.functional
+    dev = _dev()
+    for h, ok in ((41, True), (40, False), (39, True), (7, False), (8, True)):
+        x = torch.randn(2, h, 30, 4, device=dev).to(torch.bfloat16)
+        w = torch.randn(3, 5, 1, 128, device=dev)
+        call = Fq.conv_call(tuple(x.shape), tuple(w.shape), x.dtype, 2, 1, 'same', 'channels_last', 1, 'relu', True, False)
+        assert (int(_lib.lib().qk_conv_relu_pool_aux_bytes(ctypes.byref(call.desc), 3)) > 0) == ok, h
+        assert Fq.conv_relu_pool_supported(x, w, 3) == ok, h
+        if not ok:
+            with pytest.raises(RuntimeError):
+                Fq.conv_relu_pool(x, w, None, 3)
+    np.random.seed(3); torch.manual_seed(3)
+    m = TimitQCNN(num_layers=2, start_filter=32)
+    x = torch.randn(2, 4, 40, 24, device=dev).to(torch.bfloat16)
+    m.eval()
+    with torch.no_grad():
+        y = m(x)
+        os.environ['QK_NO_FUSED_FIRST'] = '1'
+        try:
+            y2 = m(x)
+        finally:
+            del os.environ['QK_NO_FUSED_FIRST']
+        # Keras' first stage by hand: conv (relu) then max over TF 'same' windows of the 40 rows (lo pad 1)
+        o = m.conv(x).float().cpu().numpy()                         # (B, C, 40, T)
+        pooled, _ = _np_pool_h_same(np.moveaxis(o, 1, -1))          # (B, 14, T, C)
+        got = m.pool(m.conv(x)).float().cpu().numpy()
+    assert torch.equal(y, y2)
+    assert pooled.shape[1] == 14 and np.array_equal(np.moveaxis(got, 1, -1), pooled)
+
+
 # ---- the first TIMIT layer fused with its frequency pooling (qk_conv_relu_pool_*) ------------------------------------
 def _np_pool_h_same(y, pool=3):
+    """MaxPooling over axis 1, window = stride = pool, padding='same' with TensorFlow's rule (_shape.tf_pads: the low
+    side gets total // 2 -- one row when H % 3 == 1)."""
+    from qcnn_amd._shape import tf_pads
     n, h, w, c = y.shape
+    lo, _ = tf_pads(h, pool, pool, 1, 'same')
     out = -(-h // pool)
     p = np.empty((n, out, w, c)); arg = np.empty((n, out, w, c), dtype=np.int64)
     for o in range(out):
-        seg = y[:, o * pool:min((o + 1) * pool, h)]
-        arg[:, o] = seg.argmax(1) + o * pool
+        a, b = max(o * pool - lo, 0), min((o + 1) * pool - lo, h)
+        seg = y[:, a:b]
+        arg[:, o] = seg.argmax(1) + a
         p[:, o] = seg.max(1)
     return p, arg
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16], ids=['bf16', 'fp16'])
-@pytest.mark.parametrize('shape,F', [((3, 41, 50, 4), 32), ((2, 9, 230, 4), 64), ((1, 7, 19, 4), 32)],
+@pytest.mark.parametrize('shape,F', [((3, 41, 50, 4), 32), ((2, 9, 230, 4), 64), ((1, 8, 19, 4), 32)],
                          ids=['timit_small', 'two_chunks_two_column_tiles', 'partial_window'])
 def test_fused_first_layer_conv_relu_pool_matches_oracle(shape, F, dtype):
     """qk_conv_relu_pool_fwd / _bwd (conv (3,5) 'same' + relu + max-pool (3,1) 'same' over H, one kernel per direction,
@@ -1046,8 +1184,8 @@ def test_fused_first_layer_conv_relu_pool_matches_oracle(shape, F, dtype):
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16], ids=['bf16', 'fp16'])
-@pytest.mark.parametrize('shape,F,per_row', [((3, 41, 50, 4), 32, True), ((2, 7, 230, 4), 64, True), ((2, 10, 33, 4), 32, False)],
-                         ids=['41x50_f32', '7x230_f64', '10x33_scalar'])
+@pytest.mark.parametrize('shape,F,per_row', [((3, 41, 50, 4), 32, True), ((2, 8, 230, 4), 64, True), ((2, 11, 33, 4), 32, False)],
+                         ids=['41x50_f32', '8x230_f64', '11x33_scalar'])
 def test_fused_first_layer_conv_prelu_pool_matches_oracle(shape, F, per_row, dtype):
     """qk_conv_prelu_pool_fwd / _bwd (linear conv (3,5) 'same' + PReLU with one slope per frequency row, or one slope +
     max-pool (3,1) 'same' over H, one kernel per direction) against oracle conv + numpy PReLU / pooling: pooled values,

@@ -307,8 +307,10 @@ def test_example_networks_match_the_reference_model_fixture(tag):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('aact,dropout', [('none', 0.0), ('prelu', 0.2)], ids=['relu', 'prelu_dropout'])
-def test_bench_model_step_trains_through_the_flat_buffers(aact, dropout):
+@pytest.mark.parametrize('aact,dropout,l2,loss_kind', [('none', 0.0, 0.0, 'sum'), ('prelu', 0.2, 0.0, 'sum'), ('none', 0.25, 1e-4, 'sum'),
+                                                         ('none', 0.25, 1e-4, 'ctc')],
+                         ids=['relu', 'prelu_dropout', 'relu_dropout_l2', 'relu_dropout_l2_ctc'])
+def test_bench_model_step_trains_through_the_flat_buffers(aact, dropout, l2, loss_kind):
     """bench.ModelTrainStep (what the driver times): autograd accumulates into the views of dp.FlatParams' gradient
     buffer (never re-homing .grad), the fused Adam consumes and zeroes it, the bucketed reducer is inert without a
     process group -- and the synthetic loss goes down."""
@@ -316,14 +318,20 @@ def test_bench_model_step_trains_through_the_flat_buffers(aact, dropout):
         pytest.skip('needs a GPU')
     import bench
     dev = torch.device('cuda:0')
-    cfg = dict(kind='model', batch=4, frames=24, sf=32, layers=2, dtype='bf16', aact=aact, dropout=dropout, activation='relu')
-    job = bench.ModelTrainStep(cfg, dev, 0, 1)
+    cfg = dict(kind='model', batch=4, frames=64 if loss_kind == 'ctc' else 24, sf=32, layers=2, dtype='bf16', aact=aact, dropout=dropout,
+               l2=l2, activation='relu')
+    job = bench.ModelTrainStep(cfg, dev, 0, 1, loss=loss_kind)
     lo, hi = job.flat.grad.data_ptr(), job.flat.grad.data_ptr() + job.flat.grad.numel() * 4
+    assert (job.decay is not None) == (l2 > 0)
+    assert all(getattr(p, '_qk_direct_grad', False) for p in job.flat.params)
 
     def loss():
         with torch.no_grad():
             job.model.eval()
-            v = float((job.model(job.x).float() * job.target).sum())
+            if loss_kind == 'ctc':
+                v = float(job.model.ctc_loss(job.x, job.labels, job.input_length, job.label_length).mean())
+            else:
+                v = float((job.model(job.x).float() * job.target).sum())
             job.model.train()
             return v
     l0 = loss()
@@ -369,9 +377,14 @@ def test_bench_defaults_name_the_headline_workload():
     """`python bench.py` with no flags = the full TIMIT QCNN step, per-GPU batch 256, bf16 (BASELINE configs[2]/[3]) for
     every N; the FLOP count of that step is the sum of its quaternion layers' 2MNK."""
     import bench
-    assert bench.DEFAULT_WORKLOAD == 'cfg3_qcnn_timit_b256_bf16'
+    assert bench.DEFAULT_WORKLOAD == 'cfg3_qcnn_relu_dropout_b256_bf16'
     cfg = bench.WORKLOADS[bench.DEFAULT_WORKLOAD]
     assert (cfg['kind'], cfg['batch'], cfg['dtype'], cfg['layers'], cfg['sf'], cfg['frames']) == ('model', 256, 'bf16', 10, 32, 200)
+    # the graph the reference builds for aact='none': Dropout behind every body conv, l2 on every kernel
+    # (interspeech_model.py:63,68,117-121,131-137); the dropout-free step of rounds 1-2 stays available
+    assert cfg['dropout'] == 0.3 and cfg['l2'] > 0 and cfg.get('aact', 'none') == 'none'
+    old = bench.WORKLOADS['cfg3_qcnn_timit_b256_bf16']
+    assert old.get('dropout', 0.0) == 0.0 and old.get('l2', 0.0) == 0.0
     m0, m1, mt = 256 * 41 * 200, 256 * 14 * 200, 256 * 200
     want = 2.0 * m0 * 128 * 60
     want += 2.0 * m1 * (5 * 128 * 1920 + 256 * 1920 + 4 * 256 * 3840)
@@ -399,7 +412,9 @@ def test_bench_prints_one_contract_line():
               'dtype', 'data', 'config', 'roofline', 'pre_warmup_steps'):
         assert k in d, k
     assert (d['n_gpus'], d['steps'], d['warmup'], d['unit'], d['dtype'], d['data'], d['scaling']) == (1, 3, 1, 'samples/s', 'bf16', 'synthetic', 'weak')
-    assert d['config']['workload'] == 'cfg3_qcnn_timit_b256_bf16' and d['vs_baseline'] is None and d['higher_is_better'] is True
+    assert d['config']['workload'] == 'cfg3_qcnn_relu_dropout_b256_bf16' and d['vs_baseline'] is None and d['higher_is_better'] is True
+    assert d['config']['dropout'] == 0.3 and d['config']['l2'] > 0 and d['config']['loss'] == 'sum' and d['config']['rccl_ranks'] is None
+    assert d['config']['input'] == [256, 4, 41, 200] and d['config']['input_layout'].startswith('channels_first')
     assert abs(d['value'] - 256 * 1e3 / d['ms_per_step']) <= 1e-6 * d['value']
     calls = d['in_step_kernels']['calls']
     assert {(c['rows'], c['n'], c['k']) for c in calls} >= {(716800, 256, 3840), (716800, 128, 1920), (716800, 256, 1920)}
