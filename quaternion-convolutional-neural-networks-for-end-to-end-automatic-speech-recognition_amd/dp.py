@@ -214,11 +214,14 @@ class BucketedAllReduce(object):
         self.launch_order = []
         self.handles = []
         self.enabled = True               # False: hooks count but nothing is launched (bench: exposed-collective time)
+        self.direct_done = set()          # ... of those, the ones whose gradient the backward kernels wrote themselves
+        self._defined = {}                # id(param) -> did autograd deliver a DEFINED gradient in this pass
         if self.active:
             for p in flat.params:
                 if p.requires_grad:
-                    self.handles.append(p.register_post_accumulate_grad_hook(self._hook))
-                    p._qk_grad_ready = self._hook       # called by the engine when it wrote the gradient itself
+                    self.handles.append(p.register_hook(lambda g, p=p: self._saw_grad(p, g)))
+                    self.handles.append(p.register_post_accumulate_grad_hook(self._auto))
+                    p._qk_grad_ready = self._direct      # called by the engine when it wrote the gradient itself
 
     def _close(self, lo, hi, params):
         b = len(self.buckets)
@@ -229,24 +232,54 @@ class BucketedAllReduce(object):
             n += bool(p.requires_grad)
         self.sizes.append(n)
 
-    def _hook(self, p):
-        """One event per parameter and backward pass: its gradient is complete.  autograd's post-accumulate hook
-        satisfies that by construction (all contributions are summed before AccumulateGrad runs); the engine's direct
-        writes (functional._grad_ready) satisfy it only when nothing else in the graph produces a gradient for the
-        same parameter.  A second event means exactly that -- a regulariser differentiated through autograd, a tied
-        weight -- and the bucket may already be on the wire with a partial sum: refuse loudly."""
+    # One event per parameter and backward pass must mean "its gradient is complete".  Two sources of events:
+    #   _direct  the engine's backward kernels ADDED the gradient into the flat buffer themselves and say so
+    #            (functional._grad_ready) -- complete only if nothing else in the graph produces a gradient for the
+    #            same parameter;
+    #   _auto    autograd's post-accumulate hook: all contributions were summed and accumulated.  It ALSO fires, with
+    #            an undefined gradient, for a parameter whose backward node returned None (the direct writers do):
+    #            that event is dropped.  A DEFINED gradient for a parameter already reported by _direct is a second
+    #            source (a regulariser differentiated through autograd, a tied weight); the bucket may already be on
+    #            the wire with a partial sum -- refuse loudly instead of reducing garbage.
+    def _saw_grad(self, p, g):
+        self._defined[id(p)] = g is not None
+        return None
+
+    def _refuse(self, p, what):
         b = self.bucket_of[id(p)]
-        if id(p) in self.fired:
-            raise RuntimeError(
-                'BucketedAllReduce: a parameter of bucket %d reported its gradient twice in one backward pass (%s). '
-                'It is written directly by the backward kernels AND receives an autograd gradient (regulariser term, '
-                'tied weight): build FlatParams(direct="auto"/False) for such parameters, or fold the regulariser into '
-                'the optimiser step (FlatParams.l2_decay + adam_step(decay=)).'
-                % (b, 'its bucket was already launched' if b in self.launch_order else 'bucket not launched yet'))
+        raise RuntimeError(
+            'BucketedAllReduce: %s for a parameter of shape %s in bucket %d (%s).  It is written directly by the backward '
+            'kernels AND receives an autograd gradient (regulariser term, tied weight): build FlatParams(direct="auto" / '
+            'False) for such parameters, or fold the regulariser into the optimiser step (FlatParams.l2_decay + '
+            'adam_step(decay=)).' % (what, tuple(p.shape), b,
+                                      'its bucket was already launched' if b in self.launch_order else 'bucket not launched yet'))
+
+    def _count(self, p):
+        b = self.bucket_of[id(p)]
         self.fired.add(id(p))
         self.pending[b] -= 1
         if self.pending[b] == 0:
             self._launch(b)
+
+    def _direct(self, p):
+        if id(p) in self.fired:
+            self._refuse(p, 'the gradient was reported twice in one backward pass')
+        self.direct_done.add(id(p))
+        self._count(p)
+
+    def _auto(self, p):
+        defined = self._defined.pop(id(p), True)
+        if id(p) in self.direct_done:
+            if defined:
+                self._refuse(p, 'a second gradient arrived through autograd')
+            return                                  # the undefined-gradient echo of a direct write
+        if id(p) in self.fired:
+            self._refuse(p, 'the gradient was reported twice in one backward pass')
+        if defined:
+            self._count(p)
+        # (undefined and not direct: no gradient this pass; finish() sends the bucket)
+
+    _hook = _auto                                   # (name kept for callers that drive the counter by hand)
 
     def _launch(self, b):
         lo, hi = self.buckets[b]
@@ -266,7 +299,7 @@ class BucketedAllReduce(object):
             w.wait()
         self.works, self.launch_order = [], []
         self.pending = list(self.sizes)
-        self.fired = set()
+        self.fired, self.direct_done, self._defined = set(), set(), {}
 
     def bucket_bytes(self):
         return [4 * (hi - lo) for lo, hi in self.buckets]
@@ -276,7 +309,7 @@ class BucketedAllReduce(object):
             h.remove()
         self.handles = []
         for p in self.flat.params:
-            if getattr(p, '_qk_grad_ready', None) == self._hook:
+            if getattr(p, '_qk_grad_ready', None) == self._direct:
                 del p._qk_grad_ready
 
 

@@ -669,6 +669,11 @@ def conv_prelu_pool(x, kernel, bias, alpha, alpha_axis=0, pool=3):
     return _ConvPreluPoolFn.apply(xc, kernel.contiguous(), bias, alpha, call, pool, post)
 
 
+# Diagnostic tap (tests): when set to a callable it receives the list [x, y_1, ..., y_n] of every chain's activations
+# as the forward produced them (tests/test_timit_parity.py compares the 16-bit gradients on the GPU's own relu masks).
+chain_tap = None
+
+
 class _ConvChainFn(torch.autograd.Function):
     """A run of quaternion convolutions applied back to back as ONE autograd node, so that the backward knows the
     structure.  Each layer ends in a fused relu (y_i = relu(W_i (x) y_{i-1} + b_i)), is linear, or carries a POST-OP
@@ -694,6 +699,8 @@ class _ConvChainFn(torch.autograd.Function):
                 pre, y = call.fwd_post(acts[-1], w, b, post)
                 acts.append(y)
                 pres.append(pre)
+        if chain_tap is not None:
+            chain_tap(list(acts))
         ctx.calls, ctx.posts = calls, posts
         ctx.param_refs = (ws, bs)
         ctx.has_bias = [b is not None for b in bs]

@@ -103,12 +103,18 @@ def _compute_fans(shape, data_format='channels_last'):
     return shape[-2] * receptive_field_size, shape[-1] * receptive_field_size
 
 
+def _rng(seed):
+    """Keras backends draw with `seed = np.random.randint(10e6)` when an initializer has seed=None, i.e. from the GLOBAL
+    numpy state: `np.random.seed(...)` makes a whole model reproducible (what data-parallel replicas rely on)."""
+    return np.random.RandomState(np.random.randint(int(10e6)) if seed is None else seed)
+
+
 class RandomNormal(Initializer):
     def __init__(self, mean=0., stddev=0.05, seed=None):
         self.mean, self.stddev, self.seed = mean, stddev, seed
 
     def __call__(self, shape, dtype=None):
-        return np.random.RandomState(self.seed).normal(self.mean, self.stddev, shape)
+        return _rng(self.seed).normal(self.mean, self.stddev, shape)
 
     def get_config(self):
         return {'mean': self.mean, 'stddev': self.stddev, 'seed': self.seed}
@@ -119,7 +125,7 @@ class RandomUniform(Initializer):
         self.minval, self.maxval, self.seed = minval, maxval, seed
 
     def __call__(self, shape, dtype=None):
-        return np.random.RandomState(self.seed).uniform(self.minval, self.maxval, shape)
+        return _rng(self.seed).uniform(self.minval, self.maxval, shape)
 
     def get_config(self):
         return {'minval': self.minval, 'maxval': self.maxval, 'seed': self.seed}
@@ -136,7 +142,7 @@ class VarianceScaling(Initializer):
         fan_in, fan_out = _compute_fans(shape) if len(shape) >= 2 else (shape[0], shape[0])
         n = {'fan_in': fan_in, 'fan_out': fan_out, 'fan_avg': (fan_in + fan_out) / 2.}[self.mode]
         scale = self.scale / max(1., n)
-        rng = np.random.RandomState(self.seed)
+        rng = _rng(self.seed)
         if self.distribution == 'normal':
             return rng.normal(0., np.sqrt(scale), shape)
         limit = np.sqrt(3. * scale)

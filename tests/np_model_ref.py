@@ -18,14 +18,17 @@ def _ident(a):
 def maxpool_freq_same(x, win=3):
     """keras MaxPooling2D((1, win), padding='same') with the default channels_last data_format applied to a
     channels_first (B, C, F, T) tensor (interspeech_model.py:103): pools axis 2.  TF 'same': out = ceil(F/win),
-    padding on the high side only here (F=41, win=3 -> one cell), padded cells never win."""
+    total padding out*win - F with the LOW side getting total // 2 (F = 41: 0 low, 1 high; F = 40: 1 low, 1 high),
+    padded cells never win."""
     b, c, f, t = x.shape
     out = -(-f // win)
+    lo = (out * win - f) // 2
     y = np.empty((b, c, out, t))
     arg = np.empty((b, c, out, t), dtype=np.int64)
     for o in range(out):
-        seg = x[:, :, o * win:min((o + 1) * win, f), :]
-        arg[:, :, o, :] = seg.argmax(2) + o * win          # first maximum wins (TF / torch)
+        a, e = max(o * win - lo, 0), min((o + 1) * win - lo, f)
+        seg = x[:, :, a:e, :]
+        arg[:, :, o, :] = seg.argmax(2) + a                # first maximum wins (TF / torch)
         y[:, :, o, :] = seg.max(2)
     return y, arg
 
@@ -77,9 +80,18 @@ class TimitRef(object):
         self.alphas = [g(p.alpha) for p in model.prelu] if model.prelu is not None else None
 
     # ---- forward ----------------------------------------------------------------------------
-    def forward(self, x):
+    def forward(self, x, forced=None, keeps=None):
+        """forced: {'pool': (B, C, F', T), 'y_c<i>': (B, C, F', T), 'y_d<i>': (B*T, units)} -- outputs of the GPU model.
+        Where given, the layer's own output is checked against it (`forced_tol`, relative to its maximum) and then
+        REPLACED by it, so that everything downstream -- the next layer's input, the relu masks and the operands of the
+        backward -- is what the GPU had (16-bit runs: the gradients can then be compared element by element).
+        keeps: {'c<i>' / 'd<i>': dropout factor (0 or 1 / (1 - rate)) per element of that layer's output} -- the
+        Dropout layers of interspeech_model.py:117-121,131-137,150-154 with the masks the fused kernels generate."""
         rnd, rw = self.rnd, self.rnd_w
         self.saved = s = {}
+        forced = forced or {}
+        keeps = keeps or {}
+        self.forced_err = {}
         kw = dict(padding='same', data_format='channels_first', activation=self.act)
         k = 0
 
@@ -89,28 +101,45 @@ class TimitRef(object):
             s['pre%d' % k] = pre
             return rnd(prelu(pre, self.alphas[k]))
 
+        def force(name, own):
+            if name not in forced:
+                return own
+            f = np.asarray(forced[name], dtype=np.float64)
+            assert f.shape == own.shape, (name, f.shape, own.shape)
+            self.forced_err[name] = float(np.abs(f - own).max()) / max(float(np.abs(own).max()), 1e-30)
+            return f
+
+        def drop(name, h):
+            if name not in keeps:
+                return h
+            s['keep_' + name] = keeps[name]
+            return rnd(h * keeps[name])
+
         s['x'] = x
         h = rnd(oracle.forward(x, rw(self.conv[0]), self.conv[1], 2, **kw))
         s['y_conv'] = h
         h = activate(h, k); k += 1
         s['pool_in_f'] = h.shape[2]
         h, s['pool_arg'] = maxpool_freq_same(h, 3)
+        h = force('pool', h)
         for i, (w, b) in enumerate(self.convs):
             s['x_c%d' % i] = h
             h = rnd(oracle.forward(h, rw(w), b, 2, **kw))
-            s['y_c%d' % i] = h
             h = activate(h, k); k += 1
+            h = force('y_c%d' % i, drop('c%d' % i, h))
+            s['y_c%d' % i] = h                            # relu runs: y > 0 <=> pre > 0 (and kept): the mask
         bsz, c, f, t = h.shape
         s['perm_shape'] = h.shape
         h = h.transpose(0, 3, 1, 2).reshape(bsz * t, c * f)        # Permute((3,1,2)) + reshape, TimeDistributed
         for i, (w, b) in enumerate(self.dense):
             s['x_d%d' % i] = h
             y = rnd(oracle.forward(h, rw(w), b, 0, activation=self.act))
-            s['y_d%d' % i] = y
             if self.alphas is not None:
                 # TimeDistributed output is (B, T, units): alpha (1, 1) broadcasts over everything
                 s['pre%d' % k] = y
                 y = rnd(prelu(y.reshape(bsz, t, -1), self.alphas[k]).reshape(bsz * t, -1))
+            y = force('y_d%d' % i, drop('d%d' % i, y))
+            s['y_d%d' % i] = y
             k += 1
             h = y
         s['x_pred'] = h
@@ -135,6 +164,8 @@ class TimitRef(object):
         k = n_act - 1
         for i in reversed(range(len(self.dense))):
             w, b = self.dense[i]
+            if 'keep_d%d' % i in s:
+                dh = dh * s['keep_d%d' % i]
             if self.alphas is not None:
                 d3, da = prelu_bwd(s['pre%d' % k].reshape(bsz, t, -1), self.alphas[k], dh.reshape(bsz, t, -1))
                 grads['alpha%d' % k] = da
@@ -146,6 +177,8 @@ class TimitRef(object):
         kw = dict(padding='same', data_format='channels_first', activation=self.act)
         for i in reversed(range(len(self.convs))):
             w, b = self.convs[i]
+            if 'keep_c%d' % i in s:
+                dh = dh * s['keep_c%d' % i]
             if self.alphas is not None:
                 dh, grads['alpha%d' % k] = prelu_bwd(s['pre%d' % k], self.alphas[k], dh)
             k -= 1

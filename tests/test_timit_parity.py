@@ -4,13 +4,13 @@ float64 oracle composition of tests/np_model_ref.py -- forward AND every gradien
 conj-convolution): conj = 1 convolutions at rank 2, QK_BWD_MASK_DX / QK_BWD_DY_PREMASKED, qk_conv_fold_taps and
 qk_maxpool2d meet the oracle here directly, not another HIP kernel.
 
-Tolerances: fp32 <= 1e-4 of max|want| per tensor (BASELINE.json north_star); bf16: the composition emulates
-the 16-bit storage of every activation and the 16-bit kernels of the matrix-core path, forward <= 2e-2 (4e-3 fp16);
-gradients <= 1.5e-1 (8e-2 fp16) in relative 2-norm (observed 3 - 7 % / 2 - 5 %, varying from run to run with the order of
-the atomic accumulation): the backward passes through ten 16-bit tensors the composition
-does not round, and relu masks are decided by each side's own outputs (an output that rounds across zero moves
-single gradient elements by a full term, so the element-wise maximum is not a meaningful bound there).  The tight
-statement about the structure is the fp32 test, the tight statements about the 16-bit kernels are the layer tests.
+Tolerances: fp32 <= 1e-4 of max|want| per tensor (BASELINE.json north_star); bf16 / fp16: the composition emulates
+the 16-bit storage of every activation and the 16-bit kernels of the matrix-core path, forward <= 2e-2 (4e-3 fp16).
+16-bit GRADIENTS are compared ELEMENT-WISE on a common relu mask (round 3): the composition is teacher-forced with the
+GPU's own layer outputs (functional.chain_tap + module hooks), so that a pre-activation that rounds across zero on
+one side only -- which moves single gradient elements by a full term and forced a 15 % 2-norm tolerance in round 2 --
+can no longer differ; what remains is the 16-bit rounding of the gradient tensors between layers.  Every forced
+output is itself checked against the composition's own value of that layer (a per-layer parity statement).
 """
 import numpy as np
 import pytest
@@ -77,29 +77,139 @@ def _round_fn(dtype):
     return lambda a: torch.tensor(a).to(dtype).double().numpy()
 
 
+def _np(t):
+    return t.detach().double().cpu().numpy()
+
+
+def _capture_layer_outputs(model, xt, run):
+    """Run `run()` (forward [+ backward]) and return the GPU's own outputs of the pooled first layer, every body
+    convolution and the three dense layers, as the composition's `forced` dictionary."""
+    import qcnn_amd
+    Fq = qcnn_amd.functional
+    taps, dense_out = [], {}
+    hooks = [model.dense[i].register_forward_hook(lambda m, a, o, i=i: dense_out.__setitem__(i, o)) for i in range(3)]
+    Fq.chain_tap = taps.append
+    try:
+        out = run()
+    finally:
+        Fq.chain_tap = None
+        for h in hooks:
+            h.remove()
+    assert taps, 'the body convolutions did not run as a chain'
+    acts = taps[-1]                                         # [pooled input, y_conv0 .. y_conv{n-1}, (head)] channels-last
+    n = len(model.convs)
+    forced = {'pool': _np(acts[0].movedim(-1, 1))}
+    for i in range(n):
+        forced['y_c%d' % i] = _np(acts[1 + i].movedim(-1, 1))
+    if len(acts) > n + 1:                                   # the first dense layer ran inside the chain as an (F, 1) convolution
+        forced['y_d0'] = _np(acts[n + 1].reshape(-1, acts[n + 1].shape[-1]))
+    for i, o in dense_out.items():
+        forced['y_d%d' % i] = _np(o.reshape(-1, o.shape[-1]))
+    return out, forced
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16], ids=['bf16', 'fp16'])
 def test_timit_qcnn_16bit_matches_oracle_composition(dtype):
-    """sf = 32: every quaternion layer is on the 16-bit MFMA path (band kernels, chain flags, conj head, fold)."""
+    """sf = 32: every quaternion layer is on the 16-bit MFMA path (band kernels, chain flags, conj head, fused first
+    layer).  Forward against the free-running composition; every layer output against the composition's value GIVEN the
+    GPU's input to that layer; gradients element-wise on the GPU's own relu masks."""
     dev = _dev()
     model, xt, dpred = _build(dev, dtype, 32, 4, 'none', 2, 24, seed=13)
-    pred = model(xt)
-    (pred.float() * torch.tensor(dpred, device=dev, dtype=torch.float32)).sum().backward()
+
+    def run():
+        pred = model(xt)
+        (pred.float() * torch.tensor(dpred, device=dev, dtype=torch.float32)).sum().backward()
+        return pred
+    pred, forced = _capture_layer_outputs(model, xt, run)
+    assert set(forced) == {'pool', 'y_c0', 'y_c1', 'y_c2', 'y_c3', 'y_d0', 'y_d1', 'y_d2'}
     rnd = _round_fn(dtype)
+    tol_f, tol_g = (2e-2, 2e-2) if dtype == torch.bfloat16 else (4e-3, 5e-3)
+    x64 = xt.detach().cpu().double().numpy()
+    free = TimitRef(model, act='relu', rnd=rnd, rnd_w=rnd)
+    assert _rel(pred.detach().float().cpu().numpy(), free.forward(x64)) <= tol_f
     ref = TimitRef(model, act='relu', rnd=rnd, rnd_w=rnd)
-    want = ref.forward(xt.detach().cpu().double().numpy())
-    tol_f, tol_g = (2e-2, 1.5e-1) if dtype == torch.bfloat16 else (4e-3, 8e-2)
+    want = ref.forward(x64, forced=forced)
+    assert max(ref.forced_err.values()) <= tol_f, ref.forced_err            # layer by layer, same inputs
     assert _rel(pred.detach().float().cpu().numpy(), want) <= tol_f
     wg = ref.backward(dpred)
     got = model_grads(model)
-    for k, v in got.items():
-        assert v is not None, k
-        # 2-norm: an output that rounds across zero on one side only (relu mask) moves a few gradient elements by
-        # a full term -- with 48 rows behind each element of the head's gradient that is tens of percent of one
-        # element, and noise in the norm; the element-wise bound only guards against gross errors
-        l2 = float(np.linalg.norm(v - wg[k])) / max(float(np.linalg.norm(wg[k])), 1e-30)
-        assert l2 <= tol_g, '%s: relative 2-norm error %.3g' % (k, l2)
-        assert _rel(v, wg[k]) <= 0.35, '%s: max-abs rel err %.3g' % (k, _rel(v, wg[k]))
+    errs = {k: _rel(v, wg[k]) for k, v in got.items()}
+    # first layer: its relu / arg-max decisions sit in FRONT of the first forced tensor (the fused kernel never writes
+    # the pre-pool activation), so single elements of ITS kernel gradient may still differ by a full term (observed
+    # 6e-2 bf16 / 2e-2 fp16; that kernel meets the oracle directly in test_fused_first_layer_conv_relu_pool_matches_oracle);
+    # everything behind the pooling shares the GPU's masks: observed <= 7e-3 bf16 / 1e-3 fp16
+    for k, e in errs.items():
+        lim = 5 * tol_g if k == 'conv.kernel' else tol_g
+        assert e <= lim, ('%s: element-wise rel err %.3g' % (k, e), errs)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['fp32', 'bf16'])
+def test_timit_qcnn_relu_dropout_matches_oracle_composition(dtype):
+    """The graph the reference builds for aact='none' with d.dropout > 0 (interspeech_model.py:117-121,131-137,150-154):
+    relu layers with Dropout behind every body convolution and the first two dense layers, here with relu + dropout
+    fused into the producing kernels (one output tensor per layer) and the derivative in the consumer's backward-data
+    epilogue.  The composition applies the same masks (the kernels' counter-based hash of (seed, element index),
+    restated in numpy) -- posteriors and every gradient."""
+    from test_gpu_parity import _np_drop_factor
+    dev = _dev()
+    from qcnn_amd.models import TimitQCNN
+    sf = 8 if dtype == torch.float32 else 32
+    np.random.seed(21); torch.manual_seed(21)
+    rate = 0.25
+    model = TimitQCNN(num_layers=4, start_filter=sf, act='relu', aact='none', dropout=rate)
+    rng = np.random.RandomState(22)
+    bsz, t = 2, 24
+    xt = torch.tensor(rng.randn(bsz, 4, 41, t).astype(np.float32), device=dev).to(dtype)
+    model.train()
+    with torch.no_grad():
+        model(xt)
+        for name, p in model.named_parameters():
+            if name.endswith('bias'):
+                p.copy_(torch.tensor(0.1 * rng.randn(*p.shape), dtype=torch.float32))
+    dpred = rng.randn(bsz, t, 62)
+
+    def run():
+        pred = model(xt)
+        (pred.double() * torch.tensor(dpred, device=dev)).sum().backward()
+        return pred
+    pred, forced = _capture_layer_outputs(model, xt, run)
+    # the masks of this forward pass: seed of the k-th activation slot = base + 7919 k (TimitQCNN._post)
+    base, n = model._drop_base, len(model.convs)
+    seed = lambda k: (base + 7919 * k) & 0xffffffff
+    keeps = {}
+    for i in range(n):
+        b_, c_, f_, t_ = forced['y_c%d' % i].shape
+        keeps['c%d' % i] = np.moveaxis(_np_drop_factor((b_, f_, t_, c_), seed(2 + i), rate), -1, 1)
+    keeps['d0'] = _np_drop_factor((bsz * t, 256), seed(2 + n), rate)
+    keeps['d1'] = _np_drop_factor((bsz * t, 256), seed(3 + n), rate)
+    dropped = np.mean([float((k == 0).mean()) for k in keeps.values()])
+    assert abs(dropped - rate) < 0.02, dropped
+    x64 = xt.detach().cpu().double().numpy()
+    if dtype == torch.float32:
+        ref = TimitRef(model, act='relu')
+        want = ref.forward(x64, keeps=keeps)
+        tol_f = tol_g = 1e-4
+    else:
+        rnd = _round_fn(dtype)
+        ref = TimitRef(model, act='relu', rnd=rnd, rnd_w=rnd)
+        want = ref.forward(x64, forced=forced, keeps=keeps)
+        tol_f, tol_g = 2e-2, 2e-2
+        assert max(ref.forced_err.values()) <= tol_f, ref.forced_err
+    assert _rel(pred.detach().float().cpu().numpy(), want) <= tol_f
+    wg = ref.backward(dpred)
+    got = model_grads(model)
+    errs = {k: _rel(v, wg[k]) for k, v in got.items()}
+    for k, e in errs.items():
+        lim = 5 * tol_g if (k == 'conv.kernel' and dtype != torch.float32) else tol_g
+        assert e <= lim, ('%s: rel err %.3g' % (k, e), errs)
+    # eval mode: Dropout is the identity (Keras' learning phase 0)
+    model.eval()
+    with torch.no_grad():
+        pe = model(xt)
+    ref_e = TimitRef(model, act='relu', **({} if dtype == torch.float32 else dict(rnd=_round_fn(dtype), rnd_w=_round_fn(dtype))))
+    assert _rel(pe.float().cpu().numpy(), ref_e.forward(x64)) <= tol_f
 
 
 @pytest.mark.gpu
