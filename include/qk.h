@@ -124,7 +124,6 @@ const char *qk_last_error(void);
 #define QK_DBG_WGRAD16_ONE_TAP 8u
 #define QK_DBG_NO_WGRAD_BAND 32u   /* 16-bit backward-weight: one block per tap (k_wgrad16) instead of the band kernel */
 #define QK_DBG_NO_POINT16 64u
-#define QK_DBG_BAND16_DMA 128u     /* 64-row band kernels stage through LDS-DMA loads (experimental; env QK_BAND16_DMA) */
 #define QK_DBG_BAND16_8WAVES 16u   /* 16-bit band kernels: 8-wave workgroups (one per CU) instead of 4-wave (two per CU) */
 unsigned qk_set_debug_flags(unsigned flags);
 unsigned qk_get_debug_flags(void);

@@ -494,29 +494,6 @@ __device__ __forceinline__ void buf_store16b(__amdgpu_buffer_rsrc_t r, unsigned 
     __builtin_amdgcn_raw_buffer_store_b128(d, r, (int)(voff + soff), 0, 0);
 }
 
-// 16-byte-per-lane LDS-DMA load (gfx950): lane l's 16 bytes land at LDS byte address m0 + 16 l, no VGPR in between.  Issued
-// through inline assembly: with the builtin hipcc waits for EVERY outstanding LDS-DMA before the next ds_read (it cannot
-// tell the buffers apart); here the waits are placed by hand (s_waitcnt vmcnt in dma_wait<>).  M0 is not used by anything
-// else in these kernels (gfx9 LDS instructions do not read it).
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ i32x4 make_rsrc_words(const void *p, unsigned bytes)
-{
-    const unsigned long long a = reinterpret_cast<unsigned long long>(p);
-    const i32x4 r = {(int)(unsigned)a, (int)((a >> 32) & 0xffffu), (int)bytes, 0x00020000};
-    return r;
-}
-__device__ __forceinline__ void dma16(const i32x4 &rsrc, unsigned voff, unsigned soff, unsigned lds_byte)
-{
-    asm volatile("s_mov_b32 m0, %3\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" : : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_byte) : "memory");
-}
-template <int N> __device__ __forceinline__ void dma_wait()
-{
-    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-}
-
 // A-band staging schedule of one group: op code q < R loads row pass q of the NEXT band into its
 // registers, R <= q < 2R stores pass q - R into the other band buffer, -1 = nothing.  A store comes at
 // least one sub-step after its load (so it never waits on it), and at most three passes are in flight
@@ -542,7 +519,7 @@ constexpr int band_op(int R, int K, int ti, int k)
 //   TRIM (N = 128, 4 x 1 waves): the band buffer holds exactly BM = 128 rows, so a tile yields BM - (KIN - 1)
 //     output rows and the last KIN - 1 rows of the wave tiles are computed and dropped (3 %): 2 x 128 rows x 256 B
 //     + 2 B tiles = 80 KB is what lets two such workgroups share a CU.
-template <typename T, int WM, int WN, int KIN, bool CONJ, bool TRIM, bool EPM, bool POSTF, bool DMA = false>
+template <typename T, int WM, int WN, int KIN, bool CONJ, bool TRIM, bool EPM, bool POSTF>
 __global__ void __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *__restrict__ zero_line,
                const float *__restrict__ bias, T *__restrict__ out, const GemmGeom g)
@@ -576,11 +553,10 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
     const int nkc = g.Q / 32;
 
     // ---- band rows of this thread (decoded once) ------------------------------------------------
-    // register staging: 8 threads per row, NTHR / 8 rows per pass.  DMA staging: one instruction of a wave fills 4 band
-    // rows (64 lanes x 16 bytes), NW * 4 rows per pass; lane l owns row 4 wave + l / 16, physical slot l % 16.
-    constexpr int RPP = DMA ? NW * 4 : NTHR / 8;    // rows per staging pass
+    // register staging: 8 threads per row, NTHR / 8 rows per pass
+    constexpr int RPP = NTHR / 8;                   // rows per staging pass
     constexpr int RPT3 = (BAND + RPP - 1) / RPP;
-    const int s_row = DMA ? wave * 4 + (lane >> 4) : tid >> 3, s8 = tid & 7;
+    const int s_row = tid >> 3, s8 = tid & 7;
     int base_off[RPT3];
     unsigned omask[RPT3];                           // bit (t0 * ks1 + t1): outer tap inside the tensor
 #pragma unroll
@@ -617,10 +593,7 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
     const int substeps = groups * KIN;
     const int cmp_lo = s8 >> 2, sub = (s8 & 3) * 8;
     const __amdgpu_buffer_rsrc_t rin = make_rsrc16(in, g.b_in_bytes), rw = make_rsrc16(wq, g.b_w_bytes);
-    // DMA: lane l fills PHYSICAL slot l % 16 of its row, i.e. logical slot (l % 16) ^ (row & 15) = (component, 8 channels)
-    const int d_ls = (lane & 15) ^ (s_row & 15);
-    const unsigned a_thr = DMA ? (unsigned)((d_ls >> 2) * g.Q + (d_ls & 3) * 8) * 2u
-                               : (unsigned)(cmp_lo * g.Q + sub) * 2u;  // this thread's (component, 8 channels) of a row
+    const unsigned a_thr = (unsigned)(cmp_lo * g.Q + sub) * 2u;         // this thread's (component, 8 channels) of a row
     const unsigned a_hi = (unsigned)g.Q * 4u;                            // two components further (wave-uniform)
     // B unit u = tid + k * NTHR lies (NTHR / BF) (slot, part) segments further per k: a wave-uniform offset
     const unsigned b_thr0 = (unsigned)((tid / BF) * g.J + j0 + tid % BF) * 16u;
@@ -699,20 +672,6 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
         uint4 *Bs = lds + 2 * A_U + buf * B_U;
         Bs[tid + k * NTHR] = k == 0 ? br0 : k == 1 ? br1 : k == 2 ? br2 : br3;
     };
-    // DMA staging: global -> LDS without registers (see dma16).  A pass r of a wave = its 4 rows of band rows
-    // [r RPP, (r + 1) RPP); the halo pass is wave 0's alone (the other waves' rows lie past the band buffer).
-    static_assert(!DMA || (RPP % 16 == 0 && HALO && NW == 4), "DMA staging: 64-row tiles of four waves");
-    const i32x4 rin_w = make_rsrc_words(in, g.b_in_bytes), rw_w = make_rsrc_words(wq, g.b_w_bytes);
-    const unsigned lds0 = (unsigned)reinterpret_cast<unsigned long long>((__attribute__((address_space(3))) char *)lds);
-    auto dma_a = [&](int r, int buf) {
-        const bool ok = (omask[r] >> aot) & 1u;
-        const unsigned voff = ok ? (unsigned)(base_off[r] + adelta) * 2u + a_thr : kOutOfRange16;
-        if (r < RPTF || wave == 0) dma16(rin_w, voff, 0, lds0 + (unsigned)(buf * A_U + (r * RPP + wave * 4) * 16) * 16u);
-    };
-    auto dma_b = [&](int k, int buf) {
-        dma16(rw_w, b_thr0, bsoff + (unsigned)k * b_kstep, lds0 + (unsigned)(2 * A_U + buf * B_U + wave * 64 + k * NTHR) * 16u);
-    };
-
     floatx16 acc[4], accn[4];
 #pragma unroll
     for (int b = 0; b < 4; ++b)
@@ -724,32 +683,21 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
 
     // ---- prologue: band 0, B tile 0 in LDS; B tile 1 in registers ---------------------------------
     a_prep();
-    if constexpr (DMA) {
 #pragma unroll
-        for (int r = 0; r < RPT3; ++r) dma_a(r, 0);
-        b_prep();
+    for (int r = 0; r < RPT3; ++r) load_a(r);
+    b_prep();
 #pragma unroll
-        for (int k = 0; k < BU; ++k) dma_b(k, 0);
-        a_advance_if_more();
-        b_advance_if_more();
-        dma_wait<0>();
-    } else {
+    for (int k = 0; k < BU; ++k) load_b1(k);
 #pragma unroll
-        for (int r = 0; r < RPT3; ++r) load_a(r);
-        b_prep();
+    for (int r = 0; r < RPT3; ++r) store_a(r, 0);
+    a_advance_if_more();
 #pragma unroll
-        for (int k = 0; k < BU; ++k) load_b1(k);
+    for (int k = 0; k < BU; ++k) store_b1(k, 0);
+    b_advance_if_more();
+    b_prep();
 #pragma unroll
-        for (int r = 0; r < RPT3; ++r) store_a(r, 0);
-        a_advance_if_more();
-#pragma unroll
-        for (int k = 0; k < BU; ++k) store_b1(k, 0);
-        b_advance_if_more();
-        b_prep();
-#pragma unroll
-        for (int k = 0; k < BU; ++k) load_b1(k);
-        b_advance_if_more();
-    }
+    for (int k = 0; k < BU; ++k) load_b1(k);
+    b_advance_if_more();
     __syncthreads();
 
     static_assert(band_op(RPT3, KIN, 0, 0) != -2, "no staging schedule for this (row passes, inner taps)");
@@ -769,14 +717,6 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
             const uint4 *b_rd = lds + b_rd0 + (s & 1) * B_U;
             const int nb = (s + 1) & 1;
             b_prep();
-            if constexpr (DMA) {
-                // B tile of the next sub-step first, then this sub-step's share of the next group's band: the loads
-                // complete in order, so waiting until only the band passes are outstanding means the B tile has landed
-#pragma unroll
-                for (int k = 0; k < BU; ++k) dma_b(k, nb);
-#pragma unroll
-                for (int r = ti; r < RPT3; r += KIN) dma_a(r, nband);
-            }
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 uint4 A[4], B[4];
@@ -797,7 +737,7 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
                         if ((tbl >> (a * 4 + b)) & 1u) accn[b] = mfma16(T(), B[a ^ b], A[a], accn[b]);
                         else acc[b] = mfma16(T(), B[a ^ b], A[a], acc[b]);
                         const int f = ks * 16 + a * 4 + b;
-                        if (!DMA && f % 2 == 1) {
+                        if (f % 2 == 1) {
                             const int op = f / 2;                        // staging slot of this sub-step
                             if (op < kBandOpsMax) {
                                 const int q = band_op(RPT3, KIN, ti, op);
@@ -810,13 +750,6 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
                     }
             }
             b_advance_if_more();
-            if constexpr (DMA) {
-                // (ti is a constant of the unrolled loop: the chains below fold to one s_waitcnt)
-                const int n_full = (RPTF - 1 - ti) / KIN + (ti < RPTF ? 1 : 0);     // full passes issued in this sub-step
-                const bool halo_here = (RPTF - ti) % KIN == 0 && RPTF >= ti;         // and the halo pass (wave 0 only)
-                const int n_out = ti == KIN - 1 ? 0 : n_full + ((halo_here && wave == 0) ? 1 : 0);   // group end: all of the next band
-                if (n_out == 0) dma_wait<0>(); else if (n_out == 1) dma_wait<1>(); else if (n_out == 2) dma_wait<2>(); else dma_wait<3>();
-            }
             __syncthreads();
         }
         a_advance_if_more();
@@ -1160,14 +1093,6 @@ int run16_band(const T *in, const uint4 *wq, const T *zero_line, const float *bi
 #define QK_GO(C, E, P) hipLaunchKernelGGL((k_hgemm16_band<T, WM, WN, KIN, C, TRIM, E, P>), grid, dim3(NTHR), 0, stream, in, wq, zero_line, bias, out, g)
     const bool epm = g.ep_mask != nullptr, pf = g.post.kind != 0 && g.post_fwd != 0;
     if (g.sign_tbl != kSignConj) return QK_ERR_LAUNCH;                 // go16 folds the plain table into the kernel
-    if constexpr (!TRIM && WM * WN == 4) {
-        if (debug_flags() & kDbgBand16Dma) {                           // LDS-DMA staging (experimental, A/B switch)
-#define QK_GOD(E, P) hipLaunchKernelGGL((k_hgemm16_band<T, WM, WN, KIN, true, TRIM, E, P, true>), grid, dim3(NTHR), 0, stream, in, wq, zero_line, bias, out, g)
-            if (epm) QK_GOD(true, false); else if (pf) QK_GOD(false, true); else QK_GOD(false, false);
-#undef QK_GOD
-            return hipGetLastError() == hipSuccess ? 1 : QK_ERR_LAUNCH;
-        }
-    }
     if (epm) QK_GO(true, true, false); else if (pf) QK_GO(true, false, true); else QK_GO(true, false, false);
 #undef QK_GO
     return hipGetLastError() == hipSuccess ? 1 : QK_ERR_LAUNCH;

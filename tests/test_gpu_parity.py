@@ -1311,31 +1311,3 @@ def test_library_profiler_times_every_call_of_a_backward():
         assert (r['rows'], r['n'], r['k']) == (4 * 14 * 40, 128, 3 * 5 * 128) and r['ms'] > 0 and r['path'].startswith('mfma16')
     F.quaternion_conv(x, w, None, padding='same', activation='relu')
     assert _lib.lib().qk_prof_count() == 3
-
-
-def test_band_kernel_lds_dma_staging_is_bit_identical():
-    """QK_DBG_BAND16_DMA: the 64-row band kernel with its A bands and B tiles staged by LDS-DMA loads (no staging
-    registers) computes the same products in the same order as the register-staged kernel -- forward, backward-data
-    with the chain mask, a 3-tap inner axis and border tiles included."""
-    import qcnn_amd
-    from qcnn_amd import _lib
-    F = qcnn_amd.functional
-    dev = _dev()
-    g = torch.Generator(device=dev).manual_seed(9)
-    for (xs, ws) in (((2, 14, 200, 256), (3, 5, 64, 256)), ((2, 9, 160, 128), (3, 3, 32, 256)), ((1, 5, 180, 256), (1, 5, 64, 512))):
-        x = torch.randn(xs, device=dev, generator=g).to(torch.bfloat16)
-        w = torch.randn(ws, device=dev, generator=g) / 30
-        b = torch.randn(ws[-1], device=dev, generator=g) / 10
-        call = F.conv_call(xs, ws, torch.bfloat16, 2, 1, 'same', 'channels_last', 1, 'relu', True)
-        dy = torch.randn(call.y_shape, device=dev, generator=g).to(torch.bfloat16)
-
-        def run():
-            y = call.fwd(x, w, b)
-            assert _lib.last_path() == 'mfma16_band'
-            dx = call.bwd(x, dy, y, w, True, flags=_lib.QK_BWD_MASK_DX | _lib.QK_BWD_DY_PREMASKED)[0]
-            torch.cuda.synchronize()
-            return y, dx
-        ref = run()
-        with _lib.debug_flags(_lib.QK_DBG_BAND16_DMA):
-            got = run()
-        assert torch.equal(ref[0], got[0]) and torch.equal(ref[1], got[1]), (xs, ws)

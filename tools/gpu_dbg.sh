@@ -1,4 +1,5 @@
 #!/bin/bash
-cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/dbg
-timeout 1200 python -m pytest tests/test_gpu_parity.py tests/test_timit_parity.py tests/test_dp_gloo.py -m gpu -q --no-header -p no:cacheprovider -k "relu_dropout or declines or full_size_properties or homogeneity or 16bit_matches or l2_regulariser or fused_first_layer" > gpurun_out/dbg/pytest.txt 2>&1; echo rc=$?
-grep -E "^(FAILED|ERROR)|passed|failed|^E  " gpurun_out/dbg/pytest.txt | head -60
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/power
+
+for k in fwd bwd_data bwd_weight; do python tools/power_trace.py --seconds 3 --kernel $k 2>&1 | grep -v amdgpu.ids | tee gpurun_out/power/trace_$k.txt; done
+
