@@ -275,12 +275,18 @@ int qk_postop_bwd(const qk_conv_desc_t *t, const qk_postop_t *post, const void *
  * kernel's windows are rows [3o, 3o + 2]; TensorFlow's 'same' rule pads one row on the LOW side when H % 3 == 1, so
  * for those heights the windows would start at row -1: not this kernel's -- 41 bins are fine); anything else returns
  * QK_ERR_UNSUPPORTED (qk_conv_relu_pool_aux_bytes: 0) and the caller runs qk_conv_fwd + qk_maxpool2d_* instead.
- * `aux` may be NULL in the forward (inference). */
+ * `aux` may be NULL in the forward (inference).
+ * desc->layout describes x ONLY here: QK_CH_LAST = (N, H, W, 4); QK_CH_FIRST = (N, 4, H, W), the four r / i / j / k
+ * component PLANES of the one quaternion channel exactly as the reference feeds its model (Input(shape=(4, 41, None)),
+ * interspeech_model.py:81) -- each plane row is read with coalesced loads and the planes are interleaved while the
+ * patch is staged in LDS.  The pooled tensor (and its gradient) is always channels_last: this layer is where a
+ * channels_first model's data enters the engine's channels-last domain, so no separate re-layout pass exists.
+ * bwd flags: 0 (dw / dbias overwritten) or QK_BWD_ACCUMULATE (added to). */
 size_t qk_conv_relu_pool_aux_bytes(const qk_conv_desc_t *desc, int32_t pool);
 int qk_conv_relu_pool_fwd(const qk_conv_desc_t *desc, int32_t pool, const void *x, const float *w, const float *bias,
                           void *pooled, void *aux, void *stream);
 int qk_conv_relu_pool_bwd(const qk_conv_desc_t *desc, int32_t pool, const void *x, const void *dpooled, const void *aux,
-                          float *dw, float *dbias, void *stream);
+                          float *dw, float *dbias, int32_t flags, void *stream);
 
 /* The same layer in its PReLU form (the reference's aact == 'prelu'): LINEAR convolution (desc->activation), PReLU with
  * one slope per row of the conv output (post->alpha_axis 0, alpha_len == in_spatial[0] <= 64: Keras shared_axes=[1,0])
@@ -291,7 +297,8 @@ int qk_conv_relu_pool_bwd(const qk_conv_desc_t *desc, int32_t pool, const void *
 int qk_conv_prelu_pool_fwd(const qk_conv_desc_t *desc, int32_t pool, const qk_postop_t *post, const void *x, const float *w,
                            const float *bias, void *pooled, void *pre_pooled, void *aux, void *stream);
 int qk_conv_prelu_pool_bwd(const qk_conv_desc_t *desc, int32_t pool, const qk_postop_t *post, const void *x, const void *dpooled,
-                           const void *pre_pooled, const void *aux, float *dw, float *dbias, float *dalpha, void *stream);
+                           const void *pre_pooled, const void *aux, float *dw, float *dbias, float *dalpha, int32_t flags,
+                           void *stream);
 
 /* Tap folding for layers with very few input channels (the first TIMIT layer has cq = 1: K = 4*taps).
  *   xcol[m, a*cq2 + t*cq + c] = x[pos(m, t), a*cq + c]      (0 in the padding and for t*cq + c >= taps*cq)

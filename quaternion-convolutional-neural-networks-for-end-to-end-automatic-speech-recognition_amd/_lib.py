@@ -89,9 +89,9 @@ SYMBOLS = {
     'qk_conv_fold_taps': (ctypes.c_int, [_CD, _VP, _VP, I32, _VP]),
     'qk_conv_relu_pool_aux_bytes': (_SZ, [_CD, I32]),
     'qk_conv_relu_pool_fwd': (ctypes.c_int, [_CD, I32, _VP, _FP, _FP, _VP, _VP, _VP]),
-    'qk_conv_relu_pool_bwd': (ctypes.c_int, [_CD, I32, _VP, _VP, _VP, _FP, _FP, _VP]),
+    'qk_conv_relu_pool_bwd': (ctypes.c_int, [_CD, I32, _VP, _VP, _VP, _FP, _FP, I32, _VP]),
     'qk_conv_prelu_pool_fwd': (ctypes.c_int, [_CD, I32, _PO, _VP, _FP, _FP, _VP, _VP, _VP, _VP]),
-    'qk_conv_prelu_pool_bwd': (ctypes.c_int, [_CD, I32, _PO, _VP, _VP, _VP, _VP, _FP, _FP, _FP, _VP]),
+    'qk_conv_prelu_pool_bwd': (ctypes.c_int, [_CD, I32, _PO, _VP, _VP, _VP, _VP, _FP, _FP, _FP, I32, _VP]),
     'qk_dense_fwd': (ctypes.c_int, [_DD, _VP, _FP, _FP, _VP, _VP, _SZ, _VP]),
     'qk_dense_bwd_data': (ctypes.c_int, [_DD, _VP, _VP, _FP, _VP, _VP, _SZ, _VP]),
     'qk_dense_bwd_weight': (ctypes.c_int, [_DD, _VP, _VP, _VP, _FP, _FP, _VP, _SZ, _VP]),

@@ -704,7 +704,8 @@ int qk_dense_bwd_weight(const qk_dense_desc_t *desc, const void *x, const void *
 
 static bool conv1_pool_ok(const qk_conv_desc_t *d, int32_t pool, int act = QK_ACT_RELU)
 {
-    return d->rank == 2 && d->layout == QK_CH_LAST && (d->dtype == QK_BF16 || d->dtype == QK_F16) && d->cq == 1 &&
+    // layout QK_CH_FIRST here describes x ONLY: (N, 4, H, W), the four component planes; the pooled tensor is channels_last
+    return d->rank == 2 && (d->dtype == QK_BF16 || d->dtype == QK_F16) && d->cq == 1 &&
            d->kernel[0] == 3 && d->kernel[1] == 5 && d->stride[0] == 1 && d->stride[1] == 1 && d->dilation[0] == 1 &&
            d->dilation[1] == 1 && d->pad_lo[0] == 1 && d->pad_lo[1] == 2 && d->out_spatial[0] == d->in_spatial[0] &&
            d->out_spatial[1] == d->in_spatial[1] && d->activation == act && d->conj == 0 && d->fq % 32 == 0 && pool == 3 &&
@@ -730,25 +731,29 @@ int qk_conv_relu_pool_fwd(const qk_conv_desc_t *desc, int32_t pool, const void *
     note_path(QK_PATH_MFMA16);
     ProfScope prof_scope(QK_OP_FWD, desc, (hipStream_t)stream);
     return check_launch(launch_conv1_pool(desc->dtype, false, x, w, bias, pooled, aux, nullptr, nullptr, desc->batch, desc->in_spatial[0],
-                                          desc->in_spatial[1], desc->fq, desc->has_bias, (hipStream_t)stream), "qk_conv_relu_pool_fwd");
+                                          desc->in_spatial[1], desc->fq, desc->has_bias, (hipStream_t)stream, nullptr, 0, nullptr, nullptr,
+                                          desc->layout == QK_CH_FIRST), "qk_conv_relu_pool_fwd");
 }
 
 int qk_conv_relu_pool_bwd(const qk_conv_desc_t *desc, int32_t pool, const void *x, const void *dpooled, const void *aux,
-                          float *dw, float *dbias, void *stream)
+                          float *dw, float *dbias, int32_t flags, void *stream)
 {
     if (int rc = validate(desc, false)) return rc;
+    if (flags & ~QK_BWD_ACCUMULATE) { set_error("qk_conv_relu_pool_bwd: only QK_BWD_ACCUMULATE is a valid flag (0x%x)", flags); return QK_ERR_INVALID_ARG; }
     if (!conv1_pool_ok(desc, pool)) { set_error("qk_conv_relu_pool: geometry outside the fused first-layer kernel (see include/qk.h)"); return QK_ERR_UNSUPPORTED; }
     if (!x || !dpooled || !aux || !dw || (desc->has_bias && !dbias)) { set_error("qk_conv_relu_pool_bwd: NULL argument"); return QK_ERR_INVALID_ARG; }
     if (!aligned(x, 8) || !aligned(dpooled, 16) || !aligned(aux, 16)) { set_error("qk_conv_relu_pool_bwd: alignment"); return QK_ERR_INVALID_ARG; }
     hipStream_t st = (hipStream_t)stream;
     note_path(QK_PATH_MFMA16);
     ProfScope prof_scope(QK_OP_BWD_WEIGHT, desc, st);
-    if (hipMemsetAsync(dw, 0, w_floats(desc) * sizeof(float), st) != hipSuccess ||
-        (desc->has_bias && hipMemsetAsync(dbias, 0, 4 * (size_t)desc->fq * sizeof(float), st) != hipSuccess)) {
+    if (!(flags & QK_BWD_ACCUMULATE) &&
+        (hipMemsetAsync(dw, 0, w_floats(desc) * sizeof(float), st) != hipSuccess ||
+         (desc->has_bias && hipMemsetAsync(dbias, 0, 4 * (size_t)desc->fq * sizeof(float), st) != hipSuccess))) {
         set_error("memset dw failed"); return QK_ERR_LAUNCH;
     }
     return check_launch(launch_conv1_pool(desc->dtype, true, x, nullptr, nullptr, dpooled, const_cast<void *>(aux), dw, desc->has_bias ? dbias : nullptr,
-                                          desc->batch, desc->in_spatial[0], desc->in_spatial[1], desc->fq, desc->has_bias, st), "qk_conv_relu_pool_bwd");
+                                          desc->batch, desc->in_spatial[0], desc->in_spatial[1], desc->fq, desc->has_bias, st, nullptr, 0, nullptr,
+                                          nullptr, desc->layout == QK_CH_FIRST), "qk_conv_relu_pool_bwd");
 }
 
 // PReLU form of the fused first layer: slopes per row of the conv output (alpha_axis 0, alpha_len == in_spatial[0] <= 64)
@@ -775,13 +780,14 @@ int qk_conv_prelu_pool_fwd(const qk_conv_desc_t *desc, int32_t pool, const qk_po
     ProfScope prof_scope(QK_OP_FWD, desc, (hipStream_t)stream);
     return check_launch(launch_conv1_pool(desc->dtype, false, x, w, bias, pooled, aux, nullptr, nullptr, desc->batch, desc->in_spatial[0],
                                           desc->in_spatial[1], desc->fq, desc->has_bias, (hipStream_t)stream, post->alpha, post->alpha_len,
-                                          pre_pooled, nullptr), "qk_conv_prelu_pool_fwd");
+                                          pre_pooled, nullptr, desc->layout == QK_CH_FIRST), "qk_conv_prelu_pool_fwd");
 }
 
 int qk_conv_prelu_pool_bwd(const qk_conv_desc_t *desc, int32_t pool, const qk_postop_t *post, const void *x, const void *dpooled,
-                           const void *pre_pooled, const void *aux, float *dw, float *dbias, float *dalpha, void *stream)
+                           const void *pre_pooled, const void *aux, float *dw, float *dbias, float *dalpha, int32_t flags, void *stream)
 {
     if (int rc = validate(desc, false)) return rc;
+    if (flags & ~QK_BWD_ACCUMULATE) { set_error("qk_conv_prelu_pool_bwd: only QK_BWD_ACCUMULATE is a valid flag (0x%x)", flags); return QK_ERR_INVALID_ARG; }
     if (!conv1_pool_ok(desc, pool, QK_ACT_LINEAR)) { set_error("qk_conv_prelu_pool: geometry outside the fused first-layer kernel (see include/qk.h)"); return QK_ERR_UNSUPPORTED; }
     if (int rc = prelu_pool_post_ok(desc, post)) return rc;
     if (!x || !dpooled || !pre_pooled || !aux || !dw || (desc->has_bias && !dbias)) { set_error("qk_conv_prelu_pool_bwd: NULL argument"); return QK_ERR_INVALID_ARG; }
@@ -789,13 +795,14 @@ int qk_conv_prelu_pool_bwd(const qk_conv_desc_t *desc, int32_t pool, const qk_po
     hipStream_t st = (hipStream_t)stream;
     note_path(QK_PATH_MFMA16);
     ProfScope prof_scope(QK_OP_BWD_WEIGHT, desc, st);
-    if (hipMemsetAsync(dw, 0, w_floats(desc) * sizeof(float), st) != hipSuccess ||
-        (desc->has_bias && hipMemsetAsync(dbias, 0, 4 * (size_t)desc->fq * sizeof(float), st) != hipSuccess)) {
+    if (!(flags & QK_BWD_ACCUMULATE) &&
+        (hipMemsetAsync(dw, 0, w_floats(desc) * sizeof(float), st) != hipSuccess ||
+         (desc->has_bias && hipMemsetAsync(dbias, 0, 4 * (size_t)desc->fq * sizeof(float), st) != hipSuccess))) {
         set_error("memset dw failed"); return QK_ERR_LAUNCH;
     }
     return check_launch(launch_conv1_pool(desc->dtype, true, x, nullptr, nullptr, dpooled, const_cast<void *>(aux), dw, desc->has_bias ? dbias : nullptr,
                                           desc->batch, desc->in_spatial[0], desc->in_spatial[1], desc->fq, desc->has_bias, st, post->alpha,
-                                          post->alpha_len, pre_pooled, dalpha), "qk_conv_prelu_pool_bwd");
+                                          post->alpha_len, pre_pooled, dalpha, desc->layout == QK_CH_FIRST), "qk_conv_prelu_pool_bwd");
 }
 
 int qk_conv_fold_taps(const qk_conv_desc_t *desc, const void *x, void *xcol, int32_t cq2, void *stream)

@@ -231,7 +231,8 @@ int launch_maxpool(int dtype, bool backward, const void *x, const void *dy, void
 size_t conv1_pool_argbits_bytes(int N, int H, int W, int F);
 int launch_conv1_pool(int dtype, bool backward, const void *x, const float *w, const float *bias, const void *io, void *argbits,
                       float *dw, float *dbias, int N, int H, int W, int F, int has_bias, hipStream_t stream,
-                      const float *alpha = nullptr, int alpha_len = 0, const void *pre = nullptr, float *dalpha = nullptr);
+                      const float *alpha = nullptr, int alpha_len = 0, const void *pre = nullptr, float *dalpha = nullptr,
+                      int x_planes = 0);
 int launch_postop(int dtype, bool backward, const void *pre, const void *dy, void *out, float *dalpha, const PostOp &p,
                   long long rows, int channels, int key_div, int key_mod, hipStream_t stream);
 int launch_adam(float *p, float *g, float *m, float *v, const float *decay, size_t n, float lr, float b1,

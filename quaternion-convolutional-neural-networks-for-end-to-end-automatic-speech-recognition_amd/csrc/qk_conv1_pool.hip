@@ -60,6 +60,8 @@ struct C1Geom {
     // PRELU variants: slopes (one, or one per row f of the conv output: Keras shared_axes=[1,0] on (C, F, T))
     const float *alpha;
     int alpha_len;
+    int x_planes;              // x is (N, 4, H, W): the four component PLANES of the one quaternion channel (channels_first,
+                               // how the reference feeds the model: Input(shape=(4, 41, None)), interspeech_model.py:81)
 };
 
 constexpr int C1_TW = 224;                 // positions per workgroup (7 waves x 32)
@@ -73,9 +75,48 @@ struct C1 {
     static constexpr int PATCH_BYTES = NR * C1_PW * 8;
 
     // x rows [PH*ho - PADH, +NR) x positions [t0 - PADW, +C1_PW) of sample n -> LDS, zeros outside the tensor
+    // x_planes: the r, i, j, k planes are read as they lie -- per plane and patch row a run of consecutive positions,
+    // two positions (4 bytes) per lane and plane, i.e. coalesced 256-byte segments per wave and plane, the four loads of a
+    // lane in flight together -- and interleaved with v_perm_b32 into the same [position][component] LDS image (two 8-byte
+    // stores); odd W or an odd first position falls back to one position per load.
     static __device__ __forceinline__ void stage_patch(const T *__restrict__ x, char *patch, const C1Geom &g, int n, int ho, int t0, int tid, int nthr)
     {
         const int f_lo = PH * ho - PADH;
+        if (g.x_planes) {
+            constexpr int HALF = C1_PW / 2;
+            static_assert(C1_PW % 2 == 0, "patch width in position pairs");
+            const bool pairs = ((g.W | (t0 - PADW)) & 1) == 0;             // both positions of a pair share the 4-byte word
+            const long long plane = (long long)g.H * g.W;
+            for (int e0 = tid; e0 < NR * HALF; e0 += nthr) {
+                int e = e0;
+                asm volatile("" : "+v"(e));
+                const int r = e / HALF, c2 = e - r * HALF;
+                const int f = f_lo + r, t = t0 - PADW + 2 * c2;
+                unsigned w4[4] = {0u, 0u, 0u, 0u};                          // plane a: positions t (low half), t + 1 (high half)
+                if (f >= 0 && f < g.H) {
+                    const T *row = x + ((long long)n * 4 * g.H + f) * g.W;
+                    if (pairs && t >= 0 && t + 1 < g.W) {
+#pragma unroll
+                        for (int a = 0; a < 4; ++a) w4[a] = *reinterpret_cast<const unsigned *>(row + a * plane + t);   // four loads in flight
+                    } else {
+#pragma unroll
+                        for (int a = 0; a < 4; ++a) {
+                            unsigned lo = 0u, hi = 0u;
+                            if (t >= 0 && t < g.W) lo = __builtin_bit_cast(unsigned short, row[a * plane + t]);
+                            if (t + 1 >= 0 && t + 1 < g.W) hi = __builtin_bit_cast(unsigned short, row[a * plane + t + 1]);
+                            w4[a] = lo | (hi << 16);
+                        }
+                    }
+                }
+                // [position][component] image: two 8-byte stores (r | i, j | k of position t, then of position t + 1)
+                const uint2 p0 = make_uint2(__builtin_amdgcn_perm(w4[1], w4[0], 0x05040100u), __builtin_amdgcn_perm(w4[3], w4[2], 0x05040100u));
+                const uint2 p1 = make_uint2(__builtin_amdgcn_perm(w4[1], w4[0], 0x07060302u), __builtin_amdgcn_perm(w4[3], w4[2], 0x07060302u));
+                char *dst = patch + (r * C1_PW + 2 * c2) * 8;
+                *reinterpret_cast<uint2 *>(dst) = p0;
+                *reinterpret_cast<uint2 *>(dst + 8) = p1;
+            }
+            return;
+        }
         for (int e0 = tid; e0 < NR * C1_PW; e0 += nthr) {
             int e = e0;
             asm volatile("" : "+v"(e));                            // (opaque, see k_conv1_pool_bwd)
@@ -475,10 +516,10 @@ size_t conv1_pool_argbits_bytes(int N, int H, int W, int F)
 
 int launch_conv1_pool(int dtype, bool backward, const void *x, const float *w, const float *bias, const void *io, void *argbits,
                       float *dw, float *dbias, int N, int H, int W, int F, int has_bias, hipStream_t stream,
-                      const float *alpha, int alpha_len, const void *pre, float *dalpha)
+                      const float *alpha, int alpha_len, const void *pre, float *dalpha, int x_planes)
 {
     C1Geom g;
-    g.N = N; g.H = H; g.W = W; g.F = F; g.has_bias = has_bias;
+    g.N = N; g.H = H; g.W = W; g.F = F; g.has_bias = has_bias; g.x_planes = x_planes;
     g.Ho = (H + 2) / 3;
     g.n_chunks = (W + C1_TW - 1) / C1_TW;
     g.n_lines = N * g.Ho * g.n_chunks;

@@ -558,10 +558,11 @@ class _ConvReluPoolFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, bias, call, pool):
-        n, h, wd, _ = x.shape
+        n, h, wd = call.desc.batch, call.desc.in_spatial[0], call.desc.in_spatial[1]      # (x: (N, H, W, 4) or planes (N, 4, H, W))
         out = torch.empty((n, -(-h // pool), wd, w.shape[-1]), dtype=x.dtype, device=x.device)
         nb = int(L.lib().qk_conv_relu_pool_aux_bytes(ctypes.byref(call.desc), pool))
         keep = any(ctx.needs_input_grad[1:3])
+        ctx.params = (w, bias)
         aux = torch.empty(nb, dtype=torch.uint8, device=x.device) if keep else None
         with _on_device(x.device):
             rc = L.lib().qk_conv_relu_pool_fwd(ctypes.byref(call.desc), pool, _ptr(x), _ptr(w), _ptr(bias), _ptr(out), _ptr(aux), _stream(x))
@@ -575,40 +576,61 @@ class _ConvReluPoolFn(torch.autograd.Function):
     def backward(ctx, dout):
         x, aux = ctx.saved_tensors
         dout = dout.contiguous()
-        dw = torch.empty(ctx.w_shape, dtype=torch.float32, device=x.device)
-        db = torch.empty((ctx.w_shape[-1],), dtype=torch.float32, device=x.device) if ctx.has_bias else None
+        direct = _direct_grad(ctx.params[0], ctx.params[1], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2])
+        if direct is not None:
+            dw, db = direct
+        else:
+            dw = torch.empty(ctx.w_shape, dtype=torch.float32, device=x.device)
+            db = torch.empty((ctx.w_shape[-1],), dtype=torch.float32, device=x.device) if ctx.has_bias else None
         with _on_device(x.device):
-            rc = L.lib().qk_conv_relu_pool_bwd(ctypes.byref(ctx.call.desc), ctx.pool, _ptr(x), _ptr(dout), _ptr(aux), _ptr(dw), _ptr(db), _stream(x))
+            rc = L.lib().qk_conv_relu_pool_bwd(ctypes.byref(ctx.call.desc), ctx.pool, _ptr(x), _ptr(dout), _ptr(aux), _ptr(dw), _ptr(db),
+                                               L.QK_BWD_ACCUMULATE if direct is not None else 0, _stream(x))
         L.check(rc, 'qk_conv_relu_pool_bwd')
+        if direct is not None:
+            _grad_ready(*ctx.params)
+            return None, None, None, None, None
         return None, dw, db, None, None
 
 
-def conv_relu_pool_supported(x, kernel, pool):
+def _first_layer_call(x, kernel, activation, use_bias, x_layout):
+    """Descriptor of the fused first layer; x_layout 'channels_last' = (N, H, W, 4), 'channels_first' = the four component
+    planes (N, 4, H, W) read as they lie (include/qk.h: for these entry points desc.layout describes x only)."""
+    if x_layout == 'channels_first':
+        n, c, h, w = x.shape
+        call = conv_call((n, h, w, c), tuple(kernel.shape), x.dtype, 2, 1, 'same', 'channels_last', 1, activation, use_bias, False)
+        call.desc.layout = L.QK_CH_FIRST
+        return call
+    return conv_call(tuple(x.shape), tuple(kernel.shape), x.dtype, 2, 1, 'same', 'channels_last', 1, activation, use_bias, False)
+
+
+def conv_relu_pool_supported(x, kernel, pool, x_layout='channels_last'):
     """True when relu(QuaternionConv2D(kernel, 'same')(x)) followed by MaxPooling over the first spatial axis (window =
     stride = pool, 'same') can run as the fused first-layer kernels: x a contiguous channels_last (N, H, W, 4) 16-bit
     device tensor that needs no gradient, kernel (3, 5, 1, 4F) with F % 32 == 0, pool == 3, and a height whose
     TensorFlow 'same' pooling pads on the high side only (H % 3 != 1: the kernel's windows start at row 0).  The
     answer is the C side's (qk_conv_relu_pool_aux_bytes is non-zero exactly for the geometries it takes), so the
     two predicates cannot drift apart."""
-    if not (x.is_cuda and x.dtype in (torch.bfloat16, torch.float16) and x.dim() == 4 and x.shape[-1] == 4 and not x.requires_grad
+    ch_axis, h_axis = (1, 2) if x_layout == 'channels_first' else (-1, 1)
+    if not (x.is_cuda and x.dtype in (torch.bfloat16, torch.float16) and x.dim() == 4 and x.shape[ch_axis] == 4 and not x.requires_grad
             and kernel.dim() == 4 and tuple(kernel.shape[:3]) == (3, 5, 1) and kernel.shape[-1] % 4 == 0 and x.shape[0] > 0):
         return False
-    if tf_pads(x.shape[1], pool, pool, 1, 'same')[0] != 0:
+    if tf_pads(x.shape[h_axis], pool, pool, 1, 'same')[0] != 0:
         return False
     try:
-        call = conv_call(tuple(x.shape), tuple(kernel.shape), x.dtype, 2, 1, 'same', 'channels_last', 1, 'relu', True, False)
+        call = _first_layer_call(x, kernel, 'relu', True, x_layout)
     except ValueError:
         return False
     return int(L.lib().qk_conv_relu_pool_aux_bytes(ctypes.byref(call.desc), pool)) > 0
 
 
-def conv_relu_pool(x, kernel, bias=None, pool=3):
-    """(N, H, W, 4) -> (N, ceil(H / pool), W, 4F): the first TIMIT layer and its frequency pooling in one kernel
-    (include/qk.h: qk_conv_relu_pool_*).  Check conv_relu_pool_supported first."""
+def conv_relu_pool(x, kernel, bias=None, pool=3, x_layout='channels_last'):
+    """(N, H, W, 4) -- or, with x_layout='channels_first', the component planes (N, 4, H, W) as the reference's model
+    receives them -- -> channels_last (N, ceil(H / pool), W, 4F): the first TIMIT layer and its frequency pooling in one
+    kernel (include/qk.h: qk_conv_relu_pool_*).  Check conv_relu_pool_supported first."""
     _require_device(x, 'conv_relu_pool')
     _check_weights(kernel, bias, kernel.shape[-1])
     xc = x.contiguous()
-    call = conv_call(tuple(xc.shape), tuple(kernel.shape), xc.dtype, 2, 1, 'same', 'channels_last', 1, 'relu', bias is not None, False)
+    call = _first_layer_call(xc, kernel, 'relu', bias is not None, x_layout)
     if not L.lib().qk_conv_relu_pool_aux_bytes(ctypes.byref(call.desc), pool):
         raise RuntimeError('conv_relu_pool: geometry outside the fused first-layer kernel')
     return _ConvReluPoolFn.apply(xc, kernel.contiguous(), bias, call, pool)
@@ -620,7 +642,8 @@ class _ConvPreluPoolFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, bias, alpha, call, pool, post):
-        n, h, wd, _ = x.shape
+        n, h, wd = call.desc.batch, call.desc.in_spatial[0], call.desc.in_spatial[1]
+        ctx.params = (w, bias)
         out = torch.empty((n, -(-h // pool), wd, w.shape[-1]), dtype=x.dtype, device=x.device)
         nb = int(L.lib().qk_conv_relu_pool_aux_bytes(ctypes.byref(call.desc), pool))
         keep = any(ctx.needs_input_grad[1:4])
@@ -640,31 +663,40 @@ class _ConvPreluPoolFn(torch.autograd.Function):
         x, aux, pre = ctx.saved_tensors
         dout = dout.contiguous()
         post = ctx.post
-        dw = torch.empty(ctx.w_shape, dtype=torch.float32, device=x.device)
-        db = torch.empty((ctx.w_shape[-1],), dtype=torch.float32, device=x.device) if ctx.has_bias else None
+        direct = _direct_grad(ctx.params[0], ctx.params[1], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2])
+        if direct is not None:
+            dw, db = direct
+        else:
+            dw = torch.empty(ctx.w_shape, dtype=torch.float32, device=x.device)
+            db = torch.empty((ctx.w_shape[-1],), dtype=torch.float32, device=x.device) if ctx.has_bias else None
         da = torch.zeros(post.flat.numel(), dtype=torch.float32, device=x.device)
         with _on_device(x.device):
             rc = L.lib().qk_conv_prelu_pool_bwd(ctypes.byref(ctx.call.desc), ctx.pool, ctypes.byref(post.struct), _ptr(x), _ptr(dout),
-                                                _ptr(pre), _ptr(aux), _ptr(dw), _ptr(db), _ptr(da), _stream(x))
+                                                _ptr(pre), _ptr(aux), _ptr(dw), _ptr(db), _ptr(da),
+                                                L.QK_BWD_ACCUMULATE if direct is not None else 0, _stream(x))
         L.check(rc, 'qk_conv_prelu_pool_bwd')
+        if direct is not None:
+            _grad_ready(*ctx.params)
+            return None, None, None, da.reshape(post.alpha.shape), None, None, None
         return None, dw, db, da.reshape(post.alpha.shape), None, None, None
 
 
-def conv_prelu_pool_supported(x, kernel, alpha, alpha_axis, pool):
+def conv_prelu_pool_supported(x, kernel, alpha, alpha_axis, pool, x_layout='channels_last'):
     """conv_relu_pool_supported for the PReLU form: float32 device slopes, one (alpha_axis -1) or one per position of
     the first spatial axis (alpha_axis 0, at most 64)."""
     n = alpha.numel()
-    return (conv_relu_pool_supported(x, kernel, pool) and alpha.is_cuda and alpha.dtype == torch.float32 and
-            ((alpha_axis == -1 and n == 1) or (alpha_axis == 0 and n == x.shape[1] and n <= 64)))
+    h = x.shape[2] if x_layout == 'channels_first' else x.shape[1]
+    return (conv_relu_pool_supported(x, kernel, pool, x_layout) and alpha.is_cuda and alpha.dtype == torch.float32 and
+            ((alpha_axis == -1 and n == 1) or (alpha_axis == 0 and n == h and n <= 64)))
 
 
-def conv_prelu_pool(x, kernel, bias, alpha, alpha_axis=0, pool=3):
-    """(N, H, W, 4) -> (N, ceil(H / pool), W, 4F): linear first layer + PReLU + frequency pooling in one kernel
-    (include/qk.h: qk_conv_prelu_pool_*).  Check conv_prelu_pool_supported first."""
+def conv_prelu_pool(x, kernel, bias, alpha, alpha_axis=0, pool=3, x_layout='channels_last'):
+    """(N, H, W, 4) [or planes (N, 4, H, W), x_layout='channels_first'] -> (N, ceil(H / pool), W, 4F): linear first layer +
+    PReLU + frequency pooling in one kernel (include/qk.h: qk_conv_prelu_pool_*).  Check conv_prelu_pool_supported first."""
     _require_device(x, 'conv_prelu_pool')
     _check_weights(kernel, bias, kernel.shape[-1])
     xc = x.contiguous()
-    call = conv_call(tuple(xc.shape), tuple(kernel.shape), xc.dtype, 2, 1, 'same', 'channels_last', 1, None, bias is not None, False)
+    call = _first_layer_call(xc, kernel, None, bias is not None, x_layout)
     post = PostOp(alpha, alpha_axis, 0.0, 0)
     return _ConvPreluPoolFn.apply(xc, kernel.contiguous(), bias, alpha, call, pool, post)
 

@@ -130,14 +130,16 @@ class TimitQCNN(torch.nn.Module):
         if not c.built:
             c._build_device = x.device
             c.build(tuple(x.shape))
-        xl = x.movedim(1, -1)                                        # (B, F, T, 4): the channels-last buffer
+        # a plain channels_first buffer (how the reference's callers hold the features) is read plane by plane by the
+        # kernel itself; a channels-last buffer behind a channels_first view (an upstream engine layer) is taken as it is
+        xl, lay = (x, 'channels_first') if x.is_contiguous() else (x.movedim(1, -1), 'channels_last')
         ok = (activations.serialize(c.activation) == 'relu' and c.padding == 'same' and c.strides == (1, 1) and
               c.dilation_rate == (1, 1) and c.internal_layout == 'channels_last' and pl.pool_size == (1, 3) and
               pl.strides == (1, 3) and pl.padding == 'same' and pl.data_format == 'channels_last' and
-              Fq.conv_relu_pool_supported(xl, c.kernel, 3))
+              Fq.conv_relu_pool_supported(xl, c.kernel, 3, lay))
         if not ok:
             return None
-        return Fq.conv_relu_pool(xl, c.kernel, c.bias, 3).movedim(-1, 1)
+        return Fq.conv_relu_pool(xl, c.kernel, c.bias, 3, lay).movedim(-1, 1)
 
     def _forward_fused_post(self, x):
         """The activation + Dropout behind every layer fused into the quaternion kernels.
@@ -158,19 +160,19 @@ class TimitQCNN(torch.nn.Module):
         relu_form = self.prelu is None
         post0 = self._post(0, shape, dropout=False)
         pl = self.pool
-        xl = x.movedim(1, -1)                                        # (B, F, T, 4): the channels-last buffer
+        xl, lay = (x, 'channels_first') if x.is_contiguous() else (x.movedim(1, -1), 'channels_last')   # see _first_layer_fused
         o = self._first_layer_fused(x) if relu_form else None
         fused_first = (not relu_form and
                        not os.environ.get('QK_NO_FUSED_FIRST') and x.dim() == 4 and c.padding == 'same' and c.strides == (1, 1) and
                        c.dilation_rate == (1, 1) and c.internal_layout == 'channels_last' and pl.pool_size == (1, 3) and
                        pl.strides == (1, 3) and pl.padding == 'same' and pl.data_format == 'channels_last' and
-                       Fq.conv_prelu_pool_supported(xl, c.kernel, post0['alpha'], post0['alpha_axis'], 3))
+                       Fq.conv_prelu_pool_supported(xl, c.kernel, post0['alpha'], post0['alpha_axis'], 3, lay))
         if o is not None:
             pass             # conv + relu + frequency pooling ran as one kernel per direction (qk_conv_relu_pool_*)
         elif relu_form:
             o = self.pool(c(x))
         elif fused_first:    # linear conv + PReLU + frequency pooling as ONE kernel per direction (qk_conv_prelu_pool_*)
-            o = Fq.conv_prelu_pool(xl, c.kernel, c.bias, post0['alpha'], post0['alpha_axis'], 3).movedim(-1, 1)
+            o = Fq.conv_prelu_pool(xl, c.kernel, c.bias, post0['alpha'], post0['alpha_axis'], 3, lay).movedim(-1, 1)
         else:
             o = Fq.quaternion_conv(x, c.kernel, c.bias, strides=c.strides, padding=c.padding, data_format='channels_first',
                                    dilation_rate=c.dilation_rate, activation=None, post=post0)

@@ -1203,10 +1203,11 @@ def _np_pool_h_same(y, pool=3):
     return p, arg
 
 
+@pytest.mark.parametrize('planes', [False, True], ids=['x_channels_last', 'x_component_planes'])
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16], ids=['bf16', 'fp16'])
 @pytest.mark.parametrize('shape,F', [((3, 41, 50, 4), 32), ((2, 9, 230, 4), 64), ((1, 8, 19, 4), 32)],
-                         ids=['timit_small', 'two_chunks_two_column_tiles', 'partial_window'])
-def test_fused_first_layer_conv_relu_pool_matches_oracle(shape, F, dtype):
+                         ids=['timit_small', 'two_chunks_two_column_tiles', 'partial_window_odd_width'])
+def test_fused_first_layer_conv_relu_pool_matches_oracle(shape, F, dtype, planes):
     """qk_conv_relu_pool_fwd / _bwd (conv (3,5) 'same' + relu + max-pool (3,1) 'same' over H, one kernel per direction,
     no pre-pool tensor) against oracle conv + numpy pooling: pooled values, d kernel, d bias.  Widths beyond one
     224-position chunk, two 32-filter column tiles and a partial last window are covered."""
@@ -1231,8 +1232,12 @@ def test_fused_first_layer_conv_relu_pool_matches_oracle(shape, F, dtype):
     xt = torch.tensor(x, device=dev).to(dtype)
     wt = torch.tensor(w, device=dev, dtype=torch.float32, requires_grad=True)
     bt = torch.tensor(b, device=dev, dtype=torch.float32, requires_grad=True)
-    assert Fq.conv_relu_pool_supported(xt, wt, 3)
-    out = Fq.conv_relu_pool(xt, wt, bt, 3)
+    if planes:          # the reference's own input layout: (N, 4, H, W), the four component planes (interspeech_model.py:81)
+        xt, lay = xt.permute(0, 3, 1, 2).contiguous(), 'channels_first'
+    else:
+        lay = 'channels_last'
+    assert Fq.conv_relu_pool_supported(xt, wt, 3, lay)
+    out = Fq.conv_relu_pool(xt, wt, bt, 3, lay)
     out.backward(torch.tensor(dp, device=dev).to(dtype))
     tol16, tol32 = (1e-2, 4e-3) if dtype == torch.bfloat16 else (2e-3, 2e-3)
     assert tuple(out.shape) == pooled.shape
@@ -1244,7 +1249,8 @@ def test_fused_first_layer_conv_relu_pool_matches_oracle(shape, F, dtype):
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16], ids=['bf16', 'fp16'])
 @pytest.mark.parametrize('shape,F,per_row', [((3, 41, 50, 4), 32, True), ((2, 8, 230, 4), 64, True), ((2, 11, 33, 4), 32, False)],
                          ids=['41x50_f32', '8x230_f64', '11x33_scalar'])
-def test_fused_first_layer_conv_prelu_pool_matches_oracle(shape, F, per_row, dtype):
+@pytest.mark.parametrize('planes', [False, True], ids=['x_channels_last', 'x_component_planes'])
+def test_fused_first_layer_conv_prelu_pool_matches_oracle(shape, F, per_row, dtype, planes):
     """qk_conv_prelu_pool_fwd / _bwd (linear conv (3,5) 'same' + PReLU with one slope per frequency row, or one slope +
     max-pool (3,1) 'same' over H, one kernel per direction) against oracle conv + numpy PReLU / pooling: pooled values,
     d kernel, d bias, d alpha.  Slopes of both signs (a negative slope makes PReLU non-monotonic: the maximum must be
@@ -1277,8 +1283,11 @@ def test_fused_first_layer_conv_prelu_pool_matches_oracle(shape, F, per_row, dty
     bt = torch.tensor(b, device=dev, dtype=torch.float32, requires_grad=True)
     at = torch.tensor(alpha.reshape((1, H, 1) if per_row else (1, 1, 1)), device=dev, dtype=torch.float32, requires_grad=True)
     axis = 0 if per_row else -1
-    assert Fq.conv_prelu_pool_supported(xt, wt, at, axis, 3)
-    out = Fq.conv_prelu_pool(xt, wt, bt, at, axis, 3)
+    lay = 'channels_last'
+    if planes:
+        xt, lay = xt.permute(0, 3, 1, 2).contiguous(), 'channels_first'
+    assert Fq.conv_prelu_pool_supported(xt, wt, at, axis, 3, lay)
+    out = Fq.conv_prelu_pool(xt, wt, bt, at, axis, 3, lay)
     out.backward(torch.tensor(dp, device=dev).to(dtype))
     tol16, tol32 = (1e-2, 5e-3) if dtype == torch.bfloat16 else (2e-3, 2e-3)
     assert tuple(out.shape) == pooled.shape
