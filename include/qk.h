@@ -124,6 +124,11 @@ const char *qk_last_error(void);
 #define QK_DBG_WGRAD16_ONE_TAP 8u
 #define QK_DBG_NO_WGRAD_BAND 32u   /* 16-bit backward-weight: one block per tap (k_wgrad16) instead of the band kernel */
 #define QK_DBG_NO_POINT16 64u
+#define QK_DBG_DETERMINISTIC 0x10000u /* bit-reproducible gradients (env QK_DETERMINISTIC): every backward-weight kernel runs
+                                         * ONE split of the reduction per gradient tile and one owner per bias column, so
+                                         * each element of dw / dbias receives exactly one (atomic) addition -- no
+                                         * order-dependent float sums.  Several times slower (the reduction over positions is
+                                         * no longer spread over the CUs): for debugging and for repeatability tests. */
 #define QK_DBG_BAND16_8WAVES 16u   /* 16-bit band kernels: 8-wave workgroups (one per CU) instead of 4-wave (two per CU) */
 unsigned qk_set_debug_flags(unsigned flags);
 unsigned qk_get_debug_flags(void);

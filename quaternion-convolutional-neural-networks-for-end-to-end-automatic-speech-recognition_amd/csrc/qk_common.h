@@ -158,6 +158,7 @@ struct WgradGeom {
     int m_per_split;    // rows of M each split reduces (multiple of the kernel's K step)
     int n_splits;
     int ablate;         // profiling only (env QK_ABLATE): 1 = skip fold + atomics, 2 = skip HBM atomics
+    int deterministic;  // QK_DBG_DETERMINISTIC: n_splits == 1 and ONE owner block per bias column / masked-dY row
     unsigned x_bytes, dy_bytes;   // extents of x and of dy / y / dym (buffer-resource bounds of the 16-bit kernel)
     // band variant (qk_wgrad_band_bf16mfma.hip): positions run over padded lines of the innermost axis (b_wp per
     // line, b_nlines lines); band row j of a tile holds input column (padded position + b_cshift)
@@ -248,7 +249,7 @@ void note_path(int qk_path);          // thread-local record behind qk_last_path
 enum : unsigned {
     kDbgNoMfma16 = QK_DBG_NO_MFMA16, kDbgNoBand16 = QK_DBG_NO_BAND16, kDbgNoBand32 = QK_DBG_NO_BAND32,
     kDbgWgradOneTap = QK_DBG_WGRAD16_ONE_TAP, kDbgBand8Waves = QK_DBG_BAND16_8WAVES, kDbgNoWgradBand = QK_DBG_NO_WGRAD_BAND,
-    kDbgNoPoint16 = QK_DBG_NO_POINT16, kDbgAblateShift = 8, kDbgAblateMask = 0xffu << 8
+    kDbgNoPoint16 = QK_DBG_NO_POINT16, kDbgDeterministic = QK_DBG_DETERMINISTIC, kDbgAblateShift = 8, kDbgAblateMask = 0xffu << 8
 };
 unsigned debug_flags();
 inline int debug_ablate() { return (int)((debug_flags() & kDbgAblateMask) >> kDbgAblateShift); }

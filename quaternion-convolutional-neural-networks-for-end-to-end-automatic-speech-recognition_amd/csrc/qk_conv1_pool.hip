@@ -495,6 +495,7 @@ int run_conv1_pool(bool backward, const void *x, const float *w, const float *bi
     } else {
         int blocks = 2 * device_cu_count();                        // 70 - 78 KB of LDS: two workgroups per CU
         if (blocks > g.n_lines) blocks = g.n_lines;
+        if (debug_flags() & kDbgDeterministic) blocks = 1;         // one flush per gradient element: no order-dependent sums
         dim3 grid((unsigned)blocks, (unsigned)(g.F / 32), 1);
         hipLaunchKernelGGL((k_conv1_pool_bwd<T, 3, 5, 3, PRELU>), grid, dim3(448), 0, stream, (const T *)x, (const T *)io, (const T *)pre,
                            (const uint4 *)argbits, dw, dbias, dalpha, g);

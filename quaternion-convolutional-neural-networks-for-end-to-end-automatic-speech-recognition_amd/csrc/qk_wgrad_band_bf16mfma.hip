@@ -109,9 +109,12 @@ k_wgrad16_band(const T *__restrict__ x, const T *__restrict__ dy, const T *__res
     const int p_end = min(g.b_nlines * WP, p_begin + g.m_per_split);
     // the blocks that stage the same dY tiles -- (outer tap, channel chunk) of one (split, filter chunk) -- take turns
     // at the bias gradient and at the masked-dY side output (one owner would set the kernel time)
-    const int n_share = n_ot * ncc;
+    // (deterministic mode: ONE owner -- the block of outer tap 0 / channel chunk 0 -- takes every turn, so each bias
+    //  column receives a single addition; the others never do)
+    const bool share0 = ot * ncc + cchunk == 0;
+    const int n_share = g.deterministic ? (share0 ? 1 : (1 << 30)) : n_ot * ncc;
     const bool bias_blk = g.want_dbias != 0, dym_blk = MASK && g.dym != nullptr;
-    int turn = ot * ncc + cchunk;                   // 0 => this K step is ours
+    int turn = g.deterministic ? (share0 ? 0 : (1 << 29)) : ot * ncc + cchunk;      // 0 => this K step is ours
 
     // ---- staging: 8 threads per position, 16-byte units -------------------------------------------------------
     constexpr int UC = CQB / 8, UF = BF / 8;        // units per component block of an X / dY row
@@ -335,6 +338,8 @@ int run_wgrad16_band(const T *x, const T *dy, const T *ymask, float *dw, float *
         const long long cost = rounds * (mps_r / KM + kEpilogueSteps);
         if (best_cost < 0 || cost < best_cost) { best_cost = cost; splits = sp; }
     }
+    g.deterministic = (debug_flags() & kDbgDeterministic) ? 1 : 0;
+    if (g.deterministic) splits = 1;                  // one block per gradient tile: one addition per element of dw
     long long mps = (total_p + splits - 1) / splits;
     mps = (mps + KM - 1) / KM * KM;
     splits = (total_p + mps - 1) / mps;

@@ -141,8 +141,10 @@ k_wgrad16(const T *__restrict__ x, const T *__restrict__ dy, const T *__restrict
     // (split, filter chunk) all stage the same dY tiles, so they take turns: group block t owns the K
     // steps with step % n_grp == t.  (One owner block would run ~30 % longer than its peers and, with
     // one workgroup per CU, set the kernel time.)
+    // (deterministic mode: tap group 0 takes every turn -- one addition per bias column)
+    const int n_turns = g.deterministic ? (t == 0 ? 1 : (1 << 30)) : n_grp;
     const bool bias_blk = g.want_dbias && cchunk == 0;
-    int bias_turn = t;                                       // 0 => this K step is ours
+    int bias_turn = g.deterministic ? (t == 0 ? 0 : (1 << 29)) : t;      // 0 => this K step is ours
 
     // ---- staging: NTHR/64 threads per row, 16-byte units ------------------------------------
     constexpr int TPROW = NTHR / KM;
@@ -179,7 +181,7 @@ k_wgrad16(const T *__restrict__ x, const T *__restrict__ dy, const T *__restrict
         r_n = s / g.osp[0];
     }
     const bool dym_blk = MASK && g.dym != nullptr && cchunk == 0;
-    int dym_turn = t;                                        // same rotation for the staged tiles
+    int dym_turn = g.deterministic ? (t == 0 ? 0 : (1 << 29)) : t;   // same rotation for the staged tiles
 
     auto decode_next = [&](int mb) {
         const int m = mb + s_row;
@@ -253,7 +255,7 @@ k_wgrad16(const T *__restrict__ x, const T *__restrict__ dy, const T *__restrict
     };
     auto dym_now = [&]() {
         const bool w = dym_blk && dym_turn == 0;
-        dym_turn = dym_turn == 0 ? n_grp - 1 : dym_turn - 1;
+        dym_turn = dym_turn == 0 ? n_turns - 1 : dym_turn - 1;
         return w;
     };
 
@@ -302,7 +304,7 @@ k_wgrad16(const T *__restrict__ x, const T *__restrict__ dy, const T *__restrict
             const char *tb = lds + (it & 1) * BUF;
             const int nb = (it + 1) & 1;
             const bool bias_now = bias_blk && bias_turn == 0;
-            bias_turn = bias_turn == 0 ? n_grp - 1 : bias_turn - 1;
+            bias_turn = bias_turn == 0 ? n_turns - 1 : bias_turn - 1;
             if (bias_now && tid < 4 * BF) {
                 const T *col = reinterpret_cast<const T *>(tb + KM * XROW) + tid;
 #pragma unroll 8
@@ -410,6 +412,8 @@ int run_wgrad16(const T *x, const T *dy, const T *ymask, float *dw, float *dbias
         const long long cost = rounds * (mps_r / KM + kEpilogueSteps);
         if (best_cost < 0 || cost < best_cost) { best_cost = cost; splits = sp; }
     }
+    g.deterministic = (debug_flags() & kDbgDeterministic) ? 1 : 0;
+    if (g.deterministic) splits = 1;
     long long mps = (g.M + splits - 1) / splits;
     mps = (mps + KM - 1) / KM * KM;
     splits = (g.M + mps - 1) / mps;

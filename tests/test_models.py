@@ -372,6 +372,38 @@ def test_tall_dense_split_reduction_matches_plain_autograd():
     assert rel(d.bias.grad, br.grad) <= 1e-4
 
 
+@pytest.mark.gpu
+def test_deterministic_mode_makes_the_training_step_bit_repeatable():
+    """QK_DBG_DETERMINISTIC (include/qk.h): every backward-weight kernel runs one split of its reduction per gradient
+    tile and one owner per bias column, so no float sum depends on the order in which atomics land (TF's CPU
+    Conv2DBackpropFilter, the reference's path, is deterministic too).  Three whole training steps of the headline graph
+    (relu + dropout, l2 folded into Adam, bf16) started twice from the same seeds must then agree BIT FOR BIT in every
+    parameter and both Adam moments; the default mode is only required to agree to rounding."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    import bench
+    from qcnn_amd import _lib
+    dev = torch.device('cuda:0')
+    cfg = dict(kind='model', batch=4, frames=24, sf=32, layers=4, dtype='bf16', dropout=0.25, l2=1e-4, activation='relu')
+
+    def run(flags):
+        with _lib.debug_flags(flags):
+            job = bench.ModelTrainStep(cfg, dev, 0, 1)
+            torch.manual_seed(7)                     # the dropout masks of the three steps
+            for _ in range(3):
+                job.step()
+            torch.cuda.synchronize()
+            return job.flat.param.clone(), job.m.clone(), job.v.clone()
+    a = run(_lib.QK_DBG_DETERMINISTIC)
+    b = run(_lib.QK_DBG_DETERMINISTIC)
+    for x, y, name in zip(a, b, ('parameters', 'first moment', 'second moment')):
+        assert torch.equal(x, y), '%s differ between two deterministic runs: max |diff| %g' % (name, float((x - y).abs().max()))
+    c = run(0)
+    # same arithmetic, other summation order: Adam moves a parameter by at most ~lr per step whatever the gradient's size, so
+    # rounding-level differences of near-zero gradients stay below steps x lr = 1.5e-3 in absolute terms
+    assert float((a[0] - c[0]).abs().max()) <= 2e-3
+
+
 # ---- bench.py: the driver's contract ----------------------------------------------------------------------------
 def test_bench_defaults_name_the_headline_workload():
     """`python bench.py` with no flags = the full TIMIT QCNN step, per-GPU batch 256, bf16 (BASELINE configs[2]/[3]) for
