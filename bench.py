@@ -220,7 +220,10 @@ class LayerTrainStep(object):
         dt = TORCH_DT[cfg['dtype']]
         B, sp, cq, fq, ks = cfg['batch'], tuple(cfg['spatial']), cfg['cq'], cfg['filters'], tuple(cfg['kernel'])
         gen = torch.Generator(device=dev).manual_seed(1234 + rank)
-        self.x = torch.randn((B,) + sp + (4 * cq,), device=dev, generator=gen).to(dt)
+        # --layout native: true channels_first (N, 4C, *spatial) buffers handed to the C-ABI as QK_CH_FIRST
+        self.native = cfg.get('layout') == 'native'
+        lay = 'channels_first' if self.native else 'channels_last'
+        self.x = torch.randn((B, 4 * cq) + sp if self.native else (B,) + sp + (4 * cq,), device=dev, generator=gen).to(dt)
         np.random.seed(0)      # identical replicas: the reference init is host-side and seeded
         w0 = qconv_init(kernel_size=ks, input_dim=cq, weight_dim=len(ks), nb_filters=fq, criterion='he')()
         kernel = torch.nn.Parameter(torch.tensor(w0, dtype=torch.float32, device=dev))
@@ -231,14 +234,14 @@ class LayerTrainStep(object):
         self.m = torch.zeros_like(self.flat.param)
         self.v = torch.zeros_like(self.flat.param)
         self.call = F.conv_call(tuple(self.x.shape), tuple(kernel.shape), dt, len(ks), 1, 'same',
-                                'channels_last', 1, cfg.get('activation', 'relu'), True)
+                                lay, 1, cfg.get('activation', 'relu'), True)
         self.call.static_buffers = True
         # bwd-data on the masked gradient bwd-weight leaves behind (no second pass over y)
         self.relu = cfg.get('activation', 'relu') == 'relu'
         self.diag_mask_in_bwd_data = bool(os.environ.get('QK_DIAG_MASK_IN_BWD_DATA'))
         self.acc_grads = not os.environ.get('QK_BENCH_FILL_GRADS')     # diagnostic: the fill-per-step form
         self.call_lin = F.conv_call(tuple(self.x.shape), tuple(kernel.shape), dt, len(ks), 1, 'same',
-                                    'channels_last', 1, 'linear', True)
+                                    lay, 1, 'linear', True)
         self.call_lin.static_buffers = True
         self.y = torch.empty(self.call.y_shape, dtype=dt, device=dev)
         self.dy = torch.randn(self.call.y_shape, device=dev, generator=gen).to(dt)
@@ -258,7 +261,7 @@ class LayerTrainStep(object):
     def k_bwd_weight(self):
         # the gradient buffer is zero on entry (initially, and after every Adam step: zero_grad), so the
         # backward adds into it -- no 5 us fill per step
-        self.call.bwd_weight(self.x, self.dy, self.y, True, out=(self.dw, self.db), masked_dy_out=self.dym,
+        self.call.bwd_weight(self.x, self.dy, self.y, True, out=(self.dw, self.db), masked_dy_out=None if self.native else self.dym,
                              accumulate=self.acc_grads)
 
     def k_bwd_weight_chain(self):
@@ -270,7 +273,7 @@ class LayerTrainStep(object):
         self.call_lin.bwd_data(self.dy, None, self.kernel.data, out=self.dx)
 
     def k_bwd_data(self):
-        if self.relu and not self.diag_mask_in_bwd_data:
+        if self.relu and not self.diag_mask_in_bwd_data and not self.native:
             self.call_lin.bwd_data(self.dym, None, self.kernel.data, out=self.dx)
         else:
             self.call.bwd_data(self.dy, self.y, self.kernel.data, out=self.dx)
@@ -563,6 +566,8 @@ def main():
                     help='with --graph and N > 1: hipGraph segments around the RCCL all-reduce')
     ap.add_argument('--no-hamilton-gemm', action='store_true', help='skip the batch-256 bf16 Hamilton GEMM kernel timing')
     ap.add_argument('--activation', default='relu', choices=['relu', 'linear'], help='layer workloads, diagnostic: linear drops the relu mask')
+    ap.add_argument('--layout', default='channels_last', choices=['channels_last', 'native'],
+                    help='layer workloads: native = true channels_first (N, 4C, *spatial) buffers at the C-ABI (QK_CH_FIRST)')
     ap.add_argument('--loss', default='sum', choices=['sum', 'ctc'],
                     help='model workloads: sum = <prediction, fixed random tensor> (SURVEY.md 8d); ctc = the CTC cost the '
                          'reference model outputs (interspeech_model.py:37-39,178), mean over the batch')
@@ -591,7 +596,7 @@ def main():
     rank, world, local = dp.init_from_env()
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
-    cfg = dict(WORKLOADS[args.workload], activation=args.activation)
+    cfg = dict(WORKLOADS[args.workload], activation=args.activation, layout=args.layout)
     is_stack = cfg.get('kind') == 'stack'
     is_model = cfg.get('kind') == 'model' or is_stack
     steps = args.steps if args.steps is not None else (30 if is_stack else 100 if is_model else 300)
@@ -637,7 +642,7 @@ def main():
                    'activation': cfg.get('aact', 'none') if cfg.get('aact', 'none') != 'none' else cfg['activation'],
                    'dropout': cfg.get('dropout', 0.0), 'l2': cfg.get('l2', 0.0),
                    'loss': args.loss if is_model and not is_stack else 'sum',
-                   'input_layout': 'channels_first (B, 4, 41, T) contiguous; re-laid out to channels-last inside the step' if is_model and not is_stack else 'channels_last',
+                   'input_layout': 'channels_first (B, 4, 41, T) contiguous: the first layer reads the four component planes as they lie' if is_model and not is_stack else ('channels_first (QK_CH_FIRST at the C-ABI)' if args.layout == 'native' else 'channels_last'),
                    'gemm_view': job.gemm, 'parallelism': 'dp%d' % world,
                    'optimizer': 'adam(5e-4)' + (' + l2 term folded into the update' if cfg.get('l2') else ''),
                    'launch': 'hipgraph' if use_graph else 'eager'},

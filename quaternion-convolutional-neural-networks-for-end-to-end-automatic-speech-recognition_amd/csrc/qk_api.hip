@@ -61,12 +61,14 @@ struct ProfRec { int op, dtype, path; long long rows; int n, k; hipEvent_t e0, e
 struct Prof { std::mutex mu; std::atomic<int> on{0}; std::vector<ProfRec> recs; };
 Prof &prof() { static Prof p; return p; }
 }  // namespace
+static thread_local int g_prof_nest = 0;     // a call that re-enters the front end (channels_first re-layout) is timed once, as a whole
 struct ProfScope {
     bool live = false;
     ProfRec r;
     hipStream_t stream;
     ProfScope(int op, const qk_conv_desc_t *d, hipStream_t st) : stream(st)
     {
+        if (g_prof_nest++ > 0) return;
         if (!prof().on.load(std::memory_order_relaxed) || !d) return;
         r.op = op; r.dtype = d->dtype; r.path = QK_PATH_NONE;
         r.rows = (long long)d->batch * d->out_spatial[0] * d->out_spatial[1] * d->out_spatial[2];
@@ -78,6 +80,7 @@ struct ProfScope {
     }
     ~ProfScope()
     {
+        --g_prof_nest;
         if (!live) return;
         (void)hipEventRecord(r.e1, stream);
         r.path = g_path;
@@ -263,8 +266,52 @@ size_t dy_bytes(const qk_conv_desc_t *d)
     return (e * elem_bytes(d->dtype) + 255) / 256 * 256;
 }
 
+// ---- channels_first 16-bit buffers on the matrix cores ----------------------------------------------------------
+// The 16-bit MFMA kernels want the reduction axis (channels) contiguous.  A QK_CH_FIRST descriptor with 16-bit
+// activations is therefore served by re-laying its operands out to channels_last in the caller's workspace
+// (k_relayout16: HBM-bound, 64 x 64 tiles through LDS), running the channels_last kernels -- post-ops, chain flags,
+// accumulation included -- and re-laying the result back.  Costs one extra read + write of every activation operand
+// (~0.15 ms per 367 MB tensor) instead of the 10x slower general fp32 kernels that served these descriptors before.
+// (The engine's own layers keep channels_first tensors physically channels-last and never come here; this is for a
+// binder that holds true NCHW buffers.)
+bool cf16_ok(const qk_conv_desc_t *d)
+{
+    if (d->layout != QK_CH_FIRST || d->dtype == QK_F32 || (debug_flags() & kDbgNoMfma16)) return false;
+    if (d->cq % 32 || d->fq % 32 || taps_of(d) > 32) return false;
+    for (int i = 0; i < 3; ++i) if (d->stride[i] != 1) return false;
+    return true;
+}
+size_t align256(size_t n) { return (n + 255) / 256 * 256; }
+size_t x_bytes16(const qk_conv_desc_t *d) { return align256((size_t)d->batch * d->in_spatial[0] * d->in_spatial[1] * d->in_spatial[2] * 4 * d->cq * 2); }
+size_t y_bytes16(const qk_conv_desc_t *d) { return align256((size_t)d->batch * d->out_spatial[0] * d->out_spatial[1] * d->out_spatial[2] * 4 * d->fq * 2); }
+int in_positions(const qk_conv_desc_t *d) { return d->in_spatial[0] * d->in_spatial[1] * d->in_spatial[2]; }
+int out_positions(const qk_conv_desc_t *d) { return d->out_spatial[0] * d->out_spatial[1] * d->out_spatial[2]; }
+qk_conv_desc_t as_ch_last(const qk_conv_desc_t *d) { qk_conv_desc_t c = *d; c.layout = QK_CH_LAST; return c; }
+// x-shaped / y-shaped tensor: channels_first -> channels_last and back
+int x_to_last(const qk_conv_desc_t *d, const void *src, void *dst, hipStream_t s) { return launch_relayout16(src, dst, d->batch, 4 * d->cq, in_positions(d), s); }
+int x_to_first(const qk_conv_desc_t *d, const void *src, void *dst, hipStream_t s) { return launch_relayout16(src, dst, d->batch, in_positions(d), 4 * d->cq, s); }
+int y_to_last(const qk_conv_desc_t *d, const void *src, void *dst, hipStream_t s) { return launch_relayout16(src, dst, d->batch, 4 * d->fq, out_positions(d), s); }
+int y_to_first(const qk_conv_desc_t *d, const void *src, void *dst, hipStream_t s) { return launch_relayout16(src, dst, d->batch, out_positions(d), 4 * d->fq, s); }
+
 size_t ws_bytes_impl(const qk_conv_desc_t *d, int op)
 {
+    if (cf16_ok(d)) {
+        // [what the channels_last call needs][re-laid-out operands]: fwd x, y (+ pre of a post-op); bwd-data dy, y, dx,
+        // dx mask; bwd-weight x, dy, y; fused bwd x, dy, y, dx (+ x_pre of a post-op) -- and never less than its parts
+        const qk_conv_desc_t c = as_ch_last(d);
+        const size_t X = x_bytes16(d), Y = y_bytes16(d);
+        const size_t fwd = align256(ws_bytes_impl(&c, QK_OP_FWD)) + X + 2 * Y;
+        const size_t bd = align256(ws_bytes_impl(&c, QK_OP_BWD_DATA)) + 2 * Y + 2 * X;
+        const size_t bw = align256(ws_bytes_impl(&c, QK_OP_BWD_WEIGHT)) + X + 2 * Y;
+        const size_t bb = align256(ws_bytes_impl(&c, QK_OP_BWD)) + 2 * X + 2 * Y;
+        switch (op) {
+        case QK_OP_FWD: return fwd;
+        case QK_OP_BWD_DATA: return bd;
+        case QK_OP_BWD_WEIGHT: return bw;
+        case QK_OP_BWD: { size_t m = bb; if (bd > m) m = bd; if (bw > m) m = bw; return m; }
+        }
+        return 0;
+    }
     // 16-bit fast path (fwd / bwd-data): 16-bit re-laid-out copy of the compact kernel (+ zero line);
     // the fp32-MFMA kernels read the compact kernel in place and need nothing
     // fused backward additionally: the relu-masked copy of dy that bwd-weight writes for bwd-data
@@ -281,6 +328,19 @@ int conv_fwd_impl(const qk_conv_desc_t *d, const void *x, const float *w, const 
     if (!x || !w || !y) { set_error("x/w/y must not be NULL"); return QK_ERR_INVALID_ARG; }
     if (d->has_bias && !bias) { set_error("has_bias set but bias is NULL"); return QK_ERR_INVALID_ARG; }
     ProfScope prof_scope(QK_OP_FWD, d, stream);
+    if (cf16_ok(d)) {
+        const qk_conv_desc_t c = as_ch_last(d);
+        const size_t base = align256(ws_bytes_impl(&c, QK_OP_FWD)), X = x_bytes16(d), Y = y_bytes16(d);
+        const bool two = post && post->kind == 1;
+        if (ws && aligned(ws, 16) && wsb >= base + X + Y + (two ? Y : 0)) {
+            char *p = static_cast<char *>(ws) + base;
+            void *xt = p, *yt = p + X, *pt = two ? p + X + Y : nullptr;
+            if (int rc = x_to_last(d, x, xt, stream)) return rc;
+            if (int rc = conv_fwd_impl(&c, xt, w, bias, yt, ws, base, stream, post, pt)) return rc;
+            if (int rc = y_to_first(d, yt, y, stream)) return rc;
+            return two ? y_to_first(d, pt, pre, stream) : 0;
+        }
+    }
     GemmGeom g;
     memset(&g, 0, sizeof(g));
     const Strides xs = act_strides(d->in_spatial, 4 * d->cq, d->layout);
@@ -336,6 +396,17 @@ int conv_bwd_data_impl(const qk_conv_desc_t *d, const void *dy, const void *y, c
     }
     if (need && !aligned(ws, 16)) { set_error("workspace must be 16-byte aligned"); return QK_ERR_WORKSPACE; }
     ProfScope prof_scope(QK_OP_BWD_DATA, d, stream);
+    if (cf16_ok(d)) {
+        const qk_conv_desc_t c = as_ch_last(d);
+        const size_t base = align256(ws_bytes_impl(&c, QK_OP_BWD_DATA)), X = x_bytes16(d), Y = y_bytes16(d);
+        char *p = static_cast<char *>(ws) + base;
+        void *dyt = p, *yt = mask ? p + Y : nullptr, *dxt = p + 2 * Y, *mt = dx_mask ? p + 2 * Y + X : nullptr;
+        if (int rc = y_to_last(d, dy, dyt, stream)) return rc;
+        if (mask) if (int rc = y_to_last(d, y, yt, stream)) return rc;
+        if (dx_mask) if (int rc = x_to_last(d, dx_mask, mt, stream)) return rc;
+        if (int rc = conv_bwd_data_impl(&c, dyt, yt, w, dxt, ws, base, stream, mt, post, dalpha)) return rc;
+        return x_to_first(d, dxt, dx, stream);
+    }
     GemmGeom g;
     memset(&g, 0, sizeof(g));
     const Strides dys = act_strides(d->out_spatial, 4 * d->fq, d->layout);
@@ -383,13 +454,28 @@ int conv_bwd_data_impl(const qk_conv_desc_t *d, const void *dy, const void *y, c
 }
 
 int conv_bwd_weight_impl(const qk_conv_desc_t *d, const void *x, const void *dy, const void *y, float *dw,
-                         float *dbias, void *dy_masked_out, hipStream_t stream, bool accumulate = false)
+                         float *dbias, void *dy_masked_out, hipStream_t stream, bool accumulate = false,
+                         void *ws = nullptr, size_t wsb = 0)
 {
     if (!x || !dy || !dw) { set_error("x/dy/dw must not be NULL"); return QK_ERR_INVALID_ARG; }
     const bool mask = d->activation == QK_ACT_RELU;
     if (mask && !y) { set_error("activation is RELU: the forward output y is required"); return QK_ERR_INVALID_ARG; }
     if (d->has_bias && !dbias) { set_error("has_bias set but dbias is NULL"); return QK_ERR_INVALID_ARG; }
     ProfScope prof_scope(QK_OP_BWD_WEIGHT, d, stream);
+    if (cf16_ok(d)) {
+        // (ws, wsb): the caller's workspace, used for the re-layout; no masked dy is left behind in this mode
+        const qk_conv_desc_t c = as_ch_last(d);
+        const size_t X = x_bytes16(d), Y = y_bytes16(d);
+        if (ws && aligned(ws, 16) && wsb >= X + Y + (mask ? Y : 0)) {
+            char *p = static_cast<char *>(ws);
+            void *xt = p, *dyt = p + X, *yt = mask ? p + X + Y : nullptr;
+            if (int rc = x_to_last(d, x, xt, stream)) return rc;
+            if (int rc = y_to_last(d, dy, dyt, stream)) return rc;
+            if (mask) if (int rc = y_to_last(d, y, yt, stream)) return rc;
+            return conv_bwd_weight_impl(&c, xt, dyt, yt, dw, dbias, nullptr, stream, accumulate);
+        }
+        dy_masked_out = nullptr;               // (the workspace may be too small to double as the masked-dy output)
+    }
     WgradGeom g;
     memset(&g, 0, sizeof(g));
     const Strides xs = act_strides(d->in_spatial, 4 * d->cq, d->layout);
@@ -442,6 +528,23 @@ int conv_bwd_impl(const qk_conv_desc_t *d, const void *x, const void *dy, const 
 {
     if (!dx) { set_error("dx must not be NULL (use qk_*_bwd_weight when d(input) is not needed)"); return QK_ERR_INVALID_ARG; }
     if (flags & ~(QK_BWD_MASK_DX | QK_BWD_DY_PREMASKED | QK_BWD_ACCUMULATE)) { set_error("unknown backward flags 0x%x", flags); return QK_ERR_INVALID_ARG; }
+    if (cf16_ok(d)) {
+        // one re-layout of x, dy (and y) serves both gradient kernels; dx goes back once
+        const qk_conv_desc_t c = as_ch_last(d);
+        const size_t base = align256(ws_bytes_impl(&c, QK_OP_BWD)), X = x_bytes16(d), Y = y_bytes16(d);
+        const bool need_y = d->activation == QK_ACT_RELU && !(flags & QK_BWD_DY_PREMASKED);
+        if (need_y && !y) { set_error("activation is RELU: the forward output y is required"); return QK_ERR_INVALID_ARG; }
+        if (!x || !dy) { set_error("x/dy must not be NULL"); return QK_ERR_INVALID_ARG; }
+        if (ws && aligned(ws, 16) && wsb >= base + 2 * X + 2 * Y) {
+            char *p = static_cast<char *>(ws) + base;
+            void *xt = p, *dxt = p + X, *dyt = p + 2 * X, *yt = need_y ? p + 2 * X + Y : nullptr;
+            if (int rc = x_to_last(d, x, xt, stream)) return rc;
+            if (int rc = y_to_last(d, dy, dyt, stream)) return rc;
+            if (need_y) if (int rc = y_to_last(d, y, yt, stream)) return rc;
+            if (int rc = conv_bwd_impl(&c, xt, dyt, yt, w, dxt, dw, dbias, ws, base, stream, flags)) return rc;
+            return x_to_first(d, dxt, dx, stream);
+        }
+    }
     const bool acc = (flags & QK_BWD_ACCUMULATE) != 0;
     const void *dx_mask = (flags & QK_BWD_MASK_DX) ? x : nullptr;
     const bool relu = d->activation == QK_ACT_RELU && !(flags & QK_BWD_DY_PREMASKED);
@@ -577,7 +680,8 @@ int qk_conv_bwd_post(const qk_conv_desc_t *desc, const void *x, const void *dy, 
     if (int rc = to_postop(post_x, desc->rank, desc->in_spatial, &p)) return rc;
     const size_t bd = ws_bytes_impl(desc, QK_OP_BWD_DATA);
     if (bd && (!workspace || workspace_bytes < bd)) { set_error("bwd needs %zu workspace bytes, got %zu", bd, workspace_bytes); return QK_ERR_WORKSPACE; }
-    if (int rc = conv_bwd_weight_impl(desc, x, dy, nullptr, dw, dbias, nullptr, (hipStream_t)stream, (flags & QK_BWD_ACCUMULATE) != 0)) return check_launch(rc, "qk_conv_bwd_post");
+    if (int rc = conv_bwd_weight_impl(desc, x, dy, nullptr, dw, dbias, nullptr, (hipStream_t)stream, (flags & QK_BWD_ACCUMULATE) != 0,
+                                      workspace, workspace_bytes)) return check_launch(rc, "qk_conv_bwd_post");
     // relu post-op: x = drop(relu(x_pre)) is its own mask (x > 0 <=> x_pre > 0 and kept)
     const void *mask_src = p.kind == 2 ? x : x_pre;
     return check_launch(conv_bwd_data_impl(desc, dy, nullptr, w, dx, workspace, bd, (hipStream_t)stream, mask_src, &p, p.kind == 2 ? nullptr : dalpha_x), "qk_conv_bwd_post");
@@ -618,7 +722,7 @@ int qk_conv_bwd_weight(const qk_conv_desc_t *desc, const void *x, const void *dy
 {
     if (int rc = validate(desc, false)) return rc;
     void *dym = (workspace && workspace_bytes >= dy_bytes(desc) && aligned(workspace, 16)) ? workspace : nullptr;
-    return check_launch(conv_bwd_weight_impl(desc, x, dy, y, dw, dbias, dym, (hipStream_t)stream), "qk_conv_bwd_weight");
+    return check_launch(conv_bwd_weight_impl(desc, x, dy, y, dw, dbias, dym, (hipStream_t)stream, false, workspace, workspace_bytes), "qk_conv_bwd_weight");
 }
 
 int qk_conv_bwd_chain(const qk_conv_desc_t *desc, const void *x, const void *dy, const void *y, const float *w,
@@ -646,7 +750,7 @@ int qk_conv_bwd_weight_acc(const qk_conv_desc_t *desc, const void *x, const void
 {
     if (int rc = validate(desc, false)) return rc;
     void *dym = (workspace && workspace_bytes >= dy_bytes(desc) && aligned(workspace, 16)) ? workspace : nullptr;
-    return check_launch(conv_bwd_weight_impl(desc, x, dy, y, dw, dbias, dym, (hipStream_t)stream, true), "qk_conv_bwd_weight_acc");
+    return check_launch(conv_bwd_weight_impl(desc, x, dy, y, dw, dbias, dym, (hipStream_t)stream, true, workspace, workspace_bytes), "qk_conv_bwd_weight_acc");
 }
 
 int qk_dense_bwd_weight_acc(const qk_dense_desc_t *desc, const void *x, const void *dy, const void *y,

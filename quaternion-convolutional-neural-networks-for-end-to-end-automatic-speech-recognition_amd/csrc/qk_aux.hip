@@ -226,7 +226,72 @@ k_postop(const T *__restrict__ pre, const T *__restrict__ dy, T *__restrict__ ou
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Re-layout of a 16-bit activation between channels_first and channels_last: per sample a (A, B) matrix with B
+// contiguous becomes (B, A) with A contiguous.  channels_first -> channels_last: A = channels, B = positions; the way
+// back: A = positions, B = channels.  64 x 64 tiles through LDS: 16-byte global loads along B, 16-byte global stores
+// along A (a tile row pitch of 33 words keeps the transposing 2-byte LDS reads on distinct banks).  HBM-bound.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_relayout16(const unsigned short *__restrict__ src, unsigned short *__restrict__ dst, int A, int B, int vec_ok)
+{
+    constexpr int TP = 66;                                  // pitch in elements (33 words)
+    __shared__ unsigned short tile[64 * TP];
+    const int tid = threadIdx.x;
+    const long long n_off = (long long)blockIdx.z * A * B;
+    const int b0 = blockIdx.x * 64, a0 = blockIdx.y * 64;
+    const int v = tid & 7;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int r = (tid >> 3) + 32 * k;                  // row of the tile: index along A
+        const int a = a0 + r, b = b0 + v * 8;
+        unsigned w[4] = {0u, 0u, 0u, 0u};
+        if (a < A) {
+            const unsigned short *p = src + n_off + (long long)a * B + b;
+            if (vec_ok && b + 8 <= B) {
+                const uint4 q = *reinterpret_cast<const uint4 *>(p);
+                w[0] = q.x; w[1] = q.y; w[2] = q.z; w[3] = q.w;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (b + i < B) w[i >> 1] |= (unsigned)p[i] << (16 * (i & 1));
+            }
+        }
+        unsigned *t4 = reinterpret_cast<unsigned *>(tile + r * TP + v * 8);
+        t4[0] = w[0]; t4[1] = w[1]; t4[2] = w[2]; t4[3] = w[3];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int r = (tid >> 3) + 32 * k;                  // row of the transposed tile: index along B
+        const int b = b0 + r, a = a0 + v * 8;
+        if (b >= B) continue;
+        unsigned w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            w[i] = (unsigned)tile[(v * 8 + 2 * i) * TP + r] | ((unsigned)tile[(v * 8 + 2 * i + 1) * TP + r] << 16);
+        unsigned short *p = dst + n_off + (long long)b * A + a;
+        if (vec_ok && a + 8 <= A) *reinterpret_cast<uint4 *>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+        else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (a + i < A) p[i] = (unsigned short)(w[i >> 1] >> (16 * (i & 1)));
+        }
+    }
+}
+
 }  // namespace
+
+// (n, A, B) -> (n, B, A), 16-bit elements (see k_relayout16)
+int launch_relayout16(const void *src, void *dst, int n, int A, int B, hipStream_t stream)
+{
+    if (n <= 0 || A <= 0 || B <= 0) return 0;
+    const int vec_ok = (A % 8 == 0 && B % 8 == 0 && (reinterpret_cast<uintptr_t>(src) % 16) == 0 && (reinterpret_cast<uintptr_t>(dst) % 16) == 0) ? 1 : 0;
+    if (n > 65535 || (A + 63) / 64 > 65535) return QK_ERR_UNSUPPORTED;
+    dim3 grid((unsigned)((B + 63) / 64), (unsigned)((A + 63) / 64), (unsigned)n);
+    hipLaunchKernelGGL(k_relayout16, grid, dim3(256), 0, stream, (const unsigned short *)src, (unsigned short *)dst, A, B, vec_ok);
+    return hipGetLastError() == hipSuccess ? 0 : QK_ERR_LAUNCH;
+}
 
 int launch_mask_gt0(int dtype, void *data, const void *mask, size_t n, hipStream_t stream)
 {

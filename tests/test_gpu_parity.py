@@ -696,22 +696,76 @@ def test_conj_and_tap_skipping_convolutions_match_oracle(case, dtype):
 NATIVE_16BIT = [c for c in ORACLE_CASES if c[0] in ('conv2d_chfirst_body_small', 'conv2d_first_layer')] + [
     ('conv1d_chfirst_native', 1, (3, 32, 45), (3, 8, 64), dict(padding='same', activation='relu', data_format='channels_first')),
     ('conv2d_chfirst_valid_native', 2, (2, 128, 9, 21), (3, 3, 32, 64), dict(padding='valid', activation=None, data_format='channels_first')),
+    # Cq, F multiples of 32: the matrix-core path through the workspace re-layout (odd extents: scalar edges of the tiles)
+    ('conv2d_chfirst_mfma_same_relu', 2, (2, 128, 7, 23), (3, 5, 32, 128), dict(padding='same', activation='relu', data_format='channels_first')),
+    ('conv2d_chfirst_mfma_64_linear', 2, (3, 256, 6, 40), (3, 5, 64, 256), dict(padding='same', activation=None, data_format='channels_first')),
+    ('conv1d_chfirst_mfma_valid', 1, (2, 128, 50), (3, 32, 128), dict(padding='valid', activation='relu', data_format='channels_first')),
 ]
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16], ids=['bf16', 'fp16'])
 @pytest.mark.parametrize('case', NATIVE_16BIT, ids=[c[0] for c in NATIVE_16BIT])
 def test_half_native_channels_first_layout_matches_oracle(case, dtype):
-    """internal_layout='native' (C-ABI QK_CH_FIRST): 16-bit NCHW buffers run as they are through the generic
-    staging path of the fp32-MFMA kernels (inputs widened while staged, fp32 kernel, 16-bit outputs)."""
+    """internal_layout='native' (C-ABI QK_CH_FIRST): true NCHW 16-bit buffers.  Channel counts that are multiples of 32
+    run on the 16-bit matrix-core kernels through a re-layout of the operands in the caller's workspace
+    (qk_api.hip: cf16_ok; round 2 dropped every such descriptor to the fp32-MFMA kernels, ~10x slower); the others go
+    through the generic staging path of the fp32-MFMA kernels (inputs widened while staged, 16-bit outputs)."""
     import qcnn_amd
     _, rank, xs, ws, kw = case
     x, w, b, dy, want = _oracle_case(rank, xs, ws, kw, seed=19, dtype=dtype)
     got = _run_layer(qcnn_amd.functional, x, w, b, dy, rank, dict(kw, fold_small_cq=False), dtype, internal_layout='native')
+    on_matrix_cores = ws[-2] % 32 == 0 and ws[-1] % 128 == 0
+    assert (qcnn_amd._lib.last_path() != 'fp32_mfma') == on_matrix_cores, qcnn_amd._lib.last_path()
     tol16, tol32 = (1e-2, 2e-3) if dtype == torch.bfloat16 else (2e-3, 1e-3)
     for k, v in got.items():
         err = _rel_err(v, want[k])
         assert err <= (tol16 if k in ('y', 'dx') else tol32), '%s: rel err %.3g' % (k, err)
+
+
+@pytest.mark.parametrize('form', ['relu_dropout', 'prelu_dropout'])
+def test_channels_first_descriptor_with_post_ops_equals_channels_last(form):
+    """QK_CH_FIRST at the C-ABI with a post-op (round 2: QK_ERR_UNSUPPORTED): qk_conv_fwd_post / qk_conv_bwd_post on true
+    NCHW bf16 buffers against the same calls on the channels-last copies of the same tensors.  The forward runs the same
+    kernels on the same values (the dropout mask is a function of the element's index in the channels-last image):
+    bit-identical; the gradients agree up to the order of the atomic accumulation."""
+    import qcnn_amd
+    from qcnn_amd import _lib
+    F = qcnn_amd.functional
+    dev = _dev()
+    dt = torch.bfloat16
+    g = torch.Generator(device=dev).manual_seed(3)
+    n, cq, fq, h, wd = 2, 32, 64, 6, 40
+    x_cl = torch.randn(n, h, wd, 4 * cq, device=dev, generator=g).to(dt)
+    dy_cl = torch.randn(n, h, wd, 4 * fq, device=dev, generator=g).to(dt)
+    w = torch.randn(3, 5, cq, 4 * fq, device=dev, generator=g) / 30
+    b = torch.randn(4 * fq, device=dev, generator=g) / 10
+    alpha = (0.05 + 0.3 * torch.rand(h, device=dev, generator=g)) if form == 'prelu_dropout' else None
+    post_y = F.PostOp(alpha, 0 if alpha is not None else -1, 0.25, 77)
+    alpha_x = (0.05 + 0.3 * torch.rand(h, device=dev, generator=g)) if form == 'prelu_dropout' else None
+    post_x = F.PostOp(alpha_x, 0 if alpha_x is not None else -1, 0.25, 78)
+    out = {}
+    for lay in ('channels_last', 'channels_first'):
+        to = (lambda t: t) if lay == 'channels_last' else (lambda t: t.permute(0, 3, 1, 2).contiguous())
+        back = (lambda t: t) if lay == 'channels_last' else (lambda t: t.permute(0, 2, 3, 1))
+        x, dy = to(x_cl), to(dy_cl)
+        call = F.conv_call(tuple(x.shape), tuple(w.shape), dt, 2, 1, 'same', lay, 1, None, True, False)
+        pre, y = call.fwd_post(x, w, b, post_y)
+        path_f = _lib.last_path()
+        # backward of the same layer, its input taken as the output of another post-op (x = post_x(x_pre))
+        x_pre = to(torch.randn(n, h, wd, 4 * cq, device=dev, generator=torch.Generator(device=dev).manual_seed(9)).to(dt))
+        xin = F.postop_fwd(back(x_pre).contiguous(), post_x)
+        xin = to(xin)
+        da = torch.zeros(h, device=dev) if alpha_x is not None else None
+        dx, dw, db = call.bwd_post(xin, dy, w, True, post_x, x_pre if alpha_x is not None else None, da)
+        out[lay] = (back(y), None if pre is None else back(pre), back(dx), dw, db, da, path_f, _lib.last_path())
+    a, c = out['channels_last'], out['channels_first']
+    assert c[6] != 'fp32_mfma' and c[7] != 'fp32_mfma' and a[6] == c[6]
+    assert torch.equal(a[0], c[0]) and (a[1] is None or torch.equal(a[1], c[1]))
+    assert torch.equal(a[2], c[2])                                   # backward-data: no atomics in its path
+    rel = lambda p, q: float((p - q).abs().max() / q.abs().max())
+    assert rel(c[3], a[3]) <= 1e-5 and rel(c[4], a[4]) <= 1e-5
+    if a[5] is not None:
+        assert rel(c[5], a[5]) <= 1e-4
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['fp32', 'bf16'])
