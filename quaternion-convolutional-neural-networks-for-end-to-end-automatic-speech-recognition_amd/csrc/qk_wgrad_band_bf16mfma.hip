@@ -250,8 +250,31 @@ k_wgrad16_band(const T *__restrict__ x, const T *__restrict__ dy, const T *__res
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 v8s A[KIN], B[CTW];
+                // The KIN tap fragments of a lane are windows [t, t + 8) of the SAME 12 consecutive band positions of its
+                // channel (tap t pairs x[P + t] with dy[P]): three transposing reads fetch the 12 positions once and the
+                // windows are cut out of the six dwords in registers -- even taps are plain register sub-ranges, odd taps
+                // one v_alignbit_b32 per dword -- instead of 2 KIN reads of overlapping rows (the kernel was LDS-bound:
+                // 14 ds_read_b64_tr_b16 per 10 MFMAs; now 7).
+                {
+                    const char *ab = tb + a_off + (ks * 16) * XROW;
+                    const v4s q0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s *)(ab));
+                    const v4s q1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s *)(ab + 4 * XROW));
+                    const v4s q2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s *)(ab + 8 * XROW));
+                    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+                    const u2 e0 = __builtin_bit_cast(u2, q0), e1 = __builtin_bit_cast(u2, q1), e2 = __builtin_bit_cast(u2, q2);
+                    const unsigned d[6] = {e0.x, e0.y, e1.x, e1.y, e2.x, e2.y};
 #pragma unroll
-                for (int t = 0; t < KIN; ++t) A[t] = tr_frag8(tb + a_off + (ks * 16 + t) * XROW, XROW);
+                    for (int t = 0; t < KIN; ++t) {
+                        u32x4 f;
+                        if (t % 2 == 0) { f.x = d[t / 2]; f.y = d[t / 2 + 1]; f.z = d[t / 2 + 2]; f.w = d[t / 2 + 3]; }
+                        else {
+                            const int o = t / 2;
+                            f.x = __builtin_amdgcn_alignbit(d[o + 1], d[o], 16); f.y = __builtin_amdgcn_alignbit(d[o + 2], d[o + 1], 16);
+                            f.z = __builtin_amdgcn_alignbit(d[o + 3], d[o + 2], 16); f.w = __builtin_amdgcn_alignbit(d[o + 4], d[o + 3], 16);
+                        }
+                        A[t] = __builtin_bit_cast(v8s, f);
+                    }
+                }
 #pragma unroll
                 for (int ct = 0; ct < CTW; ++ct) B[ct] = tr_frag8(tb + b_off + ks * 16 * DROW + ct * 64, DROW);
                 __builtin_amdgcn_sched_barrier(0);

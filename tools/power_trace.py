@@ -90,23 +90,28 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--seconds', type=float, default=4.0)
     ap.add_argument('--kernel', default='fwd', choices=['fwd', 'bwd_data', 'bwd_weight'])
+    ap.add_argument('--cq', type=int, default=64)
+    ap.add_argument('--fq', type=int, default=64)
     args = ap.parse_args()
     dev = torch.device('cuda:0')
     dt = torch.bfloat16
     g = torch.Generator(device=dev).manual_seed(0)
-    xs, ws = (256, 14, 200, 256), (3, 5, 64, 256)
+    xs, ws = (256, 14, 200, 4 * args.cq), (3, 5, args.cq, 4 * args.fq)
+    ys = (256, 14, 200, 4 * args.fq)
     w = torch.randn(ws, device=dev, generator=g) / 30
-    b = torch.zeros(256, device=dev)
+    b = torch.zeros(4 * args.fq, device=dev)
     call = F.conv_call(xs, ws, dt, 2, 1, 'same', 'channels_last', 1, None, True, False)
     call.static_buffers = True
-    r = torch.randn(xs, device=dev, generator=g)
-    keep = (torch.rand(xs, device=dev, generator=g) >= 0.3).float() / 0.7
-    data = [('all zeros', torch.zeros(xs, device=dev)), ('relu(normal): 50 % zeros', torch.relu(r)),
+    in_shape = xs if args.kernel == 'fwd' else ys          # the tensor whose VALUES are varied: x (forward) or dy (backward)
+    r = torch.randn(in_shape, device=dev, generator=g)
+    keep = (torch.rand(in_shape, device=dev, generator=g) >= 0.3).float() / 0.7
+    xfix = torch.relu(torch.randn(xs, device=dev, generator=g)).to(dt)
+    data = [('all zeros', torch.zeros(in_shape, device=dev)), ('relu(normal): 50 % zeros', torch.relu(r)),
             ('relu + dropout 0.3: 65 % zeros', torch.relu(r) * keep), ('dense normal', r)]
     y = torch.empty(call.y_shape, dtype=dt, device=dev)
     dx = torch.empty(xs, dtype=dt, device=dev)
-    dw, db = torch.zeros(ws, device=dev), torch.zeros(256, device=dev)
-    flops = 2.0 * 716800 * 256 * 3840
+    dw, db = torch.zeros(ws, device=dev), torch.zeros(4 * args.fq, device=dev)
+    flops = 2.0 * 716800 * (4 * args.fq) * (15 * 4 * args.cq)
     smp = Sampler()
     cap = None
     try:
@@ -114,16 +119,16 @@ def main():
     except Exception:
         pass
     smp.start()
-    print('# kernel: %s of the 64 -> 64 body layer (716800 x 256 x 3840, bf16); sensor source: %s (%s); idle sample (W, MHz): %r; power cap: %s W' % (args.kernel, smp.src, smp.card, smp.read(), cap))
+    print('# kernel: %s of the %d -> %d body layer (716800 x %d x %d, bf16);' % (args.kernel, args.cq, args.fq, 4 * args.fq, 60 * args.cq) + ' sensor source: %s (%s); idle sample (W, MHz): %r; power cap: %s W' % (smp.src, smp.card, smp.read(), cap))
     print('# %-32s %9s %9s %10s %10s %8s' % ('operand values', 'us/launch', 'TFLOP/s', 'power W', 'sclk MHz', 'samples'))
     for name, x in data:
         x = x.to(dt)
         if args.kernel == 'fwd':
             fn = lambda: call.fwd(x, w, b, out=y)
         elif args.kernel == 'bwd_data':
-            fn = lambda: call.bwd_data(x, None, w, out=dx)              # x plays dy: same shape (64 -> 64)
+            fn = lambda: call.bwd_data(x, None, w, out=dx)
         else:
-            fn = lambda: call.bwd_weight(x, x, None, True, out=(dw, db), accumulate=True)
+            fn = lambda: call.bwd_weight(xfix, x, None, True, out=(dw, db), accumulate=True)
         for _ in range(20):
             fn()
         torch.cuda.synchronize()
