@@ -57,7 +57,7 @@
 extern "C" {
 #endif
 
-#define QK_VERSION 101 /* major*10000 + minor*100 + patch */
+#define QK_VERSION 102 /* major*10000 + minor*100 + patch */
 
 typedef enum {
     QK_OK = 0,
@@ -89,6 +89,10 @@ typedef struct {
     int32_t activation;      /* qk_act_t fused into fwd; bwd masks dy with (y > 0) for RELU   */
     int32_t has_bias;        /* use_bias                                                      */
     int32_t conj;            /* 0: W (x) x  (conv.py:327-331);  1: conj(W) (x) x (dense table) */
+    int32_t ws_has_kernel;   /* 16-bit path: nonzero = the start of `workspace` ALREADY holds the re-laid-out 16-bit
+                              * kernel an earlier call with the same descriptor, the same operation class (forward |
+                              * backward-data / fused backward) and UNCHANGED weights left there: the call skips that
+                              * step (one small launch per call; 26 per TIMIT training step).  0 = always safe.    */
 } qk_conv_desc_t;
 
 /* One quaternion dense call (QuaternionDense state, dense.py:58-124). */
@@ -99,6 +103,7 @@ typedef struct {
     int32_t dtype;           /* qk_dtype_t of x / y / dy / dx                                 */
     int32_t activation;      /* qk_act_t                                                      */
     int32_t has_bias;
+    int32_t ws_has_kernel;   /* as in qk_conv_desc_t                                          */
 } qk_dense_desc_t;
 
 /* Library / diagnostics ------------------------------------------------------------------ */

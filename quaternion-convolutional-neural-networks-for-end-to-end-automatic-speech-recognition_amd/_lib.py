@@ -28,12 +28,12 @@ class ConvDesc(ctypes.Structure):
     _fields_ = [('rank', I32), ('batch', I32), ('in_spatial', I32 * 3), ('out_spatial', I32 * 3),
                 ('cq', I32), ('fq', I32), ('kernel', I32 * 3), ('stride', I32 * 3),
                 ('dilation', I32 * 3), ('pad_lo', I32 * 3), ('layout', I32), ('dtype', I32),
-                ('activation', I32), ('has_bias', I32), ('conj', I32)]
+                ('activation', I32), ('has_bias', I32), ('conj', I32), ('ws_has_kernel', I32)]
 
 
 class DenseDesc(ctypes.Structure):
     _fields_ = [('rows', I32), ('in_q', I32), ('q_units', I32), ('dtype', I32),
-                ('activation', I32), ('has_bias', I32)]
+                ('activation', I32), ('has_bias', I32), ('ws_has_kernel', I32)]
 
 
 # every symbol include/qk.h declares: name -> (restype, argtypes)

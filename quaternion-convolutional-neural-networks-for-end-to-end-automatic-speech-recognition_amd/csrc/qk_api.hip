@@ -359,6 +359,7 @@ int conv_fwd_impl(const qk_conv_desc_t *d, const void *x, const float *w, const 
     g.relu = d->activation == QK_ACT_RELU;
     g.has_bias = d->has_bias ? 1 : 0;
     g.has_mask = 0;
+    g.w_prepped = d->ws_has_kernel ? 1 : 0;
     const bool with_post = post && post->kind;
     if (d->dtype != QK_F32) {
         if (with_post && d->layout == QK_CH_LAST && aligned(pre, 16) && aligned(y, 16) &&
@@ -423,6 +424,7 @@ int conv_bwd_data_impl(const qk_conv_desc_t *d, const void *dy, const void *y, c
     g.out_sn = dxs.sn; g.out_ss = dxs.flat_ss; g.out_sc = dxs.sc;
     g.sign_tbl = d->conj ? kSignConv : kSignConj;   // transposed table
     g.relu = 0; g.has_bias = 0; g.has_mask = mask ? 1 : 0;
+    g.w_prepped = d->ws_has_kernel ? 1 : 0;
     if (d->dtype != QK_F32) {
         // the 16-bit kernels apply an epilogue mask themselves (needs 16-byte aligned rows of dx_mask)
         g.ep_mask = (dx_mask && aligned(dx_mask, 16)) ? dx_mask : nullptr;
@@ -578,6 +580,7 @@ qk_conv_desc_t dense_as_conv(const qk_dense_desc_t *d)
     }
     c.layout = QK_CH_LAST; c.dtype = d->dtype; c.activation = d->activation;
     c.has_bias = d->has_bias; c.conj = 1;     // dense.py:139-143 is the transposed table
+    c.ws_has_kernel = d->ws_has_kernel;
     return c;
 }
 

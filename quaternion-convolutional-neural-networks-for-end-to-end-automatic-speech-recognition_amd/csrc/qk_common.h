@@ -63,6 +63,7 @@ struct GemmGeom {
     int has_mask;       // gathered value is zeroed where mask[same index] <= 0 (relu backward)
     int ablate;         // profiling only (env QK_ABLATE): 4 = skip the MFMA loop, 8 = skip the epilogue
     int w_swapped;      // Wk is the compact kernel itself, read with q/j swapped (backward-data): no transposed copy
+    int w_prepped;      // 16-bit path: the workspace already holds the re-laid-out kernel (qk_conv_desc_t.ws_has_kernel)
     // band variant of the 16-bit kernel (qk_hgemm_bf16mfma.hip): rows of M run over PADDED lines of the
     // innermost axis (b_wp = out extent + k - 1 positions per line, b_nlines lines), band row j of a tile
     // holds input position (padded position + b_cshift); b_rev: taps walk the band backwards (bwd-data)

@@ -1133,8 +1133,10 @@ int go16(const void *in, const void *mask, const float *w, const float *bias, vo
     const long long total = (long long)g.taps * Cq * 4 * F;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL((k_prep_w16<T>), dim3(blocks), dim3(256), 0, stream, w, wq, g.taps, Cq, F, transposed ? 1 : 0, neg_ijk ? 1 : 0);
-    if (hipGetLastError() != hipSuccess) return QK_ERR_LAUNCH;
+    if (!g.w_prepped) {                              // (the caller vouches for the workspace: qk_conv_desc_t.ws_has_kernel)
+        hipLaunchKernelGGL((k_prep_w16<T>), dim3(blocks), dim3(256), 0, stream, w, wq, g.taps, Cq, F, transposed ? 1 : 0, neg_ijk ? 1 : 0);
+        if (hipGetLastError() != hipSuccess) return QK_ERR_LAUNCH;
+    }
     const uint4 *wq4 = reinterpret_cast<const uint4 *>(wq);
     const T *zero_line = wq + total;                 // 256 zeroed bytes behind the re-laid-out kernel
     GemmGeom bg;

@@ -135,6 +135,7 @@ class FlatParams(object):
                 self.param[o:o + n].copy_(p.detach().reshape(-1).float())
                 p.data = self.param[o:o + n].view(p.shape)
                 p.grad = self.grad[o:o + n].view(p.shape)
+                p._qk_flat_base = self.param     # functional._Call._ws: writes through the flat buffer invalidate cached re-layouts
                 # the engine's backward nodes add their kernel / bias gradients straight into these views (no
                 # temporary, no memset, no AccumulateGrad add): functional._direct_grad
                 p._qk_direct_grad = bool(direct is True or (direct == 'auto' and not getattr(p, '_qk_regularized', None)))

@@ -18,6 +18,7 @@ from . import _lib as L
 from ._shape import conv_output_length, normalize_tuple, tf_pads
 
 _DTYPES = {torch.float32: L.QK_F32, torch.bfloat16: L.QK_BF16, torch.float16: L.QK_F16}
+_PREP_CACHE_ON = not __import__('os').environ.get('QK_NO_PREP_CACHE')     # diagnostic: re-lay the 16-bit kernels out on every call
 
 
 def _require_device(t, what):
@@ -70,12 +71,42 @@ class _Call(object):
         self._ws_cache = {}
         self._ws_bytes = {}              # the descriptor never changes after construction
 
-    def _ws(self, op, like):
+    def _kernel_only_bytes(self):
+        """Size of the workspace when it holds NOTHING but the re-laid-out 16-bit kernel (+ its zero line); 0 for
+        fp32 and for channels_first descriptors (their workspace also carries re-laid-out operands)."""
+        d = self.desc
+        if d.dtype == L.QK_F32 or getattr(d, 'layout', L.QK_CH_LAST) != L.QK_CH_LAST:
+            return 0
+        return int(math.prod(self.w_shape)) * 2 + 256
+
+    def _ws(self, op, like, wparam=None):
+        """Workspace of operation `op`.  `wparam`: the PARAMETER the kernel argument is (a long-lived leaf tensor).  When the
+        workspace holds only the kernel's 16-bit re-layout, it is kept ON the parameter together with the tensor version it
+        was made from, and handed back with desc.ws_has_kernel = 1 as long as the weights have not changed -- the C side then
+        skips the re-layout launch (26 launches per TIMIT training step).  Every in-place update bumps the version
+        (torch ops do it themselves, adam_step through torch.autograd.graph.increment_version); a re-homed `.data` changes
+        the pointer; a parameter re-homed into a dp.FlatParams buffer is also checked against THAT buffer's version (writes through
+        the flat buffer -- the fused Adam, a broadcast -- do not touch the views' own counters); the cache dies with the parameter."""
         n = self._ws_bytes.get(op)
         if n is None:
             n = self._ws_bytes[op] = int(getattr(L.lib(), self.ws_fn)(ctypes.byref(self.desc), op))
+        self.desc.ws_has_kernel = 0
         if n == 0:
             return None, 0
+        if (wparam is not None and not self.static_buffers and n == self._kernel_only_bytes() and wparam.is_leaf
+                and wparam.requires_grad and _PREP_CACHE_ON):
+            key = ('f' if op == L.QK_OP_FWD else 't', int(self.desc.conj) if hasattr(self.desc, 'conj') else 1, int(self.desc.dtype))
+            cache = wparam.__dict__.setdefault('_qk_prep', {})
+            base = getattr(wparam, '_qk_flat_base', None)         # dp.FlatParams: the flat buffer this parameter is a view of --
+            ver = (wparam._version, -1 if base is None else base._version)    # `.data` views do not share its version counter
+            hit = cache.get(key)
+            if hit is not None and hit[0] == ver and hit[1] == wparam.data_ptr() and hit[2].numel() == n \
+                    and hit[2].device == like.device:
+                self.desc.ws_has_kernel = 1
+                return hit[2], n
+            buf = torch.empty(n, dtype=torch.uint8, device=like.device)
+            cache[key] = (ver, wparam.data_ptr(), buf)
+            return buf, n
         if self.static_buffers:
             buf = self._ws_cache.get(op)
             if buf is None:
@@ -83,18 +114,18 @@ class _Call(object):
             return buf, n
         return torch.empty(n, dtype=torch.uint8, device=like.device), n
 
-    def fwd(self, x, w, bias, out=None):
+    def fwd(self, x, w, bias, out=None, wparam=None):
         y = out if out is not None else torch.empty(self.y_shape, dtype=x.dtype, device=x.device)
-        ws, n = self._ws(L.QK_OP_FWD, x)
+        ws, n = self._ws(L.QK_OP_FWD, x, wparam)
         with _on_device(x.device):
             rc = getattr(L.lib(), self.names[0])(ctypes.byref(self.desc), _ptr(x), _ptr(w), _ptr(bias),
                                                  _ptr(y), _ptr(ws), n, _stream(x))
         L.check(rc, self.names[0])
         return y
 
-    def bwd_data(self, dy, y, w, out=None):
+    def bwd_data(self, dy, y, w, out=None, wparam=None):
         dx = out if out is not None else torch.empty(self.x_shape, dtype=dy.dtype, device=dy.device)
-        ws, n = self._ws(L.QK_OP_BWD_DATA, dy)
+        ws, n = self._ws(L.QK_OP_BWD_DATA, dy, wparam)
         with _on_device(dy.device):
             rc = getattr(L.lib(), self.names[1])(ctypes.byref(self.desc), _ptr(dy), _ptr(y), _ptr(w),
                                                  _ptr(dx), _ptr(ws), n, _stream(dy))
@@ -122,19 +153,19 @@ class _Call(object):
         return dw, db
 
 
-    def fwd_post(self, x, w, bias, post):
+    def fwd_post(self, x, w, bias, post, wparam=None):
         """(pre, y) = qk_conv_fwd_post: the LINEAR convolution and post(pre) (PReLU / dropout) from one launch.  The relu
         form of the post-op (post.alpha is None) writes y only: pre is None."""
         pre = torch.empty(self.y_shape, dtype=x.dtype, device=x.device) if post.alpha is not None else None
         y = torch.empty(self.y_shape, dtype=x.dtype, device=x.device)
-        ws, n = self._ws(L.QK_OP_FWD, x)
+        ws, n = self._ws(L.QK_OP_FWD, x, wparam)
         with _on_device(x.device):
             rc = L.lib().qk_conv_fwd_post(ctypes.byref(self.desc), ctypes.byref(post.struct), _ptr(x), _ptr(w), _ptr(bias),
                                           _ptr(pre), _ptr(y), _ptr(ws), n, _stream(x))
         L.check(rc, 'qk_conv_fwd_post')
         return pre, y
 
-    def bwd_post(self, x, dy, w, has_bias, post_x, x_pre, dalpha_x, direct=None):
+    def bwd_post(self, x, dy, w, has_bias, post_x, x_pre, dalpha_x, direct=None, wparam=None):
         """Fused backward of a LINEAR layer whose input x = post_x(x_pre): returns (d x_pre, dw, db) and accumulates
         the slope gradient of post_x into dalpha_x (qk_conv_bwd_post).  direct = (dw, db) buffers to ADD into
         (QK_BWD_ACCUMULATE; the returned dw / db are then None).  Relu form of post_x: x_pre / dalpha_x are None."""
@@ -144,7 +175,7 @@ class _Call(object):
         else:
             dw = torch.empty(self.w_shape, dtype=torch.float32, device=x.device)
             db = torch.empty((self.w_shape[-1],), dtype=torch.float32, device=x.device) if has_bias else None
-        ws, n = self._ws(L.QK_OP_BWD, x)
+        ws, n = self._ws(L.QK_OP_BWD, x, wparam)
         with _on_device(x.device):
             rc = L.lib().qk_conv_bwd_post(ctypes.byref(self.desc), _ptr(x), _ptr(dy), _ptr(w), _ptr(dx), _ptr(dw), _ptr(db),
                                           ctypes.byref(post_x.struct), _ptr(x_pre), _ptr(dalpha_x),
@@ -152,7 +183,7 @@ class _Call(object):
         L.check(rc, 'qk_conv_bwd_post')
         return (dx, None, None) if direct is not None else (dx, dw, db)
 
-    def bwd(self, x, dy, y, w, has_bias, out=None, flags=0):
+    def bwd(self, x, dy, y, w, has_bias, out=None, flags=0, wparam=None):
         """Fused backward (qk_*_bwd, or qk_*_bwd_chain with L.QK_BWD_* flags): returns (dx, dw, db)."""
         if out is not None:
             dx, dw, db = out
@@ -160,7 +191,7 @@ class _Call(object):
             dx = torch.empty(self.x_shape, dtype=dy.dtype, device=dy.device)
             dw = torch.empty(self.w_shape, dtype=torch.float32, device=x.device)
             db = torch.empty((self.w_shape[-1],), dtype=torch.float32, device=x.device) if has_bias else None
-        ws, n = self._ws(L.QK_OP_BWD, x)
+        ws, n = self._ws(L.QK_OP_BWD, x, wparam)
         name = self.names[1].replace('_bwd_data', '_bwd')
         with _on_device(x.device):
             if flags:
@@ -284,7 +315,7 @@ def _grad_ready(*params):
 class _HamiltonFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, bias, call):
-        y = call.fwd(x, w, bias)
+        y = call.fwd(x, w, bias, wparam=w)
         ctx.call = call
         ctx.has_bias = bias is not None
         ctx.params = (w, bias)
@@ -302,11 +333,11 @@ class _HamiltonFn(torch.autograd.Function):
         if ctx.needs_input_grad[0] and want_w:
             if direct is not None:
                 dx = torch.empty(call.x_shape, dtype=dy.dtype, device=dy.device)
-                call.bwd(x, dy, y, w, ctx.has_bias, out=(dx,) + direct, flags=L.QK_BWD_ACCUMULATE)
+                call.bwd(x, dy, y, w, ctx.has_bias, out=(dx,) + direct, flags=L.QK_BWD_ACCUMULATE, wparam=ctx.params[0])
             else:
-                dx, dw, db = call.bwd(x, dy, y, w, ctx.has_bias)        # fused: one pass over (dy, y)
+                dx, dw, db = call.bwd(x, dy, y, w, ctx.has_bias, wparam=ctx.params[0])        # fused: one pass over (dy, y)
         elif ctx.needs_input_grad[0]:
-            dx = call.bwd_data(dy, y, w)
+            dx = call.bwd_data(dy, y, w, wparam=ctx.params[0])
         elif want_w:
             if direct is not None:
                 call.bwd_weight(x, dy, y, ctx.has_bias, out=direct, accumulate=True)
@@ -511,6 +542,9 @@ def adam_step(param, grad, m, v, step, lr=0.001, beta1=0.9, beta2=0.999, eps=1e-
             fn = L.lib().qk_adam_step_zero_grad if zero_grad else L.lib().qk_adam_step
             rc = fn(_ptr(param), _ptr(grad), _ptr(m), _ptr(v), n, lr, beta1, beta2, eps, int(step), grad_scale, _stream(param))
     L.check(rc, 'qk_adam_step')
+    # the kernel wrote `param` behind torch's back: move its version counter (every view of a flat buffer shares it), so that
+    # cached 16-bit re-layouts of the kernels (_Call._ws) are seen as stale
+    torch.autograd.graph.increment_version(param)
 
 
 class _MaxPoolCL(torch.autograd.Function):
@@ -725,10 +759,10 @@ class _ConvChainFn(torch.autograd.Function):
         acts, pres = [x], []
         for call, w, b, post in zip(calls, ws, bs, posts):
             if post is None:
-                acts.append(call.fwd(acts[-1], w, b))
+                acts.append(call.fwd(acts[-1], w, b, wparam=w))
                 pres.append(None)
             else:
-                pre, y = call.fwd_post(acts[-1], w, b, post)
+                pre, y = call.fwd_post(acts[-1], w, b, post, wparam=w)
                 acts.append(y)
                 pres.append(pre)
         if chain_tap is not None:
@@ -761,7 +795,7 @@ class _ConvChainFn(torch.autograd.Function):
             direct = _direct_grad(pw, pb, ctx.needs_input_grad[3 + i], ctx.has_bias[i] and ctx.needs_input_grad[3 + n + i])
             if i > 0 and posts[i - 1] is not None:
                 g, dws[i], dbs[i] = calls[i].bwd_post(acts[i], g, ws[i], ctx.has_bias[i], posts[i - 1], pres[i - 1], das[i - 1],
-                                                      direct=direct)
+                                                      direct=direct, wparam=pw)
                 if direct is not None:
                     _grad_ready(pw, pb)
                 continue
@@ -782,11 +816,12 @@ class _ConvChainFn(torch.autograd.Function):
                 flags |= L.QK_BWD_DY_PREMASKED
             if direct is not None:
                 dx = torch.empty(calls[i].x_shape, dtype=g.dtype, device=g.device)
-                calls[i].bwd(acts[i], g, acts[i + 1], ws[i], ctx.has_bias[i], out=(dx,) + direct, flags=flags | L.QK_BWD_ACCUMULATE)
+                calls[i].bwd(acts[i], g, acts[i + 1], ws[i], ctx.has_bias[i], out=(dx,) + direct, flags=flags | L.QK_BWD_ACCUMULATE,
+                             wparam=pw)
                 _grad_ready(pw, pb)
                 g = dx
             else:
-                g, dws[i], dbs[i] = calls[i].bwd(acts[i], g, acts[i + 1], ws[i], ctx.has_bias[i], flags=flags)
+                g, dws[i], dbs[i] = calls[i].bwd(acts[i], g, acts[i + 1], ws[i], ctx.has_bias[i], flags=flags, wparam=pw)
         das = [None if d is None else d.reshape(p.alpha.shape) for d, p in zip(das, posts)]      # (relu form: no slopes)
         return (g, None, None) + tuple(dws) + tuple(dbs) + tuple(das)
 

@@ -1354,6 +1354,60 @@ def test_fused_first_layer_conv_prelu_pool_matches_oracle(shape, F, per_row, dty
     assert float(np.abs(at.grad.reshape(-1).cpu().numpy() - dalpha).max()) <= tol32 * scale
 
 
+def test_cached_kernel_relayout_follows_every_kind_of_weight_update():
+    """The 16-bit re-layout of a layer's kernel is kept on the parameter and reused (desc.ws_has_kernel = 1: no k_prep_w16
+    launch) until the weights change.  Every way the weights can change must invalidate it: a torch in-place op on the
+    parameter, the fused Adam kernel writing through a dp.FlatParams buffer, a torch op on that flat buffer, and re-homing the
+    parameter's storage.  Reference: the same call with the cache switched off."""
+    import qcnn_amd
+    F = qcnn_amd.functional
+    dev = _dev()
+    dt = torch.bfloat16
+    g = torch.Generator(device=dev).manual_seed(5)
+    x = torch.randn(2, 6, 40, 128, device=dev, generator=g).to(dt).requires_grad_(True)
+    w = torch.nn.Parameter(torch.randn(3, 5, 32, 128, device=dev, generator=g) / 30)
+    b = torch.nn.Parameter(torch.zeros(128, device=dev))
+    dy = torch.randn(2, 6, 40, 128, device=dev, generator=g).to(dt)
+    kw = dict(padding='same', activation=None)      # (a fused-relu layer's backward workspace also carries the masked dy: not cached)
+
+    def run():
+        x.grad = None
+        y = F.quaternion_conv(x, w, b, **kw)
+        y.backward(dy)
+        return y.detach().clone(), x.grad.clone()
+
+    def fresh():
+        F._PREP_CACHE_ON = False
+        try:
+            return run()
+        finally:
+            F._PREP_CACHE_ON = True
+
+    def check(what):
+        got, want = run(), fresh()
+        assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]), what
+        return got
+    y0 = check('first call')
+    assert set(w._qk_prep) == {('f', 0, 1), ('t', 0, 1)}                       # forward and backward-data layouts are cached
+    bufs = {k: v[2].data_ptr() for k, v in w._qk_prep.items()}
+    y1 = check('second call: cache hit')
+    assert {k: v[2].data_ptr() for k, v in w._qk_prep.items()} == bufs and torch.equal(y0[0], y1[0])
+    with torch.no_grad():
+        w.mul_(2.0)                                                          # torch in-place op on the parameter
+    y2 = check('after w.mul_')
+    assert not torch.equal(y2[0], y1[0])
+    flat = qcnn_amd.dp.FlatParams([w, b], direct=True)                        # storage re-homed
+    check('after re-homing into FlatParams')
+    m, v = torch.zeros_like(flat.param), torch.zeros_like(flat.param)
+    flat.grad.normal_(generator=g)
+    F.adam_step(flat.param, flat.grad, m, v, 1, lr=1e-2, zero_grad=True)      # raw writes through the flat buffer
+    y3 = check('after adam_step')
+    with torch.no_grad():
+        flat.param.mul_(0.5)                                                 # torch op on the flat buffer, not on the view
+    y4 = check('after flat.param.mul_')
+    assert not torch.equal(y4[0], y3[0])
+
+
 def test_library_profiler_times_every_call_of_a_backward():
     """qk_prof_* (include/qk.h): with the recorder on, a layer's forward and its fused backward (backward-weight +
     backward-data inside ONE C call, on autograd's thread) leave three records carrying the layer's GEMM view, the
