@@ -363,6 +363,14 @@ int qk_adam_step_zero_grad(float *param, float *grad, float *m, float *v, size_t
                            float beta1, float beta2, float eps, int32_t step, float grad_scale,
                            void *stream);
 
+/* Batched form of the 16-bit kernel re-layout every forward / backward-data call otherwise does for itself: for job i,
+ * write into workspaces[i] what a call of operation ops[i] (QK_OP_FWD, or QK_OP_BWD_DATA / QK_OP_BWD) with descriptor
+ * descs[i] and kernel w[i] would write at the start of its workspace -- ONE launch for up to 32 jobs.  Meant to run once
+ * behind each optimiser step; the calls of the next training step then pass desc.ws_has_kernel = 1 with those workspaces
+ * and launch nothing but their GEMM kernel.  16-bit channels_last descriptors with cq, fq multiples of 32 only. */
+int qk_conv_prep_kernels(int32_t n, const qk_conv_desc_t *const *descs, const int32_t *ops, const float *const *w,
+                         void *const *workspaces, void *stream);
+
 /* qk_adam_step(_zero_grad) with the model's l2 kernel regularisers folded in.  Keras adds  l2 * sum(w^2)  of every
  * regularised kernel to the loss (models/interspeech_model.py:63,68,173: kernel_regularizer=l2(d.l2)); its gradient
  * 2 * l2 * w is applied here as  g = grad * grad_scale + decay[i] * param[i]  (decay: one coefficient per element,

@@ -981,6 +981,37 @@ int qk_maxpool2d_bwd(const qk_pool_desc_t *desc, const void *x, const void *dy, 
     return check_launch(launch_maxpool(desc->dtype, true, x, dy, dx, g, (hipStream_t)stream), "qk_maxpool2d_bwd");
 }
 
+int qk_conv_prep_kernels(int32_t n, const qk_conv_desc_t *const *descs, const int32_t *ops, const float *const *w,
+                         void *const *workspaces, void *stream)
+{
+    if (n < 0 || (n > 0 && (!descs || !ops || !w || !workspaces))) { set_error("qk_conv_prep_kernels: NULL argument"); return QK_ERR_INVALID_ARG; }
+    for (int dt = QK_BF16; dt <= QK_F16; ++dt) {
+        PrepJobs jobs;
+        int m = 0;
+        for (int i = 0; i <= n; ++i) {
+            if (i < n) {
+                const qk_conv_desc_t *d = descs[i];
+                if (!d || !w[i] || !workspaces[i]) { set_error("qk_conv_prep_kernels: job %d has a NULL member", i); return QK_ERR_INVALID_ARG; }
+                if (d->dtype != dt) continue;
+                if (ops[i] != QK_OP_FWD && ops[i] != QK_OP_BWD_DATA && ops[i] != QK_OP_BWD) { set_error("qk_conv_prep_kernels: job %d: bad op %d", i, ops[i]); return QK_ERR_INVALID_ARG; }
+                if (d->cq % 32 || d->fq % 32 || !aligned(workspaces[i], 16)) { set_error("qk_conv_prep_kernels: job %d is outside the 16-bit path", i); return QK_ERR_UNSUPPORTED; }
+                const bool bwd = ops[i] != QK_OP_FWD;
+                PrepJob &j = jobs.j[m++];
+                j.w = w[i]; j.wq = workspaces[i]; j.taps = taps_of(d); j.cq = d->cq; j.fq = d->fq;
+                j.transposed = bwd ? 1 : 0;
+                j.neg_ijk = bwd ? (d->conj ? 1 : 0) : (d->conj ? 0 : 1);       // the sign table go16 folds into the kernel
+            }
+            if (m == 32 || (i == n && m > 0)) {
+                if (int rc = launch_prep_w16_batch(dt, jobs, m, (hipStream_t)stream)) return check_launch(rc, "qk_conv_prep_kernels");
+                m = 0;
+            }
+        }
+    }
+    for (int i = 0; i < n; ++i)
+        if (descs[i]->dtype != QK_BF16 && descs[i]->dtype != QK_F16) { set_error("qk_conv_prep_kernels: job %d is not a 16-bit descriptor", i); return QK_ERR_INVALID_ARG; }
+    return QK_OK;
+}
+
 int qk_adam_step(float *param, const float *grad, float *m, float *v, size_t n, float lr, float beta1,
                  float beta2, float eps, int32_t step, float grad_scale, void *stream)
 {

@@ -228,6 +228,10 @@ int launch_wgrad(int dtype, const void *x, const void *dy, const void *ymask, fl
                  float *dbias, WgradGeom g, bool vec_ok, hipStream_t stream);
 int launch_fold_taps(int dtype, const void *x, void *xcol, const GemmGeom &g, int cq2, hipStream_t stream);
 int launch_mask_gt0(int dtype, void *data, const void *mask, size_t n, hipStream_t stream);   // data *= (mask > 0)
+// batched 16-bit re-layout of compact kernels (qk_conv_prep_kernels): up to 32 jobs per launch, passed by value
+struct PrepJob { const float *w; void *wq; int taps, cq, fq, transposed, neg_ijk; };
+struct PrepJobs { PrepJob j[32]; };
+int launch_prep_w16_batch(int dtype, const PrepJobs &jobs, int n, hipStream_t stream);
 int launch_relayout16(const void *src, void *dst, int n, int A, int B, hipStream_t stream);     // (n, A, B) -> (n, B, A), 16-bit
 struct PoolGeom { int batch, ih, iw, C, wh, ww, oh, ow; };
 int launch_maxpool(int dtype, bool backward, const void *x, const void *dy, void *out, const PoolGeom &g, hipStream_t stream);

@@ -100,6 +100,37 @@ k_prep_w16(const float *__restrict__ w, T *__restrict__ wq, int taps, int Cq, in
     if (blockIdx.x == 0 && threadIdx.x < 128) wq[total + threadIdx.x] = from_f32<T>(0.f);   // zero line for padding rows
 }
 
+// The same re-layout for up to 32 (layer, direction) jobs in ONE launch (qk_conv_prep_kernels): a training step re-lays
+// every kernel out twice (forward and backward-data form) after each optimiser step -- 26 launches of ~5 us for the TIMIT
+// model; batched, they are one.
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_prep_w16_batch(const PrepJobs jobs)
+{
+    const PrepJob &jb = jobs.j[blockIdx.y];
+    const float *__restrict__ w = jb.w;
+    T *__restrict__ wq = static_cast<T *>(jb.wq);
+    const int Cq = jb.cq, F = jb.fq, transposed = jb.transposed, neg_ijk = jb.neg_ijk;
+    const int Q = transposed ? F : Cq;
+    const int J = transposed ? Cq : F;
+    const long long total = (long long)jb.taps * Q * 4 * J;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        long long r = idx;
+        const int e = r % 8; r /= 8;
+        const int j = r % J; r /= J;
+        const int p = r % 4; r /= 4;
+        const int slot = r % 4; r /= 4;
+        const int kc = r % (Q / 32);
+        const int t = r / (Q / 32);
+        const int k = kc * 32 + slot * 8 + e;
+        const int c = transposed ? j : k;
+        const int f = transposed ? k : j;
+        const float v = w[((long long)(t * Cq + c) * 4 + p) * F + f];
+        wq[idx] = from_f32<T>(neg_ijk && p ? -v : v);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 128) wq[total + threadIdx.x] = from_f32<T>(0.f);
+}
+
 // Workgroup-wide OR of a per-thread bit mask (bits [0, nbits)) over NW waves: one ballot per bit inside each
 // wave, one LDS word per wave, one barrier.  (512 atomicOr on one LDS word serialise: ~7 us per tile, measured.)
 template <int NW>
@@ -1181,6 +1212,24 @@ int go16(const void *in, const void *mask, const float *w, const float *bias, vo
 }
 
 }  // namespace
+
+int launch_prep_w16_batch(int dtype, const PrepJobs &jobs, int n, hipStream_t stream)
+{
+    if (n <= 0) return 0;
+    long long most = 0;
+    for (int i = 0; i < n; ++i) {
+        const long long t = (long long)jobs.j[i].taps * jobs.j[i].cq * 4 * jobs.j[i].fq;
+        if (t > most) most = t;
+    }
+    int blocks = (int)((most + 255) / 256);
+    if (blocks > 256) blocks = 256;
+    if (blocks < 1) blocks = 1;
+    dim3 grid((unsigned)blocks, (unsigned)n, 1);
+    if (dtype == QK_BF16) hipLaunchKernelGGL((k_prep_w16_batch<bf16>), grid, dim3(256), 0, stream, jobs);
+    else if (dtype == QK_F16) hipLaunchKernelGGL((k_prep_w16_batch<f16>), grid, dim3(256), 0, stream, jobs);
+    else return QK_ERR_INVALID_ARG;
+    return hipGetLastError() == hipSuccess ? 0 : QK_ERR_LAUNCH;
+}
 
 // Returns 1 when the 16-bit MFMA path took the call, 0 when the shape is outside its fast path
 // (the caller then runs the general fp32-MFMA kernel), < 0 on error.

@@ -19,6 +19,48 @@ from ._shape import conv_output_length, normalize_tuple, tf_pads
 
 _DTYPES = {torch.float32: L.QK_F32, torch.bfloat16: L.QK_BF16, torch.float16: L.QK_F16}
 _PREP_CACHE_ON = not __import__('os').environ.get('QK_NO_PREP_CACHE')     # diagnostic: re-lay the 16-bit kernels out on every call
+_PREP_PARAMS = __import__('weakref').WeakValueDictionary()   # id -> parameter that carries cached 16-bit re-layouts (_Call._ws)
+
+
+def refresh_prepped_kernels(base=None):
+    """Bring every cached 16-bit kernel re-layout up to date in ONE launch (qk_conv_prep_kernels): called by adam_step
+    behind the update, so that the next training step's forward / backward calls find their workspace ready
+    (desc.ws_has_kernel = 1) and launch nothing but the GEMM kernel -- 26 small launches per TIMIT step become one.
+    base: restrict to the parameters that live in this flat buffer (or are this tensor).  Returns the number of jobs."""
+    descs, ops, ws_ptrs, w_ptrs, entries = [], [], [], [], []
+    dev = None
+    for p in list(_PREP_PARAMS.values()):
+        cache = p.__dict__.get('_qk_prep')
+        if not cache or not p.is_cuda:
+            continue
+        pbase = getattr(p, '_qk_flat_base', None)
+        if base is not None and pbase is not base and p is not base:
+            continue
+        ver = (p._version, -1 if pbase is None else pbase._version)
+        for key, ent in cache.items():
+            if ent[0] == ver or ent[1] != p.data_ptr():
+                continue
+            if dev is None:
+                dev = p.device
+            if p.device != dev:
+                continue
+            job = ent[3]
+            descs.append(job[0]); ops.append(job[1]); ws_ptrs.append(ent[2].data_ptr()); w_ptrs.append(p.data_ptr())
+            entries.append((ent, ver))
+    n = len(descs)
+    if n == 0:
+        return 0
+    dp = (ctypes.POINTER(L.ConvDesc) * n)(*[ctypes.pointer(d) for d in descs])
+    op_arr = (ctypes.c_int32 * n)(*ops)
+    w_arr = (ctypes.c_void_p * n)(*w_ptrs)
+    ws_arr = (ctypes.c_void_p * n)(*ws_ptrs)
+    with torch.cuda.device(dev):
+        rc = L.lib().qk_conv_prep_kernels(n, dp, op_arr, w_arr, ws_arr, _raw_stream(dev.index) if _raw_stream is not None
+                                          else torch.cuda.current_stream(dev).cuda_stream)
+    L.check(rc, 'qk_conv_prep_kernels')
+    for ent, ver in entries:
+        ent[0] = ver
+    return n
 
 
 def _require_device(t, what):
@@ -71,6 +113,18 @@ class _Call(object):
         self._ws_cache = {}
         self._ws_bytes = {}              # the descriptor never changes after construction
 
+    def _prep_job(self, op):
+        """(conv descriptor, operation) that reproduces this call's kernel re-layout through qk_conv_prep_kernels."""
+        d = self.desc
+        if isinstance(d, L.DenseDesc):
+            c = L.ConvDesc()
+            c.rank, c.batch, c.cq, c.fq, c.dtype, c.conj, c.layout = 0, d.rows, d.in_q, d.q_units, d.dtype, 1, L.QK_CH_LAST
+            for i in range(3):
+                c.in_spatial[i] = c.out_spatial[i] = c.kernel[i] = c.stride[i] = c.dilation[i] = 1
+        else:
+            c = L.ConvDesc.from_buffer_copy(d)
+        return c, (L.QK_OP_FWD if op == L.QK_OP_FWD else L.QK_OP_BWD_DATA)
+
     def _kernel_only_bytes(self):
         """Size of the workspace when it holds NOTHING but the re-laid-out 16-bit kernel (+ its zero line); 0 for
         fp32 and for channels_first descriptors (their workspace also carries re-laid-out operands)."""
@@ -105,7 +159,8 @@ class _Call(object):
                 self.desc.ws_has_kernel = 1
                 return hit[2], n
             buf = torch.empty(n, dtype=torch.uint8, device=like.device)
-            cache[key] = (ver, wparam.data_ptr(), buf)
+            cache[key] = [ver, wparam.data_ptr(), buf, self._prep_job(op)]
+            _PREP_PARAMS[id(wparam)] = wparam
             return buf, n
         if self.static_buffers:
             buf = self._ws_cache.get(op)
@@ -545,6 +600,8 @@ def adam_step(param, grad, m, v, step, lr=0.001, beta1=0.9, beta2=0.999, eps=1e-
     # the kernel wrote `param` behind torch's back: move its version counter (every view of a flat buffer shares it), so that
     # cached 16-bit re-layouts of the kernels (_Call._ws) are seen as stale
     torch.autograd.graph.increment_version(param)
+    if _PREP_CACHE_ON:
+        refresh_prepped_kernels(param)
 
 
 class _MaxPoolCL(torch.autograd.Function):
