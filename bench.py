@@ -582,7 +582,7 @@ def main():
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
         # started plainly: this process becomes the launcher of N ranks (one per GPU) and relays rank 0's line
         n_dev = torch.cuda.device_count()
-        if n_dev < args.gpus:
+        if n_dev < args.gpus and not os.environ.get('QK_DP_SHARE_DEVICE'):       # (diagnostic: all ranks on cuda:0, see dp.init_from_env)
             sys.exit('bench.py: --gpus %d but only %d GPU(s) are visible on this node' % (args.gpus, n_dev))
         sys.exit(dp.spawn_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
                                 env=dict(os.environ, QK_BENCH_SELF_LAUNCHED='1')))
@@ -591,7 +591,7 @@ def main():
     world_env, local_env = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('LOCAL_RANK', '0'))
     if world_env != args.gpus:
         sys.exit('bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks' % (args.gpus, world_env))
-    if local_env >= torch.cuda.device_count():
+    if local_env >= torch.cuda.device_count() and not os.environ.get('QK_DP_SHARE_DEVICE'):
         sys.exit('bench.py: LOCAL_RANK %d but only %d GPU(s) are visible' % (local_env, torch.cuda.device_count()))
     rank, world, local = dp.init_from_env()
     dev = torch.device('cuda', local)
@@ -631,7 +631,8 @@ def main():
 
     out = {
         'metric': 'quaternion-conv samples/sec (fwd+bwd+Adam of %s)' % ('the config-5 stack, per-GPU batch %d' % cfg['batch'] if is_stack else 'the full TIMIT QCNN, per-GPU batch %d' % cfg['batch'] if is_model else 'one QuaternionConv layer'),
-        'ranks': 'one process per GPU (%s)' % ('launched by bench.py itself: qcnn_amd.dp.spawn_ranks' if os.environ.get('QK_BENCH_SELF_LAUNCHED') else
+        'ranks': ('DIAGNOSTIC: %d ranks sharing cuda:0 over %s -- not a performance number' % (world, os.environ.get('QK_DP_BACKEND', 'nccl'))) if os.environ.get('QK_DP_SHARE_DEVICE') else
+                 'one process per GPU (%s)' % ('launched by bench.py itself: qcnn_amd.dp.spawn_ranks' if os.environ.get('QK_BENCH_SELF_LAUNCHED') else
                                                'started by an external launcher' if 'WORLD_SIZE' in os.environ else 'single process'),
         'value': samples_per_s, 'unit': 'samples/s', 'n_gpus': world, 'steps': steps,
         'warmup': warmup, 'pre_warmup_steps': pre, 'ms_per_step': ms_per_step, 'higher_is_better': True,

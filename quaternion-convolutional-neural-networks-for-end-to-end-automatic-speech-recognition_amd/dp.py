@@ -86,12 +86,18 @@ def init_from_env(backend=None):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    # Diagnostics for a ONE-GPU box: QK_DP_SHARE_DEVICE=1 puts every rank on cuda:0 and QK_DP_BACKEND=gloo carries the
+    # collectives (RCCL refuses two ranks on one device) -- the engine's data-parallel step (direct gradient writes, buckets
+    # launched from the backward, fused Adam) then runs with REAL peer processes; tests/test_dp_gloo.py uses it.  Not a
+    # performance mode.
+    if os.environ.get('QK_DP_SHARE_DEVICE'):
+        local = 0
     if (world > 1 or _FORCE) and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+            backend = os.environ.get('QK_DP_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         if backend == 'nccl':
             torch.cuda.set_device(local)
             dist.init_process_group(backend, rank=rank, world_size=world,
