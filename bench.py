@@ -134,9 +134,10 @@ class ModelTrainStep(object):
         self.target = torch.randn(B, T, 62, device=dev, generator=gen)
         if loss == 'ctc':        # K.ctc_batch_cost inputs (interspeech_model.py:37-39,83-85): 61 phone labels + blank
             cg = torch.Generator().manual_seed(99 + rank)
-            self.label_length = torch.randint(20, 51, (B, 1), generator=cg)
-            self.labels = torch.randint(0, 61, (B, 50), generator=cg).to(dev)
-            self.input_length = torch.full((B, 1), T, dtype=torch.long)
+            # resident on the device like the features (a host tensor would be copied -- and the stream synchronised -- every step)
+            self.label_length = torch.randint(20, 51, (B, 1), generator=cg).to(dev, torch.int32)
+            self.labels = torch.randint(0, 61, (B, 50), generator=cg).to(dev, torch.int32)
+            self.input_length = torch.full((B, 1), T, dtype=torch.int32, device=dev)
         self.t = 0
         self.flops_per_kernel = qcnn_flops(cfg['sf'], cfg['layers'], B, T)      # forward; step = 3x
         self.gemm = dict(layers='conv 1->%d, %dx conv, 3x TD-dense' % (cfg['sf'], cfg['layers']),

@@ -363,6 +363,19 @@ int qk_adam_step_zero_grad(float *param, float *grad, float *m, float *v, size_t
                            float beta1, float beta2, float eps, int32_t step, float grad_scale,
                            void *stream);
 
+/* K.ctc_batch_cost(y_true, y_pred, input_length, label_length) -- what the reference's TIMIT model outputs
+ * (models/interspeech_model.py:37-39,178) -- and its gradient, as one launch: y_pred (batch, frames, classes) are the
+ * model's softmax outputs (blank = classes - 1), labels (batch, max_label_len) int32 padded, input_length / label_length
+ * (batch) int32.  Keras 2.x / TensorFlow semantics: log(y_pred + 1e-7) taken as LOGITS (normalised again per frame),
+ * ctc_merge_repeated = True, frames >= input_length ignored.  cost (batch) float32 = -log p(labels | y_pred);
+ * dy_pred (same dtype / shape as y_pred, or NULL) = d cost[b] / d y_pred[b].  One workgroup per sample; limits:
+ * max_label_len <= 127, classes <= 256, frames up to ~15 000 (LDS); QK_ERR_UNSUPPORTED beyond.
+ * Workspace: qk_ctc_workspace_bytes (the alpha lattice, frames x (2 max_label_len + 1) floats per sample). */
+size_t qk_ctc_workspace_bytes(int32_t batch, int32_t frames, int32_t max_label_len);
+int qk_ctc_batch_cost(int32_t dtype, int32_t batch, int32_t frames, int32_t classes, const void *y_pred, const int32_t *labels,
+                      int32_t max_label_len, const int32_t *input_length, const int32_t *label_length, float *cost, void *dy_pred,
+                      void *workspace, size_t workspace_bytes, void *stream);
+
 /* Batched form of the 16-bit kernel re-layout every forward / backward-data call otherwise does for itself: for job i,
  * write into workspaces[i] what a call of operation ops[i] (QK_OP_FWD, or QK_OP_BWD_DATA / QK_OP_BWD) with descriptor
  * descs[i] and kernel w[i] would write at the start of its workspace -- ONE launch for up to 32 jobs.  Meant to run once

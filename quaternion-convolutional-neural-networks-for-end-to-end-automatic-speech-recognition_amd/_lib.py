@@ -98,6 +98,8 @@ SYMBOLS = {
     'qk_dense_bwd_weight': (ctypes.c_int, [_DD, _VP, _VP, _VP, _FP, _FP, _VP, _SZ, _VP]),
     'qk_adam_step_zero_grad': (ctypes.c_int, [_FP, _FP, _FP, _FP, _SZ, ctypes.c_float, ctypes.c_float,
                                               ctypes.c_float, ctypes.c_float, I32, ctypes.c_float, _VP]),
+    'qk_ctc_workspace_bytes': (_SZ, [I32, I32, I32]),
+    'qk_ctc_batch_cost': (ctypes.c_int, [I32, I32, I32, I32, _VP, _VP, I32, _VP, _VP, _FP, _VP, _VP, _SZ, _VP]),
     'qk_conv_prep_kernels': (ctypes.c_int, [I32, ctypes.POINTER(_CD), ctypes.POINTER(I32), ctypes.POINTER(ctypes.c_void_p),
                                             ctypes.POINTER(ctypes.c_void_p), _VP]),
     'qk_adam_step_l2': (ctypes.c_int, [_FP, _FP, _FP, _FP, _FP, _SZ, ctypes.c_float, ctypes.c_float,

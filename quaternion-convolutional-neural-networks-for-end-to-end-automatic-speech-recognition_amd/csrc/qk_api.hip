@@ -981,6 +981,27 @@ int qk_maxpool2d_bwd(const qk_pool_desc_t *desc, const void *x, const void *dy, 
     return check_launch(launch_maxpool(desc->dtype, true, x, dy, dx, g, (hipStream_t)stream), "qk_maxpool2d_bwd");
 }
 
+size_t qk_ctc_workspace_bytes(int32_t batch, int32_t frames, int32_t max_label_len)
+{
+    if (batch <= 0 || frames <= 0 || max_label_len < 0) return 0;
+    return ctc_workspace_bytes(batch, frames, max_label_len);
+}
+
+int qk_ctc_batch_cost(int32_t dtype, int32_t batch, int32_t frames, int32_t classes, const void *y_pred, const int32_t *labels,
+                      int32_t max_label_len, const int32_t *input_length, const int32_t *label_length, float *cost, void *dy_pred,
+                      void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (batch <= 0 || frames <= 0 || classes < 2 || max_label_len < 0) { set_error("ctc: bad extents (%d, %d, %d, %d)", batch, frames, classes, max_label_len); return QK_ERR_INVALID_ARG; }
+    if (!y_pred || !input_length || !label_length || !cost || (max_label_len > 0 && !labels)) { set_error("ctc: NULL argument"); return QK_ERR_INVALID_ARG; }
+    const size_t need = ctc_workspace_bytes(batch, frames, max_label_len);
+    if (!workspace || workspace_bytes < need || !aligned(workspace, 4)) { set_error("ctc needs %zu workspace bytes, got %zu", need, workspace_bytes); return QK_ERR_WORKSPACE; }
+    if ((long long)batch * frames * classes > INT_MAX) { set_error("ctc: tensor with >= 2^31 elements"); return QK_ERR_UNSUPPORTED; }
+    const int rc = launch_ctc(dtype, batch, frames, classes, y_pred, labels, max_label_len, input_length, label_length, cost, dy_pred,
+                              static_cast<float *>(workspace), (hipStream_t)stream);
+    if (rc == QK_ERR_UNSUPPORTED) set_error("ctc: more than 127 labels, more than 256 classes or too many frames for one workgroup's LDS");
+    return check_launch(rc, "qk_ctc_batch_cost");
+}
+
 int qk_conv_prep_kernels(int32_t n, const qk_conv_desc_t *const *descs, const int32_t *ops, const float *const *w,
                          void *const *workspaces, void *stream)
 {

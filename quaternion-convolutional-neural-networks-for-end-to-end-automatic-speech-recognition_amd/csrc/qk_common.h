@@ -232,6 +232,9 @@ int launch_mask_gt0(int dtype, void *data, const void *mask, size_t n, hipStream
 struct PrepJob { const float *w; void *wq; int taps, cq, fq, transposed, neg_ijk; };
 struct PrepJobs { PrepJob j[32]; };
 int launch_prep_w16_batch(int dtype, const PrepJobs &jobs, int n, hipStream_t stream);
+size_t ctc_workspace_bytes(int B, int T, int Lmax);
+int launch_ctc(int dtype, int B, int T, int C, const void *pred, const int *labels, int Lmax, const int *in_len, const int *lab_len,
+               float *cost, void *dpred, float *ws, hipStream_t stream);
 int launch_relayout16(const void *src, void *dst, int n, int A, int B, hipStream_t stream);     // (n, A, B) -> (n, B, A), 16-bit
 struct PoolGeom { int batch, ih, iw, C, wh, ww, oh, ow; };
 int launch_maxpool(int dtype, bool backward, const void *x, const void *dy, void *out, const PoolGeom &g, hipStream_t stream);

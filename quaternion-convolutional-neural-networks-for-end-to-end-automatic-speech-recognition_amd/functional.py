@@ -911,3 +911,44 @@ def quaternion_conv_chain(x, layers):
         alphas.append(None if po is None else po['alpha'])
         shape = tuple(call.y_shape)
     return _ConvChainFn.apply(xp, tuple(calls), tuple(posts), *ws, *bs, *alphas)
+
+
+class _CtcFn(torch.autograd.Function):
+    """qk_ctc_batch_cost: cost and d cost / d y_pred from one launch; the backward only scales the stored gradient."""
+
+    @staticmethod
+    def forward(ctx, y_pred, labels, input_length, label_length):
+        b, t, c = y_pred.shape
+        lab = labels.to(device=y_pred.device, dtype=torch.int32).contiguous()
+        il = input_length.reshape(-1).to(device=y_pred.device, dtype=torch.int32).contiguous()
+        ll = label_length.reshape(-1).to(device=y_pred.device, dtype=torch.int32).contiguous()
+        lmax = lab.shape[1] if lab.dim() == 2 else 0
+        cost = torch.empty(b, dtype=torch.float32, device=y_pred.device)
+        want = ctx.needs_input_grad[0]
+        dpred = torch.empty_like(y_pred) if want else None
+        n = int(L.lib().qk_ctc_workspace_bytes(b, t, lmax))
+        ws = torch.empty(n, dtype=torch.uint8, device=y_pred.device)
+        with _on_device(y_pred.device):
+            rc = L.lib().qk_ctc_batch_cost(_DTYPES[y_pred.dtype], b, t, c, _ptr(y_pred), _ptr(lab), lmax, _ptr(il), _ptr(ll), _ptr(cost),
+                                           _ptr(dpred), _ptr(ws), n, _stream(y_pred))
+        L.check(rc, 'qk_ctc_batch_cost')
+        ctx.save_for_backward(dpred)
+        return cost.reshape(b, 1)
+
+    @staticmethod
+    def backward(ctx, dcost):
+        dpred, = ctx.saved_tensors
+        return dpred * dcost.reshape(-1, 1, 1).to(dpred.dtype), None, None, None
+
+
+def ctc_supported(y_pred, labels):
+    """qk_ctc_batch_cost takes a contiguous (B, T, C) device tensor with C <= 256 and at most 127 labels per sample."""
+    return (y_pred.is_cuda and y_pred.dtype in _DTYPES and y_pred.dim() == 3 and y_pred.shape[-1] <= 256 and y_pred.shape[0] > 0
+            and labels.dim() == 2 and labels.shape[1] <= 127 and (y_pred.shape[1] + 4 * labels.shape[1] + 2 + y_pred.shape[-1] + 4) * 4 <= 64 * 1024)
+
+
+def ctc_batch_cost(y_pred, labels, input_length, label_length):
+    """K.ctc_batch_cost(labels, y_pred, input_length, label_length) (interspeech_model.py:37-39): per-sample CTC cost (B, 1) of
+    the softmax outputs y_pred (B, T, C), blank = C - 1, Keras / TensorFlow semantics (include/qk.h: qk_ctc_batch_cost)."""
+    _require_device(y_pred, 'ctc_batch_cost')
+    return _CtcFn.apply(y_pred.contiguous(), labels, input_length, label_length)

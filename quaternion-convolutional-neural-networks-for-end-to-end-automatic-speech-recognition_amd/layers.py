@@ -10,6 +10,7 @@ torch ops with the Keras/TensorFlow semantics the models rely on (SURVEY.md 8f r
     (B, 4F, 41, T) tensor this pools the 41-bin frequency axis 41 -> 14).
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -260,6 +261,8 @@ def ctc_batch_cost(y_pred, labels, input_length, label_length, blank=None):
     the per-sample negative log-likelihood (B, 1).  Keras 2.x hands log(y_pred + epsilon()) to tf.nn.ctc_loss as
     LOGITS, and that op normalises them again (softmax), so the log-probabilities are
     log_softmax(log(y_pred + 1e-7)); ctc_merge_repeated=True, no collapse of repeated labels (TF defaults)."""
+    if (blank is None and y_pred.is_cuda and Fq.ctc_supported(y_pred, labels) and not os.environ.get('QK_NO_FUSED_CTC')):
+        return Fq.ctc_batch_cost(y_pred, labels, input_length, label_length)        # one HIP launch: cost + gradient
     blank = y_pred.shape[-1] - 1 if blank is None else blank
     logp = torch.log_softmax(torch.log(y_pred.float() + 1e-7), dim=-1).transpose(0, 1)
     loss = F.ctc_loss(logp, labels.long(), input_length.reshape(-1).long(), label_length.reshape(-1).long(),

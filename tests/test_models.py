@@ -373,6 +373,46 @@ def test_tall_dense_split_reduction_matches_plain_autograd():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['fp32', 'bf16'])
+@pytest.mark.parametrize('shape', [(5, 30, 10, 6), (3, 27, 62, 9), (256, 200, 62, 50), (2, 300, 62, 20)], ids=['small', 'odd', 'timit_b256', 'long_lp_from_global'])
+def test_fused_ctc_batch_cost_matches_the_keras_restatement(shape, dtype):
+    """qk_ctc_batch_cost (K.ctc_batch_cost of interspeech_model.py:37-39 as one launch: cost and d cost / d y_pred) against the
+    torch restatement of the Keras / TensorFlow op that the golden fixture G17 pins (layers.ctc_batch_cost with the fused path
+    off): ragged input and label lengths, repeated labels, an empty label sequence, frames past the input length."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    dev = torch.device('cuda:0')
+    b, t, c, lmax = shape
+    g = torch.Generator().manual_seed(b + t)
+    logits = torch.randn(b, t, c, generator=g) * 2.0
+    pred = torch.softmax(logits, -1).to(dev).to(dtype)
+    labels = torch.randint(0, c - 1, (b, lmax), generator=g)
+    labels[0, 1] = labels[0, 0]                                        # a repeated label: needs a blank between the two
+    ll = torch.randint(1, lmax + 1, (b, 1), generator=g)
+    ll[1, 0] = 0 if b > 1 else ll[0, 0]                                # an empty label sequence
+    il = torch.randint(max(2 * lmax + 2, t // 2), t + 1, (b, 1), generator=g).clamp(max=t)
+    w = torch.rand(b, 1, generator=g).to(dev) + 0.5                    # upstream gradient of the cost
+    outs = {}
+    for fused in (True, False):
+        if not fused:
+            os.environ['QK_NO_FUSED_CTC'] = '1'
+        try:
+            p = pred.clone().requires_grad_(True)
+            cost = ctc_batch_cost(p, labels.to(dev), il, ll)
+            (cost * w).sum().backward()
+            outs[fused] = (cost.detach().double().cpu(), p.grad.detach().double().cpu())
+        finally:
+            os.environ.pop('QK_NO_FUSED_CTC', None)
+    (cf, gf), (ct, gt) = outs[True], outs[False]
+    assert tuple(cf.shape) == (b, 1) and torch.isfinite(cf).all()
+    assert float((cf - ct).abs().max() / ct.abs().max()) <= (1e-5 if dtype == torch.float32 else 1e-5)     # same 16-bit inputs, fp32 math
+    tol = 2e-4 if dtype == torch.float32 else 1e-2                                                          # bf16: the gradient is stored in bf16
+    assert float((gf - gt).abs().max() / gt.abs().max()) <= tol
+    for i in range(b):                                                 # frames past the input length get no gradient
+        assert float(gf[i, int(il[i]):].abs().sum()) == 0.0
+
+
+@pytest.mark.gpu
 def test_deterministic_mode_makes_the_training_step_bit_repeatable():
     """QK_DBG_DETERMINISTIC (include/qk.h): every backward-weight kernel runs one split of its reduction per gradient
     tile and one owner per bias column, so no float sum depends on the order in which atomics land (TF's CPU
