@@ -118,7 +118,7 @@ def test_bench_step_through_one_rank_rccl_group():
     ar = rec['dp']['allreduce']
     assert ar['buckets'] == rec['config']['gemm_view']['allreduce_buckets'] and sum(ar['bucket_bytes']) == ar['bytes_per_step']
     assert ar['bytes_per_step'] >= 4 * rec['config']['gemm_view']['parameters']
-    assert abs(ar['exposed_ms_per_step']) < 0.2 * rec['ms_per_step']          # one rank: the collectives are (nearly) free
+    assert abs(ar['exposed_ms_per_step']) < 0.05 * rec['ms_per_step']         # one rank: nothing is sent, the collectives are free
 
 
 def _bucket_worker(rank, world, port, out_dir):

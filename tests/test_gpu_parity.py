@@ -1408,6 +1408,64 @@ def test_cached_kernel_relayout_follows_every_kind_of_weight_update():
     assert not torch.equal(y4[0], y3[0])
 
 
+def _random_layer_configs(n, seed):
+    """Seeded random layer configurations over everything the layer API accepts: rank 1-3 (+ dense), kernel extents 1-5,
+    strides / dilations 1-2 (never both > 1, as in Keras), valid / same / causal, both data formats, with and without bias,
+    relu / linear, channel counts on and off the 16-bit matrix-core path."""
+    rng = np.random.RandomState(seed)
+    out = []
+    for i in range(n):
+        rank = int(rng.choice([0, 1, 1, 2, 2, 3]))
+        cq = int(rng.choice([1, 2, 3, 5, 8, 32]))
+        fq = int(rng.choice([1, 2, 4, 32]))
+        bias = bool(rng.rand() < 0.7)
+        act = 'relu' if rng.rand() < 0.6 else None
+        if rank == 0:
+            out.append(('fuzz%02d_dense_%dx%d' % (i, cq, fq), 0, (int(rng.randint(1, 40)), 4 * cq), (cq, 4 * fq), dict(activation=act), bias))
+            continue
+        ks = tuple(int(rng.randint(1, 6 if rank < 3 else 4)) for _ in range(rank))
+        if rng.rand() < 0.5:
+            st, dl = tuple(int(rng.randint(1, 3)) for _ in range(rank)), (1,) * rank
+        else:
+            st, dl = (1,) * rank, tuple(int(rng.randint(1, 3)) for _ in range(rank))
+        pad = str(rng.choice(['valid', 'same', 'causal'] if rank == 1 else ['valid', 'same']))
+        sp = tuple(int(rng.randint((k - 1) * d + 1, (k - 1) * d + (14 if rank < 3 else 7))) for k, d in zip(ks, dl))
+        fmt = str(rng.choice(['channels_last', 'channels_first']))
+        bsz = int(rng.randint(1, 4))
+        xs = (bsz, 4 * cq) + sp if fmt == 'channels_first' else (bsz,) + sp + (4 * cq,)
+        kw = dict(strides=st, dilation_rate=dl, padding=pad, data_format=fmt, activation=act)
+        out.append(('fuzz%02d_r%d_k%s_s%s_d%s_%s_%s_c%d_f%d' % (i, rank, 'x'.join(map(str, ks)), 'x'.join(map(str, st)), 'x'.join(map(str, dl)),
+                                                               pad, 'cf' if fmt == 'channels_first' else 'cl', cq, fq), rank, xs, ks + (cq, 4 * fq), kw, bias))
+    return out
+
+
+FUZZ_CASES = _random_layer_configs(48, seed=2024)
+
+
+@pytest.mark.parametrize('layout', ['channels_last', 'native'])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['fp32', 'bf16'])
+@pytest.mark.parametrize('case', FUZZ_CASES, ids=[c[0] for c in FUZZ_CASES])
+def test_random_layer_configurations_match_oracle(case, dtype, layout):
+    """48 seeded random layer configurations (see _random_layer_configs) x {fp32, bf16} x {internal channels-last, native
+    layout}: output, d input, d kernel, d bias against the float64 oracle on the same operands -- the reference ships no
+    tests, so breadth over its argument space is ours to supply."""
+    import qcnn_amd
+    _, rank, xs, ws, kw, bias = case
+    if layout == 'native' and (rank == 0 or kw.get('data_format') != 'channels_first'):
+        pytest.skip('native == channels_last for this configuration')
+    x, w, b, dy, want = _oracle_case(rank, xs, ws, kw, seed=77, dtype=dtype, use_bias=bias)
+    got = _run_layer(qcnn_amd.functional, x, w, b, dy, rank, dict(kw), dtype, internal_layout=layout)
+    tol16, tol32 = (1e-4, 1e-4) if dtype == torch.float32 else (1e-2, 3e-3)
+    for k, v in got.items():
+        err = _rel_err(v, want[k])
+        if dtype == torch.float32 and kw.get('activation') == 'relu' and k != 'y' and err > 1e-4:
+            # a pre-activation within float32 rounding of zero may flip its relu mask: compare on the GPU's own mask
+            from oracle import oracle
+            dxm, dwm, dbm = oracle.backward(x, w, b, dy * (got['y'] > 0), rank, **dict(kw, activation=None))
+            err = _rel_err(v, dict(dx=dxm, dkernel=dwm, dbias=dbm)[k])
+        assert err <= (tol16 if k in ('y', 'dx') else tol32), '%s: rel err %.3g (%s)' % (k, err, case[0])
+
+
 def test_library_profiler_times_every_call_of_a_backward():
     """qk_prof_* (include/qk.h): with the recorder on, a layer's forward and its fused backward (backward-weight +
     backward-data inside ONE C call, on autograd's thread) leave three records carrying the layer's GEMM view, the
