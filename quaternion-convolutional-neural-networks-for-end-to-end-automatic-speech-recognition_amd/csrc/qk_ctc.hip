@@ -60,7 +60,8 @@ k_ctc(const T *__restrict__ pred, const int *__restrict__ labels, const int *__r
     // state of this thread (S <= CTC_THREADS is checked by the launcher)
     const int s = tid;
     const bool live = s < S;
-    const int cls = live ? ((s & 1) ? labels[b * g.Lmax + (s >> 1)] : blank) : blank;
+    // (a label outside [0, C - 2] is clamped: never an out-of-range read; TF raises for such input)
+    const int cls = live ? ((s & 1) ? min(max(labels[b * g.Lmax + (s >> 1)], 0), g.C - 1) : blank) : blank;
     const bool skip_ok = live && (s & 1) && s >= 3 && labels[b * g.Lmax + (s >> 1)] != labels[b * g.Lmax + (s >> 1) - 1];   // s-2 -> s
     // the beta recursion looks the other way: s -> s + 2 is allowed when state s + 2 is a label different from state s
     const bool skip_fw = live && (s & 1) && s + 2 < S && labels[b * g.Lmax + (s >> 1)] != labels[b * g.Lmax + (s >> 1) + 1];

@@ -196,7 +196,9 @@ class BucketedAllReduce(object):
     post-accumulate hook on every parameter counts its bucket down; the moment a bucket is complete its
     slice of the flat buffer goes out as one asynchronous sum all-reduce (RCCL on the process group's own
     stream, overlapping the remaining backward kernels).  `finish()` waits for every bucket -- call it before
-    the optimiser step.  For the 6.7 MB TIMIT model this is 4-7 messages; for the 145 MB config-5 stack one
+    the optimiser step -- and after EVERY backward pass: the per-parameter counters assume one gradient event per parameter
+    between two finish() calls (accumulating several micro-batches before finish() is refused, not mis-counted).
+    For the 6.7 MB TIMIT model this is 3-7 messages; for the 145 MB config-5 stack one
     message per 15.7 MB layer, each hidden behind the next layer's 100+ ms of backward.
     Single-process runs (no process group) do nothing unless QK_DP_FORCE_COLLECTIVES is set."""
 
