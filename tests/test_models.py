@@ -493,3 +493,20 @@ def test_bench_prints_one_contract_line():
     r = d['roofline']
     assert r['bound'] == 'mfma' and r['peak'] == 2500.0 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9
     assert abs(r['achieved'] - r['flops_per_launch'] / (r['avg_launch_ms'] * 1e-3) / 1e12) <= 1e-6 * r['achieved']
+
+
+@pytest.mark.gpu
+def test_timit_training_example_runs_and_learns():
+    """examples/train_timit_synthetic.py: the reference's getTimitModel2D attribute bag, CTC cost, l2 in Adam, flat buffers -- the
+    cost of a memorised synthetic batch must fall."""
+    import re
+    import subprocess
+    import sys
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, 'examples', 'train_timit_synthetic.py'), '--steps', '30', '--batch', '4', '--frames', '96',
+                          '--layers', '2', '--dropout', '0.1'], capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    costs = [float(v) for v in re.findall(r'ctc cost ([0-9.]+)', out.stdout)]
+    assert len(costs) >= 3 and costs[-1] < 0.5 * costs[0], costs
