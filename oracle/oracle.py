@@ -35,7 +35,7 @@ def build(force=False):
     """Compile the C restatement with gcc (no GPU, no torch)."""
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(_SRC):
         os.makedirs(_BUILD, exist_ok=True)
-        subprocess.check_call(['gcc', '-O2', '-std=c99', '-shared', '-fPIC', _SRC, '-o', _SO])
+        subprocess.check_call(['gcc', '-O2', '-std=c99', '-fopenmp', '-shared', '-fPIC', _SRC, '-o', _SO])
     return _SO
 
 
@@ -51,6 +51,13 @@ def _load():
         lib.qko_fwd.restype = None
         lib.qko_bwd.argtypes = [ctypes.POINTER(_Desc)] + [dp] * 7
         lib.qko_bwd.restype = None
+        fp, ip = ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int64)
+        lib.qko_fwd_at.argtypes = [ctypes.POINTER(_Desc), fp, dp, dp, ip, ctypes.c_int64, dp]
+        lib.qko_dx_at.argtypes = [ctypes.POINTER(_Desc), dp, fp, fp, ip, ctypes.c_int64, dp]
+        lib.qko_dw_at.argtypes = [ctypes.POINTER(_Desc), fp, fp, fp, ip, ctypes.c_int64, dp]
+        lib.qko_dbias.argtypes = [ctypes.POINTER(_Desc), fp, fp, dp]
+        for f in (lib.qko_fwd_at, lib.qko_dx_at, lib.qko_dw_at, lib.qko_dbias):
+            f.restype = None
         _lib = lib
     return _lib
 
@@ -161,4 +168,59 @@ def backward(x, w, bias, dy, rank, y=None, **kw):
     dw = np.empty(w.shape, dtype=np.float64)
     db = np.empty((w.shape[-1],), dtype=np.float64) if bias is not None else None
     _load().qko_bwd(ctypes.byref(d), _p(x), _p(w), _p(y), _p(dy), _p(dx), _p(dw), _p(db))
+    return dx, dw, db
+
+
+# ---------------------------------------------------------------------------------------
+# sampled evaluation (qko_*_at): the oracle at BASELINE's full sizes, a few thousand
+# entries at a time.  Activations are float32 arrays (exact images of bf16 / fp16 / fp32
+# device tensors); kernel, bias and results float64.
+# ---------------------------------------------------------------------------------------
+def _f32(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _fp(a):
+    return None if a is None else a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+
+
+def _idx(idx, limit):
+    idx = np.ascontiguousarray(idx, dtype=np.int64).reshape(-1)
+    assert idx.size == 0 or (idx.min() >= 0 and idx.max() < limit), 'sample index out of range'
+    return idx
+
+
+def forward_at(x, w, bias, idx, rank, **kw):
+    """y.reshape(-1)[idx] of forward(x, w, bias, rank, **kw) -- only those outputs are computed."""
+    x, w, bias = _f32(x), _c(w), _c(bias)
+    d, y_shape = make_desc(x.shape, w.shape, rank, use_bias=bias is not None, **kw)
+    idx = _idx(idx, int(np.prod(y_shape)))
+    out = np.empty(idx.size, dtype=np.float64)
+    _load().qko_fwd_at(ctypes.byref(d), _fp(x), _p(w), _p(bias), idx.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)),
+                       idx.size, _p(out))
+    return out
+
+
+def backward_at(x, w, dy, rank, y=None, dx_idx=None, dw_idx=None, want_dbias=False, **kw):
+    """(dx.reshape(-1)[dx_idx], dw.reshape(-1)[dw_idx], dbias) of backward(...), sampled.  `y` (the forward output, for
+    the relu mask) is required when activation='relu'; x may be None when dw_idx is None.  Entries not asked for are None."""
+    w, dy, y, x = _c(w), _f32(dy), _f32(y), _f32(x)
+    x_shape = x.shape if x is not None else kw.pop('x_shape')
+    kw.pop('x_shape', None)
+    d, y_shape = make_desc(x_shape, w.shape, rank, use_bias=True, **kw)
+    assert tuple(dy.shape) == tuple(y_shape), (dy.shape, y_shape)
+    assert not d.relu or y is not None, 'the relu mask needs the forward output'
+    ip = ctypes.POINTER(ctypes.c_int64)
+    dx = dw = db = None
+    if dx_idx is not None:
+        dx_idx = _idx(dx_idx, int(np.prod(x_shape)))
+        dx = np.empty(dx_idx.size, dtype=np.float64)
+        _load().qko_dx_at(ctypes.byref(d), _p(w), _fp(y), _fp(dy), dx_idx.ctypes.data_as(ip), dx_idx.size, _p(dx))
+    if dw_idx is not None:
+        dw_idx = _idx(dw_idx, int(np.prod(w.shape)))
+        dw = np.empty(dw_idx.size, dtype=np.float64)
+        _load().qko_dw_at(ctypes.byref(d), _fp(x), _fp(y), _fp(dy), dw_idx.ctypes.data_as(ip), dw_idx.size, _p(dw))
+    if want_dbias:
+        db = np.empty(w.shape[-1], dtype=np.float64)
+        _load().qko_dbias(ctypes.byref(d), _fp(y), _fp(dy), _p(db))
     return dx, dw, db

@@ -77,3 +77,56 @@ def test_tf_same_padding_rule():
     assert oracle.tf_pads(15, 3, 1, 2, 'causal') == (4, 0)
     assert oracle.conv_output_length(17, 4, 'same', 2) == 9
     assert oracle.conv_output_length(19, 3, 'valid', 1, 2) == 15
+
+
+@pytest.mark.parametrize('path', FILES, ids=[os.path.basename(f)[:-4] for f in FILES])
+def test_sampled_oracle_entry_points_match_reference_golden(path):
+    """qko_fwd_at / qko_dx_at / qko_dw_at / qko_dbias (the oracle at sampled indices, used by the full-size GPU parity
+    tests) at EVERY index of every fixture: (1) to 1e-12 against the full oracle on the same float32-representable
+    operands (the sampled entry points take float32 activations), (2) against the values the reference's own code
+    produced, to the float32 rounding of the operands (2e-6)."""
+    rec, cfg = load_golden(path)
+    rank, kw = layer_kwargs(cfg)
+    bias = rec.get('bias')
+    x32, dy32 = rec['x'].astype(np.float32), rec['dy'].astype(np.float32)
+    w = rec['kernel']
+    y_full = oracle.forward(x32, w, bias, rank, **kw)
+    y_at = oracle.forward_at(x32, w, bias, np.arange(y_full.size), rank, **kw).reshape(y_full.shape)
+    _close(y_at, y_full)
+    _close(y_at, rec['y'], tol=2e-6)
+    y32 = y_full.astype(np.float32)               # relu mask: y > 0 survives the rounding (no float32 underflow at these magnitudes)
+    assert np.array_equal(y32 > 0, y_full > 0)
+    dx_f, dw_f, db_f = oracle.backward(x32, w, bias, dy32, rank, y=y_full, **kw)
+    dx, dw, db = oracle.backward_at(x32, w, dy32, rank, y=y32, dx_idx=np.arange(x32.size), dw_idx=np.arange(w.size),
+                                    want_dbias=True, **kw)
+    _close(dx.reshape(x32.shape), dx_f)
+    _close(dw.reshape(w.shape), dw_f)
+    _close(db, db_f if db_f is not None else oracle.backward(x32, w, np.zeros(w.shape[-1]), dy32, rank, y=y_full, **kw)[2])
+    # the reference's values: only where no output sits within rounding distance of the relu kink
+    if kw.get('activation') != 'relu' or np.abs(rec['y'][np.abs(rec['y']) > 0]).min() > 1e-5:
+        _close(dx.reshape(x32.shape), rec['dx'], tol=5e-6)
+        _close(dw.reshape(w.shape), rec['dkernel'], tol=5e-6)
+        if bias is not None:
+            _close(db, rec['dbias'], tol=5e-6)
+
+
+def test_sampled_oracle_subset_and_order():
+    """Arbitrary index subsets in arbitrary order, x omitted when only dx is wanted."""
+    rng = np.random.RandomState(5)
+    x = rng.randn(2, 6, 7, 8).astype(np.float32)
+    w = rng.randn(3, 2, 2, 12)
+    b = rng.randn(12)
+    kw = dict(strides=(1, 2), padding='same', activation='relu')
+    y = oracle.forward(x, w, b, 2, **kw)
+    dy = rng.randn(*y.shape).astype(np.float32)
+    dx_f, dw_f, db_f = oracle.backward(x, w, b, dy, 2, y=y, **kw)
+    iy = rng.permutation(y.size)[:50]
+    _close(oracle.forward_at(x, w, b, iy, 2, **kw), y.reshape(-1)[iy])
+    ix, iw = rng.permutation(x.size)[:40], rng.permutation(w.size)[:30]
+    dx, dw, db = oracle.backward_at(None, w, dy, 2, y=y, dx_idx=ix, x_shape=x.shape, **kw)
+    assert dw is None and db is None
+    _close(dx, dx_f.reshape(-1)[ix])
+    dx, dw, db = oracle.backward_at(x, w, dy, 2, y=y, dw_idx=iw, want_dbias=True, **kw)
+    assert dx is None
+    _close(dw, dw_f.reshape(-1)[iw])
+    _close(db, db_f)
