@@ -369,6 +369,9 @@ int qk_adam_step_zero_grad(float *param, float *grad, float *m, float *v, size_t
  * (batch) int32.  Keras 2.x / TensorFlow semantics: log(y_pred + 1e-7) taken as LOGITS (normalised again per frame),
  * ctc_merge_repeated = True, frames >= input_length ignored.  cost (batch) float32 = -log p(labels | y_pred);
  * dy_pred (same dtype / shape as y_pred, or NULL) = d cost[b] / d y_pred[b].  One workgroup per sample; limits:
+ * Degenerate samples: an infeasible one (more labels, counting a blank between repeats, than frames -- TensorFlow raises
+ * for it) gets cost = +inf and a ZERO gradient row; input_length == 0 gives cost 0 for an empty label sequence, +inf
+ * otherwise; labels outside [0, classes - 2] are clamped (TensorFlow raises).
  * max_label_len <= 127, classes <= 256, frames up to ~15 000 (LDS); QK_ERR_UNSUPPORTED beyond.
  * Workspace: qk_ctc_workspace_bytes (the alpha lattice, frames x (2 max_label_len + 1) floats per sample). */
 size_t qk_ctc_workspace_bytes(int32_t batch, int32_t frames, int32_t max_label_len);
@@ -380,7 +383,9 @@ int qk_ctc_batch_cost(int32_t dtype, int32_t batch, int32_t frames, int32_t clas
  * write into workspaces[i] what a call of operation ops[i] (QK_OP_FWD, or QK_OP_BWD_DATA / QK_OP_BWD) with descriptor
  * descs[i] and kernel w[i] would write at the start of its workspace -- ONE launch for up to 32 jobs.  Meant to run once
  * behind each optimiser step; the calls of the next training step then pass desc.ws_has_kernel = 1 with those workspaces
- * and launch nothing but their GEMM kernel.  16-bit channels_last descriptors with cq, fq multiples of 32 only. */
+ * and launch nothing but their GEMM kernel.  16-bit descriptors only (QK_ERR_INVALID_ARG otherwise); a job whose cq or fq
+ * is not a multiple of 32 is SKIPPED, not refused: its calls run the fp32-MFMA kernels, which read the compact kernel in
+ * place and never look at the workspace, so a model that mixes on-path and off-path layers hands over all of them. */
 int qk_conv_prep_kernels(int32_t n, const qk_conv_desc_t *const *descs, const int32_t *ops, const float *const *w,
                          void *const *workspaces, void *stream);
 

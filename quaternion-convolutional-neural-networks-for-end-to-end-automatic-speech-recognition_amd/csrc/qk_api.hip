@@ -1015,7 +1015,8 @@ int qk_conv_prep_kernels(int32_t n, const qk_conv_desc_t *const *descs, const in
                 if (!d || !w[i] || !workspaces[i]) { set_error("qk_conv_prep_kernels: job %d has a NULL member", i); return QK_ERR_INVALID_ARG; }
                 if (d->dtype != dt) continue;
                 if (ops[i] != QK_OP_FWD && ops[i] != QK_OP_BWD_DATA && ops[i] != QK_OP_BWD) { set_error("qk_conv_prep_kernels: job %d: bad op %d", i, ops[i]); return QK_ERR_INVALID_ARG; }
-                if (d->cq % 32 || d->fq % 32 || !aligned(workspaces[i], 16)) { set_error("qk_conv_prep_kernels: job %d is outside the 16-bit path", i); return QK_ERR_UNSUPPORTED; }
+                if (!aligned(workspaces[i], 16)) { set_error("qk_conv_prep_kernels: job %d: workspace not 16-byte aligned", i); return QK_ERR_INVALID_ARG; }
+                if (d->cq % 32 || d->fq % 32) continue;       // outside the matrix-core path: its calls run the fp32-MFMA kernels, which never read the workspace
                 const bool bwd = ops[i] != QK_OP_FWD;
                 PrepJob &j = jobs.j[m++];
                 j.w = w[i]; j.wq = workspaces[i]; j.taps = taps_of(d); j.cq = d->cq; j.fq = d->fq;

@@ -88,8 +88,8 @@ k_ctc(const T *__restrict__ pred, const int *__restrict__ labels, const int *__r
         if constexpr (LPS) return lpt[t * g.C + cls];
         else return __logf(to_f32(p[t * g.C + cls]) + g.eps) - lse[t];
     };
-    if (Tn == 0) {
-        if (tid == 0) cost[b] = 0.f;
+    if (Tn == 0) {             // no frames: the empty labelling has probability 1, any other is impossible
+        if (tid == 0) cost[b] = S > 1 ? INFINITY : 0.f;
         if (dpred) for (int e = tid; e < g.T * g.C; e += CTC_THREADS) dpred[(long long)b * g.T * g.C + e] = from_f32<T>(0.f);
         return;
     }
@@ -125,6 +125,13 @@ k_ctc(const T *__restrict__ pred, const int *__restrict__ labels, const int *__r
     __syncthreads();
     if (!dpred) return;
     const float nll = nll_s[0];
+    if (nll >= 1e29f) {
+        // no alignment fits (more labels, counting the blanks between repeats, than frames): the cost is +inf and has no
+        // gradient.  (TensorFlow's ctc_loss raises "Not enough time for target transition sequence" here; a finite
+        // softmax / (p + eps) "gradient" with all occupancies zero would push the optimiser somewhere meaningless.)
+        for (int e = tid; e < g.T * g.C; e += CTC_THREADS) dpred[(long long)b * g.T * g.C + e] = from_f32<T>(0.f);
+        return;
+    }
 
     // ---- phase 2: beta, posterior occupancies, gradient ------------------------------------------------------------------
     T *dp = dpred + (long long)b * g.T * g.C;

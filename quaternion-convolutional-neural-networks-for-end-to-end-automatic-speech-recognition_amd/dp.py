@@ -97,7 +97,16 @@ def init_from_env(backend=None):
         os.environ.setdefault('MASTER_PORT', '29500')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         if backend is None:
-            backend = os.environ.get('QK_DP_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+            override = os.environ.get('QK_DP_BACKEND')
+            if override and override != backend:
+                # the override exists for ONE purpose: several ranks on one device (RCCL refuses that).  A production
+                # run -- one rank per GPU -- must not be able to end up on gloo because a variable leaked into its
+                # environment: host-staged collectives would be silently ~100x slower.
+                if not os.environ.get('QK_DP_SHARE_DEVICE'):
+                    raise RuntimeError('QK_DP_BACKEND=%s is a diagnostic for ranks sharing one GPU and is honoured only together '
+                                       'with QK_DP_SHARE_DEVICE=1; unset it (one rank per GPU always uses RCCL: backend "nccl")' % override)
+                backend = override
         if backend == 'nccl':
             torch.cuda.set_device(local)
             dist.init_process_group(backend, rank=rank, world_size=world,
@@ -178,6 +187,11 @@ def broadcast_params(flat, src=0, group=None):
     so ranks usually agree already; this makes it unconditional)."""
     if dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.broadcast(flat.param, src=src, group=group)
+        # c10d collectives write the buffer WITHOUT moving its version counter; the cached 16-bit kernel re-layouts
+        # (functional._Call._ws) compare versions -- without this a non-src rank that had already run a forward would keep
+        # multiplying by its pre-broadcast kernels until the next optimiser step.  Any other raw write into flat.param
+        # (parameter averaging, a checkpoint load through a collective) must do the same.
+        torch.autograd.graph.increment_version(flat.param)
 
 
 def allreduce_sum_(tensor, group=None, async_op=False):

@@ -23,12 +23,13 @@ _PREP_PARAMS = __import__('weakref').WeakValueDictionary()   # id -> parameter t
 
 
 def refresh_prepped_kernels(base=None):
-    """Bring every cached 16-bit kernel re-layout up to date in ONE launch (qk_conv_prep_kernels): called by adam_step
-    behind the update, so that the next training step's forward / backward calls find their workspace ready
+    """Bring every cached 16-bit kernel re-layout up to date in ONE launch per device (qk_conv_prep_kernels): called by
+    adam_step behind the update, so that the next training step's forward / backward calls find their workspace ready
     (desc.ws_has_kernel = 1) and launch nothing but the GEMM kernel -- 26 small launches per TIMIT step become one.
-    base: restrict to the parameters that live in this flat buffer (or are this tensor).  Returns the number of jobs."""
-    descs, ops, ws_ptrs, w_ptrs, entries = [], [], [], [], []
-    dev = None
+    base: restrict to the parameters that live in this flat buffer (or are this tensor).  Returns the number of jobs.
+    A refresh that fails is not fatal (the optimiser step that called it has already happened): the device's entries
+    are dropped from the cache and the next call of each layer re-lays its kernel out itself (ws_has_kernel = 0)."""
+    per_dev = {}
     for p in list(_PREP_PARAMS.values()):
         cache = p.__dict__.get('_qk_prep')
         if not cache or not p.is_cuda:
@@ -40,27 +41,25 @@ def refresh_prepped_kernels(base=None):
         for key, ent in cache.items():
             if ent[0] == ver or ent[1] != p.data_ptr():
                 continue
-            if dev is None:
-                dev = p.device
-            if p.device != dev:
-                continue
-            job = ent[3]
-            descs.append(job[0]); ops.append(job[1]); ws_ptrs.append(ent[2].data_ptr()); w_ptrs.append(p.data_ptr())
-            entries.append((ent, ver))
-    n = len(descs)
-    if n == 0:
-        return 0
-    dp = (ctypes.POINTER(L.ConvDesc) * n)(*[ctypes.pointer(d) for d in descs])
-    op_arr = (ctypes.c_int32 * n)(*ops)
-    w_arr = (ctypes.c_void_p * n)(*w_ptrs)
-    ws_arr = (ctypes.c_void_p * n)(*ws_ptrs)
-    with torch.cuda.device(dev):
-        rc = L.lib().qk_conv_prep_kernels(n, dp, op_arr, w_arr, ws_arr, _raw_stream(dev.index) if _raw_stream is not None
-                                          else torch.cuda.current_stream(dev).cuda_stream)
-    L.check(rc, 'qk_conv_prep_kernels')
-    for ent, ver in entries:
-        ent[0] = ver
-    return n
+            per_dev.setdefault(p.device, []).append((p, key, ent, ver))
+    total = 0
+    for dev, jobs in per_dev.items():
+        n = len(jobs)
+        dp = (ctypes.POINTER(L.ConvDesc) * n)(*[ctypes.pointer(j[2][3][0]) for j in jobs])
+        op_arr = (ctypes.c_int32 * n)(*[j[2][3][1] for j in jobs])
+        w_arr = (ctypes.c_void_p * n)(*[j[0].data_ptr() for j in jobs])
+        ws_arr = (ctypes.c_void_p * n)(*[j[2][2].data_ptr() for j in jobs])
+        with torch.cuda.device(dev):
+            rc = L.lib().qk_conv_prep_kernels(n, dp, op_arr, w_arr, ws_arr, _raw_stream(dev.index) if _raw_stream is not None
+                                              else torch.cuda.current_stream(dev).cuda_stream)
+        if rc != 0:
+            for p, key, ent, ver in jobs:
+                p.__dict__.get('_qk_prep', {}).pop(key, None)
+            continue
+        for p, key, ent, ver in jobs:
+            ent[0] = ver
+        total += n
+    return total
 
 
 def _require_device(t, what):
@@ -131,6 +130,9 @@ class _Call(object):
         d = self.desc
         if d.dtype == L.QK_F32 or getattr(d, 'layout', L.QK_CH_LAST) != L.QK_CH_LAST:
             return 0
+        cq, fq = (d.in_q, d.q_units) if isinstance(d, L.DenseDesc) else (d.cq, d.fq)
+        if cq % 32 or fq % 32:
+            return 0            # off the matrix-core path: the fp32-MFMA kernels never read the workspace -- nothing to cache or refresh
         return int(math.prod(self.w_shape)) * 2 + 256
 
     def _ws(self, op, like, wparam=None):

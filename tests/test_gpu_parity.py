@@ -1408,6 +1408,50 @@ def test_cached_kernel_relayout_follows_every_kind_of_weight_update():
     assert not torch.equal(y4[0], y3[0])
 
 
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16], ids=['bf16', 'fp16'])
+def test_adam_step_with_16bit_layers_off_the_matrix_core_path(dtype):
+    """Round-3 advisor (medium): the cached 16-bit kernel re-layouts were registered for EVERY trainable 16-bit layer, also
+    those whose channel counts keep them off the matrix-core path (cq or fq not a multiple of 32); the batched refresh behind
+    adam_step then failed with QK_ERR_UNSUPPORTED on the first optimiser step.  A model that mixes on-path and off-path
+    layers must train: three steps, the loss goes down, the on-path layer's cache is refreshed, the off-path layers carry none."""
+    import qcnn_amd
+    from qcnn_amd import dp
+    F = qcnn_amd.functional
+    dev = _dev()
+    g = torch.Generator(device=dev).manual_seed(2)
+    mk = lambda *s: torch.nn.Parameter(torch.randn(*s, device=dev, generator=g) / (4.0 * np.prod(s[:-1])) ** 0.5)
+    w_small, w_path, w_dense = mk(3, 2, 4 * 16), mk(3, 16, 4 * 8), mk(8, 4 * 3)          # cq 2 -> fq 16, cq 16 -> fq 8, dense 8 -> 3
+    w_on = mk(3, 32, 4 * 32)
+    x = torch.randn(4, 30, 8, device=dev, generator=g).to(dtype)
+    x_on = torch.randn(4, 30, 128, device=dev, generator=g).to(dtype)
+    params = [w_small, w_path, w_dense, w_on]
+    flat = dp.FlatParams(params, direct=True)
+    m, v = torch.zeros_like(flat.param), torch.zeros_like(flat.param)
+    losses = []
+    for step in (1, 2, 3):
+        h = F.quaternion_conv(x, w_small, None, padding='same', activation='relu', fold_small_cq=False)
+        h = F.quaternion_conv(h, w_path, None, padding='same', activation='relu')
+        y = F.quaternion_dense(h.reshape(-1, h.shape[-1]), w_dense, None)
+        y_on = F.quaternion_conv(x_on, w_on, None, padding='same')
+        loss = (y.float() ** 2).sum() + (y_on.float() ** 2).sum()
+        loss.backward()
+        losses.append(float(loss))
+        F.adam_step(flat.param, flat.grad, m, v, step, lr=1e-2, zero_grad=True)          # raised here before the fix
+    torch.cuda.synchronize()
+    assert losses[2] < losses[0]
+    assert not w_small.__dict__.get('_qk_prep') and not w_path.__dict__.get('_qk_prep') and not w_dense.__dict__.get('_qk_prep')
+    cache = w_on.__dict__.get('_qk_prep')
+    assert cache and all(ent[0] == (w_on._version, flat.param._version) for ent in cache.values())     # refreshed behind Adam
+    # and the C entry point itself skips off-path jobs instead of refusing the whole batch
+    call = F.conv_call((4, 30, 8), (3, 2, 64), dtype, 1, 1, 'same', 'channels_last', 1, None, False)
+    job, op = call._prep_job(qcnn_amd._lib.QK_OP_FWD)
+    ws = torch.empty(3 * 2 * 64 * 2 + 256, dtype=torch.uint8, device=dev)
+    rc = qcnn_amd._lib.lib().qk_conv_prep_kernels(1, (ctypes.POINTER(qcnn_amd._lib.ConvDesc) * 1)(ctypes.pointer(job)), (ctypes.c_int32 * 1)(op),
+                                                  (ctypes.c_void_p * 1)(w_small.data_ptr()), (ctypes.c_void_p * 1)(ws.data_ptr()),
+                                                  torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+
+
 def _random_layer_configs(n, seed):
     """Seeded random layer configurations over everything the layer API accepts: rank 1-3 (+ dense), kernel extents 1-5,
     strides / dilations 1-2 (never both > 1, as in Keras), valid / same / causal, both data formats, with and without bias,

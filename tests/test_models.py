@@ -413,6 +413,39 @@ def test_fused_ctc_batch_cost_matches_the_keras_restatement(shape, dtype):
 
 
 @pytest.mark.gpu
+def test_fused_ctc_degenerate_samples():
+    """Samples TensorFlow's ctc_loss raises for (round-3 advisor): a label sequence that does not fit its frames (with the
+    blank a repeated label needs) gets cost +inf and NO gradient -- not a finite softmax / (p + eps) row that would steer
+    the optimiser; zero frames with labels likewise; zero frames and zero labels cost 0.  The feasible samples of the same
+    batch are unaffected."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(3)
+    b, t, c = 5, 12, 9
+    pred = torch.softmax(torch.randn(b, t, c, generator=g), -1).to(dev)
+    labels = torch.tensor([[1, 2, 3, 4], [2, 2, 2, 0], [1, 2, 3, 4], [5, 6, 0, 0], [1, 1, 0, 0]])
+    ll = torch.tensor([[4], [3], [4], [2], [0]])
+    il = torch.tensor([[12], [4], [3], [0], [0]])       # 0: fits; 1: 3 repeats need 5 frames, has 4; 2: 4 labels in 3 frames; 3: no frames; 4: empty / empty
+    p = pred.clone().requires_grad_(True)
+    cost = ctc_batch_cost(p, labels.to(dev), il, ll)
+    cost[0].sum().backward()
+    cst = cost.detach().cpu().reshape(-1)
+    assert torch.isfinite(cst[0]) and cst[0] > 0 and float(cst[4]) == 0.0
+    assert torch.isinf(cst[1]) and torch.isinf(cst[2]) and torch.isinf(cst[3]) and (cst[1:4] > 0).all()
+    p2 = pred.clone().requires_grad_(True)
+    c2 = ctc_batch_cost(p2, labels.to(dev), il, ll)
+    torch.where(torch.isfinite(c2), c2, torch.zeros_like(c2)).sum().backward(retain_graph=True)
+    assert float(p2.grad[0].abs().sum()) > 0 and float(p2.grad[1:].abs().sum()) == 0.0
+    # the stored gradient rows of the infeasible samples are zero themselves (not merely masked by the caller)
+    from qcnn_amd import functional as Fq
+    p3 = pred.clone().requires_grad_(True)
+    c3 = Fq.ctc_batch_cost(p3, labels, il, ll)
+    gr, = torch.autograd.grad(c3, p3, torch.ones_like(c3))
+    assert torch.isfinite(gr).all() and float(gr[1:].abs().sum()) == 0.0 and float(gr[0].abs().sum()) > 0
+
+
+@pytest.mark.gpu
 def test_deterministic_mode_makes_the_training_step_bit_repeatable():
     """QK_DBG_DETERMINISTIC (include/qk.h): every backward-weight kernel runs one split of its reduction per gradient
     tile and one owner per bias column, so no float sum depends on the order in which atomics land (TF's CPU
