@@ -129,47 +129,81 @@ k_wgrad16_band(const T *__restrict__ x, const T *__restrict__ dy, const T *__res
     const unsigned d_thr = (unsigned)((s_sub / UF) * g.F + f0 + (s_sub % UF) * 8) * 2u;
     const unsigned x_ustep = (unsigned)((8 / UC) * g.Cq) * 2u, d_ustep = (unsigned)((8 / UF) * g.F) * 2u;
     uint4 xr[UX], xh[UX], dr[UD], mr[MASK ? UD : 1];
-    // position of this thread's row: (line, u) with line = (n * osp0 + o0) * osp1 + o1; advanced by KM per decode
-    int r_line, r_u, r_n, r_o0, r_o1;
+    // position of this thread's row: (line, u) with line = (n * osp0 + o0) * osp1 + o1; advanced by KM per decode.
+    // Round 4: the offsets themselves are carried along (xo2 / dyo2: byte offsets of the row's x / dY units, exact modulo 2^32
+    // whenever the row is inside the tensor) -- an advance is additions of wave-uniform constants selected by the carries, no
+    // multiplications and no branches, so its pieces can sit between the MFMAs of the K step instead of in front of them
+    // (the decode was 11 % of the kernel by ablation: ~60 VALU with six v_mul_lo / v_mad_u64 and nested exec-mask branches
+    // that every wave of the CU ran right behind the barrier, with the matrix pipe idle).
+    int r_line, r_u, r_o0, r_o1, r_i0, r_i1;
+    unsigned xo2, dyo2;
+    const int W_ = g.osp[2];
     {
         const int P = p_begin + s_row;
         r_line = P / WP; r_u = P - r_line * WP;
         int l = r_line;
         r_o1 = l % g.osp[1]; l /= g.osp[1];
         r_o0 = l % g.osp[0];
-        r_n = l / g.osp[0];
+        const int r_n = l / g.osp[0];
+        r_i0 = r_o0 * g.pa[0] + t0 * g.pb[0] + g.pc[0];
+        r_i1 = r_o1 * g.pa[1] + t1 * g.pb[1] + g.pc[1];
+        xo2 = (unsigned)(r_n * (int)g.x_sn + r_i0 * (int)g.x_ss[0] + r_i1 * (int)g.x_ss[1] + (r_u + g.b_cshift) * (int)g.x_ss[2]) * 2u + x_thr;
+        dyo2 = (unsigned)((r_line * W_ + r_u) * (int)g.dy_ss) * 2u + d_thr;
     }
+    // wave-uniform steps: KM positions along a line; line -> next line; last line of axis 1 -> next row of axis 0; -> next sample
+    const unsigned cXA = (unsigned)(KM * (int)g.x_ss[2]) * 2u, cDA = (unsigned)(KM * (int)g.dy_ss) * 2u;
+    const unsigned cXL = (unsigned)((int)g.x_ss[1] * g.pa[1] - WP * (int)g.x_ss[2]) * 2u, cDL = (unsigned)((W_ - WP) * (int)g.dy_ss) * 2u;
+    const unsigned cX1 = (unsigned)((int)g.x_ss[0] * g.pa[0] - g.osp[1] * g.pa[1] * (int)g.x_ss[1]) * 2u;
+    const unsigned cX0 = (unsigned)((int)g.x_sn - g.osp[0] * g.pa[0] * (int)g.x_ss[0]) * 2u;
+    const int cI1 = g.osp[1] * g.pa[1], cI0 = g.osp[0] * g.pa[0];
+    constexpr bool INTERLEAVE = !(MASK && KIN == 5);   // (the masked 5-tap forms have no register to spare for the longer live ranges)
+    const bool fast_lines = WP >= KM;                // at most one line end per advance (every image wider than 60 positions)
     // offsets of the row this thread loads next (vx: band row of the tile, vd: its dY row) and of the one after
     // (vx_n: also the HALO row of the tile, band row KM + s_row, for the threads with s_row < KIN - 1)
     unsigned vx = kOOR, vd = kOOR, vx_n = kOOR, vd_n = kOOR, vd_cur = kOOR;
     int p_next = p_begin;                            // position base of the next decode
-    auto decode = [&]() {
-        const bool in_img = r_line < g.b_nlines;
-        const int col = r_u + g.b_cshift;
-        const int i0 = r_o0 * g.pa[0] + t0 * g.pb[0] + g.pc[0], i1 = r_o1 * g.pa[1] + t1 * g.pb[1] + g.pc[1];
-        const bool x_in = in_img && col >= 0 && col < g.isp[2] && i0 >= 0 && i0 < g.isp[0] && i1 >= 0 && i1 < g.isp[1];
-        const int xo = r_n * (int)g.x_sn + i0 * (int)g.x_ss[0] + i1 * (int)g.x_ss[1] + col * (int)g.x_ss[2];
-        vx_n = x_in ? (unsigned)xo * 2u + x_thr : kOOR;
-        const bool d_in = in_img && r_u < W && p_next + s_row < p_end;
-        vd_n = d_in ? (unsigned)((r_line * W + r_u) * (int)g.dy_ss) * 2u + d_thr : kOOR;
-        p_next += KM;
-        if (WP >= KM) {                                 // carry-propagate (no divisions in the loop)
-            r_u += KM;
-            const bool c = r_u >= WP;
-            r_u -= c ? WP : 0; r_line += c ? 1 : 0;
-            r_o1 += c ? 1 : 0;
-            const bool c1 = r_o1 == g.osp[1];
-            r_o1 = c1 ? 0 : r_o1; r_o0 += c1 ? 1 : 0;
-            const bool c0_ = r_o0 == g.osp[0];
-            r_o0 = c0_ ? 0 : r_o0; r_n += c0_ ? 1 : 0;
-        } else {                                        // short lines: decode again
-            const int P = p_next + s_row;
-            r_line = P / WP; r_u = P - r_line * WP;
-            int l = r_line;
-            r_o1 = l % g.osp[1]; l /= g.osp[1];
-            r_o0 = l % g.osp[0];
-            r_n = l / g.osp[0];
+    bool carry = false, carry1 = false;
+    // decode = piece 0 (offsets of the current row) + pieces 1 .. 3 (advance by KM positions)
+    auto decode_piece = [&](int k) {
+        if (k == 0) {
+            const bool in_img = r_line < g.b_nlines;
+            const bool x_in = in_img && (unsigned)(r_u + g.b_cshift) < (unsigned)g.isp[2] && (unsigned)r_i0 < (unsigned)g.isp[0]
+                              && (unsigned)r_i1 < (unsigned)g.isp[1];
+            vx_n = x_in ? xo2 : kOOR;
+            const bool d_in = in_img && r_u < W_ && p_next + s_row < p_end;
+            vd_n = d_in ? dyo2 : kOOR;
+            p_next += KM;
+        } else if (k == 1) {
+            r_u += KM; xo2 += cXA; dyo2 += cDA;
+            carry = r_u >= WP;
+            r_u -= carry ? WP : 0; r_line += carry ? 1 : 0; r_o1 += carry ? 1 : 0; r_i1 += carry ? g.pa[1] : 0;
+            xo2 += carry ? cXL : 0u; dyo2 += carry ? cDL : 0u;
+        } else if (k == 2) {
+            carry1 = carry && r_o1 == g.osp[1];
+            r_o1 = carry1 ? 0 : r_o1; r_i1 -= carry1 ? cI1 : 0; r_o0 += carry1 ? 1 : 0; r_i0 += carry1 ? g.pa[0] : 0;
+            xo2 += carry1 ? cX1 : 0u;
+        } else {
+            const bool carry0 = carry1 && r_o0 == g.osp[0];
+            r_o0 = carry0 ? 0 : r_o0; r_i0 -= carry0 ? cI0 : 0;
+            xo2 += carry0 ? cX0 : 0u;
         }
+    };
+    auto decode_short_lines = [&]() {                // lines shorter than a K step: several line ends per advance -- decode afresh
+        decode_piece(0);
+        const int P = p_next + s_row;
+        r_line = P / WP; r_u = P - r_line * WP;
+        int l = r_line;
+        r_o1 = l % g.osp[1]; l /= g.osp[1];
+        r_o0 = l % g.osp[0];
+        const int r_n = l / g.osp[0];
+        r_i0 = r_o0 * g.pa[0] + t0 * g.pb[0] + g.pc[0];
+        r_i1 = r_o1 * g.pa[1] + t1 * g.pb[1] + g.pc[1];
+        xo2 = (unsigned)(r_n * (int)g.x_sn + r_i0 * (int)g.x_ss[0] + r_i1 * (int)g.x_ss[1] + (r_u + g.b_cshift) * (int)g.x_ss[2]) * 2u + x_thr;
+        dyo2 = (unsigned)((r_line * W_ + r_u) * (int)g.dy_ss) * 2u + d_thr;
+    };
+    auto decode = [&]() {
+        if (fast_lines) { decode_piece(0); decode_piece(1); decode_piece(2); decode_piece(3); }
+        else decode_short_lines();
     };
     auto shift = [&]() { vx = vx_n; vd = vd_n; };
     const bool halo_thr = s_row < KIN - 1;
@@ -246,7 +280,8 @@ k_wgrad16_band(const T *__restrict__ x, const T *__restrict__ dy, const T *__res
 #pragma unroll 8
                 for (int mm = 0; mm < KM; ++mm) dbacc += to_f32(col[mm * (DROW / 2)]);
             }
-            shift(); decode();
+            shift();
+            if (!INTERLEAVE || !fast_lines) decode();        // (else: the four pieces ride between the MFMAs of ks = 0)
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 v8s A[KIN], B[CTW];
@@ -283,6 +318,7 @@ k_wgrad16_band(const T *__restrict__ x, const T *__restrict__ dy, const T *__res
                 for (int j = 0; j < NMF; ++j) {
                     const int t = j / CTW, ct = j % CTW;
                     acc[t][ct] = mfma16b(T(), A[t], B[ct], acc[t][ct]);
+                    if (INTERLEAVE && ks == 0 && j >= 1 && j <= 4 && fast_lines) decode_piece(j - 1);      // vx_n / vd_n: first used in ks = 1
                     const int u = u_lo + j / 2;
                     if (u < u_hi) {
                         if (j % 2 == 0) store_unit(u, nb, dym_blk && mine_next);

@@ -2,7 +2,7 @@
 """Where the time of the 16-bit kernels goes: fwd / bwd-data / bwd-weight of the TIMIT layer shapes with parts of
 the kernel switched off (qk_set_debug_flags ablation bits -- results are WRONG, timing only):
   hgemm: 0 full | 4 no K loop (prologue + epilogue) | 8 no epilogue | 12 prologue only
-  wgrad: 0 full | 1 no fold/atomics | 2 no HBM atomics"""
+  wgrad: 0 full | 1 no fold/atomics | 2 no HBM atomics | 4 no per-step row decode | 8 no per-step barrier | 12 both"""
 import os, sys, statistics
 ROOT = os.path.dirname(os.path.dirname(os.path.realpath(__file__)))
 sys.path.insert(0, ROOT)
@@ -26,7 +26,7 @@ for n in (sys.argv[1:] or ['c64', 'c32', 'head']):
     dx = torch.empty_like(x); dw = torch.empty_like(w); db = torch.empty_like(b)
     fns = {'fwd': (lambda: call.fwd(x, w, b, out=y), (0, 4, 8, 12)),
            'bwd_data': (lambda: call.bwd_data(dy, y, w, out=dx), (0, 4, 8, 12)),
-           'bwd_weight': (lambda: call.bwd_weight(x, dy, y, True, out=(dw, db)), (0, 1, 2))}
+           'bwd_weight': (lambda: call.bwd_weight(x, dy, y, True, out=(dw, db)), (0, 1, 2, 4, 8, 12))}
     for k, (fn, abl) in fns.items():
         for a in abl:
             with _lib.debug_flags(0, ablate=a):

@@ -1,0 +1,128 @@
+// Energy-apportioning probe (diagnostic, not product code): where do the watts of the band kernels go?
+//
+// The body kernels sit at the 1.4 kW socket cap and run at whatever clock that allows, so what bounds
+// them is ENERGY PER FLOP.  This probe runs the inner loop of k_hgemm16_band (qk_hgemm_bf16mfma.hip) in isolation, in
+// variants that add one energy consumer at a time, on zero and on random operands:
+//   kind 0  MFMA only: 7 accumulator tiles per 32-row block, operands fixed in registers          (the power-limited MFMA roof)
+//   kind 1  + fragments re-read from LDS every 16-deep step, 8 ds_read_b128 per 16 MFMAs        (today's wave tile: 32 rows x 128 columns)
+//   kind 2  + staging: global loads (L2-resident, 4/5 from a shared 512 KB image) and ds_write_b128 at the band kernel's rate
+//           (5 + 5 per 32 MFMAs with 64-row workgroup tiles; 6 + 6 per 64 MFMAs with 128-row tiles)
+//   RB = 2  64-row wave tiles (one wave per SIMD, 14 accumulator tiles, 12 reads per 32 MFMAs): the "512-register" form
+// Geometry: WPS waves per SIMD (2: two 4-wave workgroups per CU as today, or 1: one 4-wave workgroup per CU).
+// tools/probe/energy_probe.py launches each variant back to back for a few seconds and samples socket power and shader clock.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ floatx16 mfma(const uint4 &a, const uint4 &b, floatx16 c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+constexpr unsigned kSignConj = 0x284E;       // qk_common.h: entries that subtract (conjugate table, as every 16-bit kernel uses)
+
+template <int RB, int KIND>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB == 2 ? 1 : 2, RB == 2 ? 1 : 2)))
+k_probe(const uint4 *__restrict__ src, float *__restrict__ out, int iters, unsigned src_units)
+{
+    constexpr int A_U = 4096, B_U = 2048;                  // 64 KB + 32 KB of 16-byte units (an A band pair + B tiles)
+    __shared__ __attribute__((aligned(16))) uint4 lds[RB == 2 ? A_U + B_U + 512 : (A_U + B_U) / 2 + 768];
+    constexpr int LU = sizeof(lds) / 16;
+    constexpr unsigned MK = RB == 2 ? 1023u : 511u;        // the read base cycles through a power-of-two window; fragments sit at immediate offsets
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int i = tid; i < LU; i += 256) lds[i] = src[(blockIdx.x * 977u + i) % src_units];
+    __syncthreads();
+    floatx16 acc[RB][4], accn[RB][4];
+#pragma unroll
+    for (int r = 0; r < RB; ++r)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { acc[r][b][e] = 0.f; accn[r][b][e] = 0.f; }
+    uint4 A[RB][4], B[4];
+    unsigned rd = (unsigned)tid & MK;                         // 16-byte unit this lane reads next (contiguous per wave: conflict-free)
+#pragma unroll
+    for (int r = 0; r < RB; ++r)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) A[r][a] = lds[rd + (r * 4 + a) * 256];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) B[p] = lds[rd + (RB * 4 + p) * 256];
+    uint4 st[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) st[q] = make_uint4(0u, 0u, 0u, 0u);
+    const unsigned own0 = (32768u + blockIdx.x * 8192u) & (src_units - 1u);          // src_units: a power of two >= 2^22
+    unsigned gsh = (unsigned)tid, gown = own0 + tid;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            if (KIND >= 1) {
+#pragma unroll
+                for (int r = 0; r < RB; ++r)
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) A[r][a] = lds[rd + (r * 4 + a) * 256];
+#pragma unroll
+                for (int p = 0; p < 4; ++p) B[p] = lds[rd + (RB * 4 + p) * 256];
+                rd = (rd + 3 * 64) & MK;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < RB; ++r)
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        if ((kSignConj >> (a * 4 + b)) & 1u) accn[r][b] = mfma(B[a ^ b], A[r][a], accn[r][b]);
+                        else acc[r][b] = mfma(B[a ^ b], A[r][a], acc[r][b]);
+                        if (KIND >= 2) {
+                            // staging at the band kernel's rate, L2-resident like the real thing: per thread and 32 RB MFMAs
+                            // NLD 16-byte units, 4 of 5 from the kernel image every workgroup shares (the B tiles: 480 KB
+                            // per row tile), the rest from this workgroup's own band rows
+                            constexpr int NLD = RB == 2 ? 6 : 5;
+                            const int f = (ks * RB + r) * 16 + a * 4 + b;          // 0 .. 32 RB - 1
+                            constexpr int GAP = (32 * RB) / (2 * NLD);
+                            if (f % GAP == GAP - 1 && f / GAP < 2 * NLD) {
+                                const int slot = f / GAP, q = slot >> 1;
+                                if (slot & 1) {             // (a unit is stored one iteration after its load was issued, as in the kernel)
+                                    if (q == NLD - 1) { st[q] = src[gown]; gown = own0 + ((gown + 256u) & 8191u); }
+                                    else { st[q] = src[gsh]; gsh = (gsh + 256u) & 32767u; }
+                                } else lds[rd + (RB * 4 + 4 + q) * 256] = st[q];
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+        }
+        if (KIND >= 1) __syncthreads();
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < RB; ++r)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s += acc[r][b][e] - accn[r][b][e];
+    if (s == 123.456f) out[blockIdx.x * 256 + tid] = s;
+}
+
+// resident waves that only sleep: what the clocked-but-idle chip draws
+__global__ void __launch_bounds__(256) k_idle(float *out, int iters)
+{
+    for (int it = 0; it < iters; ++it) __builtin_amdgcn_s_sleep(64);
+    if (iters < 0) out[threadIdx.x] = 1.f;
+}
+
+extern "C" {
+// rb: 1 | 2, kind: 0..2 (kind 3 = idle), wgs_per_cu: workgroups of 4 waves per CU.  Returns the MFMA count of the launch (0 for idle).
+double probe_launch(int rb, int kind, int wgs_per_cu, int iters, const void *src, unsigned src_units, float *out, void *stream)
+{
+    const int grid = 256 * wgs_per_cu;
+    hipStream_t s = (hipStream_t)stream;
+    if (kind == 3) { hipLaunchKernelGGL(k_idle, dim3(grid), dim3(256), 0, s, out, iters); return 0.0; }
+#define GO(R, K) hipLaunchKernelGGL((k_probe<R, K>), dim3(grid), dim3(256), 0, s, (const uint4 *)src, out, iters, src_units)
+    if (rb == 1) { if (kind == 0) GO(1, 0); else if (kind == 1) GO(1, 1); else GO(1, 2); }
+    else { if (kind == 0) GO(2, 0); else if (kind == 1) GO(2, 1); else GO(2, 2); }
+#undef GO
+    return (double)grid * 4.0 * iters * 32.0 * rb;
+}
+}
