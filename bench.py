@@ -152,7 +152,7 @@ class ModelTrainStep(object):
             loss = self.model.ctc_loss(self.x, self.labels, self.input_length, self.label_length).mean()
         else:
             pred = self.model(self.x)
-            loss = (pred.float() * self.target).sum()
+            loss = self.F.weighted_sum(pred, self.target)            # sum(pred * target): one launch each way
         loss.backward()                                 # gradients accumulate into the zeroed flat buffer; the
         self.reducer.finish()                           # buckets go out while the backward is still running
         self.F.adam_step(self.flat.param, self.flat.grad, self.m, self.v, self.t, lr=5e-4,

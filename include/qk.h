@@ -379,6 +379,18 @@ int qk_ctc_batch_cost(int32_t dtype, int32_t batch, int32_t frames, int32_t clas
                       int32_t max_label_len, const int32_t *input_length, const int32_t *label_length, float *cost, void *dy_pred,
                       void *workspace, size_t workspace_bytes, void *stream);
 
+/* Softmax over the last axis of a (rows, cols <= 64) matrix, one wave per row -- the activation of the model's
+ * TimeDistributed(Dense(62, activation='softmax')) output layer (models/interspeech_model.py:171-175) and its autodiff:
+ *   fwd   y = softmax(logits + bias)          logits: fp32 (the GEMM's fp32 output), bias: fp32 or NULL, y: `dtype`
+ *   bwd   dlogits = y * (dy - sum_j dy_j y_j)   (dtype; the operand of the layer's two gradient GEMMs)
+ *         dbias[j] += sum over rows of dlogits  (fp32, ACCUMULATED: the caller zeroes it or hands in a gradient buffer; NULL = skip)
+ * The Dense(62) GEMMs themselves are plain library GEMMs; these two launches replace the ~25 elementwise / reduction
+ * launches a framework spends around them. */
+int qk_softmax_rows_fwd(int32_t dtype, int64_t rows, int32_t cols, const float *logits, const float *bias, void *y, void *stream);
+int qk_softmax_rows_bwd(int32_t dtype, int64_t rows, int32_t cols, const void *y, const void *dy, void *dlogits, float *dbias, void *stream);
+/* *out += sum_i a[i] * w[i]  (a: `dtype`, w / out: fp32): a linear functional of the model output as one launch. */
+int qk_weighted_sum(int32_t dtype, int64_t n, const void *a, const float *w, float *out, void *stream);
+
 /* Batched form of the 16-bit kernel re-layout every forward / backward-data call otherwise does for itself: for job i,
  * write into workspaces[i] what a call of operation ops[i] (QK_OP_FWD, or QK_OP_BWD_DATA / QK_OP_BWD) with descriptor
  * descs[i] and kernel w[i] would write at the start of its workspace -- ONE launch for up to 32 jobs.  Meant to run once

@@ -104,6 +104,9 @@ SYMBOLS = {
                                             ctypes.POINTER(ctypes.c_void_p), _VP]),
     'qk_adam_step_l2': (ctypes.c_int, [_FP, _FP, _FP, _FP, _FP, _SZ, ctypes.c_float, ctypes.c_float,
                                        ctypes.c_float, ctypes.c_float, I32, ctypes.c_float, I32, _VP]),
+    'qk_softmax_rows_fwd': (ctypes.c_int, [I32, ctypes.c_int64, I32, _VP, _VP, _VP, _VP]),
+    'qk_softmax_rows_bwd': (ctypes.c_int, [I32, ctypes.c_int64, I32, _VP, _VP, _VP, _VP, _VP]),
+    'qk_weighted_sum': (ctypes.c_int, [I32, ctypes.c_int64, _VP, _VP, _VP, _VP]),
     'qk_maxpool2d_fwd': (ctypes.c_int, [_PD, _VP, _VP, _VP]),
     'qk_maxpool2d_bwd': (ctypes.c_int, [_PD, _VP, _VP, _VP, _VP]),
     'qk_adam_step': (ctypes.c_int, [_FP, _FP, _FP, _FP, _SZ, ctypes.c_float, ctypes.c_float,

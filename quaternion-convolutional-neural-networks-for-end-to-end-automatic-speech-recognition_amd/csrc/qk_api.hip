@@ -1002,6 +1002,27 @@ int qk_ctc_batch_cost(int32_t dtype, int32_t batch, int32_t frames, int32_t clas
     return check_launch(rc, "qk_ctc_batch_cost");
 }
 
+int qk_softmax_rows_fwd(int32_t dtype, int64_t rows, int32_t cols, const float *logits, const float *bias, void *y, void *stream)
+{
+    if (!logits || !y || rows < 0 || cols < 1 || cols > 64 || dtype < QK_F32 || dtype > QK_F16) { set_error("qk_softmax_rows_fwd: bad argument (1 <= cols <= 64)"); return QK_ERR_INVALID_ARG; }
+    if (rows == 0) return QK_OK;
+    return check_launch(launch_softmax_rows(dtype, false, logits, bias, y, nullptr, rows, cols, (hipStream_t)stream), "qk_softmax_rows_fwd");
+}
+
+int qk_softmax_rows_bwd(int32_t dtype, int64_t rows, int32_t cols, const void *y, const void *dy, void *dlogits, float *dbias, void *stream)
+{
+    if (!y || !dy || !dlogits || rows < 0 || cols < 1 || cols > 64 || dtype < QK_F32 || dtype > QK_F16) { set_error("qk_softmax_rows_bwd: bad argument (1 <= cols <= 64)"); return QK_ERR_INVALID_ARG; }
+    if (rows == 0) return QK_OK;
+    return check_launch(launch_softmax_rows(dtype, true, y, dy, dlogits, dbias, rows, cols, (hipStream_t)stream), "qk_softmax_rows_bwd");
+}
+
+int qk_weighted_sum(int32_t dtype, int64_t n, const void *a, const float *w, float *out, void *stream)
+{
+    if (!a || !w || !out || n < 0 || dtype < QK_F32 || dtype > QK_F16) { set_error("qk_weighted_sum: bad argument"); return QK_ERR_INVALID_ARG; }
+    if (n == 0) return QK_OK;
+    return check_launch(launch_weighted_sum(dtype, a, w, out, n, (hipStream_t)stream), "qk_weighted_sum");
+}
+
 int qk_conv_prep_kernels(int32_t n, const qk_conv_desc_t *const *descs, const int32_t *ops, const float *const *w,
                          void *const *workspaces, void *stream)
 {

@@ -280,6 +280,85 @@ k_relayout16(const unsigned short *__restrict__ src, unsigned short *__restrict_
     }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Row softmax behind the TIMIT model's TimeDistributed(Dense(62, activation='softmax')) (interspeech_model.py:171-175):
+// one wave per row, lane j = class j (cols <= 64), fp32 logits in (the GEMM's fp32 output), T out.
+//   fwd:  y = softmax(logits + bias)
+//   bwd:  d logits = y * (dy - sum_j dy_j y_j)   (T, the operand of the two gradient GEMMs),
+//         d bias[j] += sum over rows of d logits   (one atomic per class and workgroup)
+// Replaces ~25 elementwise / reduction launches of framework glue per step (cast, bias add, softmax forward and
+// backward in 16 bits, the bias-gradient reduction and the fills they need).
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_max64(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_sum64(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_softmax_rows_fwd(const float *__restrict__ logits, const float *__restrict__ bias, T *__restrict__ y, long long rows, int cols)
+{
+    const int lane = threadIdx.x & 63;
+    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long long)gridDim.x * 4;
+    const bool live = lane < cols;
+    const float b = (live && bias) ? bias[lane] : 0.f;
+    for (long long r = wave; r < rows; r += nwaves) {
+        const float v = live ? logits[r * cols + lane] + b : -INFINITY;
+        const float m = wave_max64(v);
+        const float e = live ? __expf(v - m) : 0.f;
+        const float s = wave_sum64(e);
+        if (live) y[r * cols + lane] = from_f32<T>(e / s);
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_softmax_rows_bwd(const T *__restrict__ y, const T *__restrict__ dy, T *__restrict__ dlogits, float *__restrict__ dbias,
+                   long long rows, int cols)
+{
+    __shared__ float part[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long long wave = (long long)blockIdx.x * 4 + w, nwaves = (long long)gridDim.x * 4;
+    const bool live = lane < cols;
+    float db = 0.f;
+    for (long long r = wave; r < rows; r += nwaves) {
+        const float yv = live ? to_f32(y[r * cols + lane]) : 0.f;
+        const float gv = live ? to_f32(dy[r * cols + lane]) : 0.f;
+        const float dot = wave_sum64(yv * gv);
+        const T q = from_f32<T>(yv * (gv - dot));
+        if (live) dlogits[r * cols + lane] = q;
+        db += to_f32(q);                              // the bias gradient is the column sum of what the GEMMs see
+    }
+    if (dbias) {
+        part[w][lane] = db;
+        __syncthreads();
+        if (w == 0 && live) atomicAdd(dbias + lane, part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane]);
+    }
+}
+
+// sum_i a_i * w_i of a T tensor and an fp32 weight tensor, ADDED to *out (the bench's linear stand-in loss)
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_weighted_sum(const T *__restrict__ a, const float *__restrict__ w, float *__restrict__ out, long long n)
+{
+    __shared__ float part[4];
+    float s = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) s = fmaf(to_f32(a[i]), w[i], s);
+    s = wave_sum64(s);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
+}
+
 }  // namespace
 
 // (n, A, B) -> (n, B, A), 16-bit elements (see k_relayout16)
@@ -361,6 +440,30 @@ int launch_postop(int dtype, bool backward, const void *pre, const void *dy, voi
     else if (dtype == QK_BF16) { if (backward) QK_PO(bf16, true); else QK_PO(bf16, false); }
     else { if (backward) QK_PO(f16, true); else QK_PO(f16, false); }
 #undef QK_PO
+    return hipGetLastError() == hipSuccess ? 0 : QK_ERR_LAUNCH;
+}
+
+int launch_softmax_rows(int dtype, bool backward, const void *a, const void *b, void *out, float *dbias, long long rows, int cols,
+                        hipStream_t stream)
+{
+    long long blocks = (rows + 15) / 16;              // four rows per wave at least
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+#define QK_SM(T) do { if (backward) hipLaunchKernelGGL((k_softmax_rows_bwd<T>), dim3((unsigned)blocks), dim3(256), 0, stream, (const T *)a, (const T *)b, (T *)out, dbias, rows, cols); \
+                      else hipLaunchKernelGGL((k_softmax_rows_fwd<T>), dim3((unsigned)blocks), dim3(256), 0, stream, (const float *)a, (const float *)b, (T *)out, rows, cols); } while (0)
+    if (dtype == QK_F32) QK_SM(float); else if (dtype == QK_BF16) QK_SM(bf16); else QK_SM(f16);
+#undef QK_SM
+    return hipGetLastError() == hipSuccess ? 0 : QK_ERR_LAUNCH;
+}
+
+int launch_weighted_sum(int dtype, const void *a, const float *w, float *out, long long n, hipStream_t stream)
+{
+    long long blocks = (n + 256 * 16 - 1) / (256 * 16);
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    if (dtype == QK_F32) hipLaunchKernelGGL((k_weighted_sum<float>), dim3((unsigned)blocks), dim3(256), 0, stream, (const float *)a, w, out, n);
+    else if (dtype == QK_BF16) hipLaunchKernelGGL((k_weighted_sum<bf16>), dim3((unsigned)blocks), dim3(256), 0, stream, (const bf16 *)a, w, out, n);
+    else hipLaunchKernelGGL((k_weighted_sum<f16>), dim3((unsigned)blocks), dim3(256), 0, stream, (const f16 *)a, w, out, n);
     return hipGetLastError() == hipSuccess ? 0 : QK_ERR_LAUNCH;
 }
 

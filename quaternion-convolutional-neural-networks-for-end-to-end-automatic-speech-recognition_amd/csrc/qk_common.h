@@ -245,6 +245,9 @@ int launch_conv1_pool(int dtype, bool backward, const void *x, const float *w, c
                       int x_planes = 0);
 int launch_postop(int dtype, bool backward, const void *pre, const void *dy, void *out, float *dalpha, const PostOp &p,
                   long long rows, int channels, int key_div, int key_mod, hipStream_t stream);
+int launch_softmax_rows(int dtype, bool backward, const void *a, const void *b, void *out, float *dbias, long long rows, int cols,
+                        hipStream_t stream);
+int launch_weighted_sum(int dtype, const void *a, const float *w, float *out, long long n, hipStream_t stream);
 int launch_adam(float *p, float *g, float *m, float *v, const float *decay, size_t n, float lr, float b1,
                 float b2, float eps, int step, float gscale, bool zero_grad, hipStream_t stream);
 

@@ -946,6 +946,7 @@ k_hgemm16_point(const T *__restrict__ in, const uint4 *__restrict__ wq, const fl
     int cur_slice = -1;
     // backward post-op (PReLU / dropout derivative of the tensor whose gradient is produced, see k_hgemm16)
     const bool post_on = EPM && g.post.kind != 0;
+    const bool post_fwd_relu = !EPM && g.post.kind == 2 && g.post_fwd != 0;
     float *aslab = reinterpret_cast<float *>(lds + B_U + BF + 8 * 32 * EP_PITCH / 16);
     if (post_on && g.dalpha && tid < 256) aslab[tid] = 0.f;      // (the first unit's slice load brings the barrier)
     const uint4 *w_rd = lds + wn * 32 + lr;
@@ -1049,6 +1050,8 @@ k_hgemm16_point(const T *__restrict__ in, const uint4 *__restrict__ wq, const fl
                 if constexpr (EPM) {
                     if (post_on) v = post_bwd8<T>(v, em[b][pass], a_val[pass], o_off[pass] / 2u + (unsigned)(b * g.J), g.post, dal[pass]);
                     else v = mask8(v, em[b][pass]);
+                } else {
+                    if (post_fwd_relu) v = post_fwd8<T>(v, 0.f, o_off[pass] / 2u + (unsigned)(b * g.J), g.post);     // y = dropout(relu(pre))
                 }
                 buf_store16b(rout, o_off[pass], (unsigned)(b * g.J) * 2u, v);
             }
@@ -1070,8 +1073,11 @@ k_hgemm16_point(const T *__restrict__ in, const uint4 *__restrict__ wq, const fl
 inline bool point_geom(const GemmGeom &g, GemmGeom *o)
 {
     if (g.has_mask || (g.Q != 32 && g.Q != 64) || g.J % 64 != 0) return false;
-    if (g.post.kind != 0) {       // only the backward form (derivative in the epilogue, pre-activation in ep_mask)
-        if (!g.ep_mask || g.post_fwd || g.post.alpha_len > 256 || (g.taps == 1 && g.post.alpha_sel >= 0)) return false;
+    if (g.post.kind != 0) {
+        // the backward form (derivative in the epilogue, pre-activation / y in ep_mask), or -- round 4 -- the forward RELU form
+        // y = dropout(relu(pre)) with its single output tensor (the TimeDistributed dense layers of the TIMIT model as chain links)
+        const bool fwd_relu = g.post_fwd && g.post.kind == 2 && !g.pre_out && !g.ep_mask;
+        if (!fwd_relu && (!g.ep_mask || g.post_fwd || g.post.alpha_len > 256 || (g.taps == 1 && g.post.alpha_sel >= 0))) return false;
     }
     *o = g;
     if (g.taps == 1) {

@@ -882,6 +882,7 @@ class _ConvChainFn(torch.autograd.Function):
             else:
                 g, dws[i], dbs[i] = calls[i].bwd(acts[i], g, acts[i + 1], ws[i], ctx.has_bias[i], flags=flags, wparam=pw)
         das = [None if d is None else d.reshape(p.alpha.shape) for d, p in zip(das, posts)]      # (relu form: no slopes)
+        dws = [None if d is None else d.reshape(w.shape) for d, w in zip(dws, ctx.param_refs[0])]   # (dense links: 2-D parameters)
         return (g, None, None) + tuple(dws) + tuple(dbs) + tuple(das)
 
 
@@ -898,12 +899,22 @@ def quaternion_conv_chain(x, layers):
     calls, ws, bs, posts, alphas = [], [], [], [], []
     shape = tuple(xp.shape)
     for kernel, bias, kw in layers:
-        rank = kernel.dim() - 2
+        if kernel.dim() == 2:
+            # a QuaternionDense weight (in_q, 4 * units): the layer applied to every position of the channels-last tensor is
+            # the 1 x ... x 1 conj-convolution with that weight as its single tap (dense.py:139-143 builds the transposed
+            # table).  The PARAMETER itself is passed on (same memory as the (1, ..., in_q, 4 units) kernel): its cached
+            # 16-bit re-layout and the direct gradient writes keep working.
+            rank = len(shape) - 2
+            kw = dict(kw, conj=True, strides=1, padding='valid', dilation_rate=1)
+            w_shape = (1,) * rank + tuple(kernel.shape)
+        else:
+            rank = kernel.dim() - 2
+            w_shape = tuple(kernel.shape)
         _check_weights(kernel, bias, kernel.shape[-1])
         po = kw.get('post')
         if po is not None and kw.get('activation') not in (None, 'linear'):
             raise ValueError('a layer with a post-op must be linear (the post-op is its activation)')
-        call = conv_call(shape, tuple(kernel.shape), xp.dtype, rank, kw.get('strides', 1), kw.get('padding', 'valid'),
+        call = conv_call(shape, w_shape, xp.dtype, rank, kw.get('strides', 1), kw.get('padding', 'valid'),
                          'channels_last', kw.get('dilation_rate', 1), kw.get('activation'), bias is not None,
                          bool(kw.get('conj', False)))
         calls.append(call)
@@ -913,6 +924,59 @@ def quaternion_conv_chain(x, layers):
         alphas.append(None if po is None else po['alpha'])
         shape = tuple(call.y_shape)
     return _ConvChainFn.apply(xp, tuple(calls), tuple(posts), *ws, *bs, *alphas)
+
+
+def softmax_rows_fwd(logits, bias, out_dtype):
+    """softmax(logits + bias) over the last axis of an fp32 (rows, cols <= 64) device matrix, written in `out_dtype`
+    (include/qk.h: qk_softmax_rows_fwd)."""
+    _require_device(logits, 'softmax_rows_fwd')
+    if logits.dtype != torch.float32 or logits.dim() != 2 or not logits.is_contiguous() or logits.shape[1] > 64:
+        raise ValueError('softmax_rows_fwd: contiguous fp32 (rows, cols <= 64) logits')
+    y = torch.empty(logits.shape, dtype=out_dtype, device=logits.device)
+    with _on_device(logits.device):
+        rc = L.lib().qk_softmax_rows_fwd(_DTYPES[out_dtype], logits.shape[0], logits.shape[1], _ptr(logits), _ptr(bias), _ptr(y), _stream(logits))
+    L.check(rc, 'qk_softmax_rows_fwd')
+    return y
+
+
+def softmax_rows_bwd(y, dy, dbias=None):
+    """d logits = y * (dy - <dy, y>) (returned, y's dtype); the bias gradient (column sums) is ADDED to the fp32 buffer `dbias`."""
+    _require_device(y, 'softmax_rows_bwd')
+    dl = torch.empty_like(y)
+    with _on_device(y.device):
+        rc = L.lib().qk_softmax_rows_bwd(_DTYPES[y.dtype], y.shape[0], y.shape[1], _ptr(y), _ptr(dy), _ptr(dl), _ptr(dbias), _stream(y))
+    L.check(rc, 'qk_softmax_rows_bwd')
+    return dl
+
+
+class _WeightedSumFn(torch.autograd.Function):
+    """sum(a * w) for a 16-bit / fp32 device tensor `a` and a CONSTANT fp32 weight tensor `w` as one launch (qk_weighted_sum);
+    the backward hands back w in a's dtype (cast once, kept on the weight tensor)."""
+
+    @staticmethod
+    def forward(ctx, a, w):
+        out = torch.zeros((), dtype=torch.float32, device=a.device)
+        with _on_device(a.device):
+            rc = L.lib().qk_weighted_sum(_DTYPES[a.dtype], a.numel(), _ptr(a), _ptr(w), _ptr(out), _stream(a))
+        L.check(rc, 'qk_weighted_sum')
+        cache = w.__dict__.setdefault('_qk_cast', {})
+        hit = cache.get(a.dtype)
+        if hit is None or hit[0] != w._version:
+            hit = cache[a.dtype] = (w._version, w.to(a.dtype))
+        ctx.wt = hit[1]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return ctx.wt * g.to(ctx.wt.dtype), None
+
+
+def weighted_sum(a, w):
+    """The linear functional sum(a * w) of a model output (the bench's stand-in loss), one launch forward, one backward."""
+    _require_device(a, 'weighted_sum')
+    if w.dtype != torch.float32 or w.numel() != a.numel() or w.requires_grad:
+        raise ValueError('weighted_sum: w must be a constant fp32 tensor with as many elements as a')
+    return _WeightedSumFn.apply(a.contiguous(), w.contiguous())
 
 
 class _CtcFn(torch.autograd.Function):

@@ -68,6 +68,56 @@ class _TallDenseFn(torch.autograd.Function):
         return dx, dw, db
 
 
+def _cast_cached(w, dtype):
+    """w.to(dtype), kept on the parameter until it changes (version counters as in functional._Call._ws: the fused Adam bumps
+    the flat buffer's, torch ops the parameter's own)."""
+    base = getattr(w, '_qk_flat_base', None)
+    ver = (w._version, -1 if base is None else base._version, w.data_ptr())
+    hit = w.__dict__.get('_qk_cast16')
+    if hit is None or hit[0] != ver or hit[1].dtype != dtype:
+        hit = (ver, w.detach().to(dtype))
+        w.__dict__['_qk_cast16'] = hit
+    return hit[1]
+
+
+class _DenseSoftmaxFn(torch.autograd.Function):
+    """softmax(x @ W + b) for MANY rows of a 16-bit device tensor and fp32 master weights -- the model's output layer,
+    TimeDistributed(Dense(62, activation='softmax')) on 51 200 rows (interspeech_model.py:171-175) -- in three launches
+    forward (kernel cast when stale, one library GEMM with fp32 output, qk_softmax_rows_fwd: bias + softmax from the fp32
+    logits) and four backward (qk_softmax_rows_bwd: d logits + the bias gradient, one GEMM for dx, the split GEMM + sum of
+    _TallDenseFn for the kernel gradient) instead of ~35 framework launches (16-bit bias add, softmax forward / backward,
+    reductions, fills).  The softmax sees fp32 logits (the unfused path rounds them to 16 bits first)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        w16 = _cast_cached(w, x.dtype)
+        logits = torch.mm(x, w16, out_dtype=torch.float32)
+        y = Fq.softmax_rows_fwd(logits, b, x.dtype)
+        ctx.save_for_backward(x, w16, y)
+        ctx.bias = b
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w16, y = ctx.saved_tensors
+        b = ctx.bias
+        want_b = b is not None and ctx.needs_input_grad[2]
+        direct = want_b and getattr(b, '_qk_direct_grad', False) and b.grad is not None and b.grad.dtype == torch.float32
+        db = None
+        if want_b:
+            db = b.grad if direct else torch.zeros(b.shape, dtype=torch.float32, device=y.device)
+        dl = Fq.softmax_rows_bwd(y, dy.contiguous(), db)
+        dx = dl @ w16.t() if ctx.needs_input_grad[0] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            s = _TallDenseFn.SPLITS
+            dw = torch.bmm(x.view(s, -1, x.shape[1]).transpose(1, 2), dl.view(s, -1, dl.shape[1]), out_dtype=torch.float32).sum(0)
+        if direct:
+            Fq._grad_ready(b)                 # the kernel added the bias gradient into the flat buffer itself
+            db = None
+        return dx, dw, db
+
+
 class Dense(Layer):
     """keras.layers.Dense on the last axis (kernel (in, units), glorot_uniform by default)."""
 
@@ -93,8 +143,13 @@ class Dense(Layer):
 
     def call(self, inputs):
         rows = inputs.numel() // max(inputs.shape[-1], 1)
-        if (inputs.is_cuda and inputs.dtype in (torch.bfloat16, torch.float16) and self.kernel.dtype == torch.float32
-                and rows >= 8192 and rows % _TallDenseFn.SPLITS == 0 and inputs.is_contiguous()):
+        tall = (inputs.is_cuda and inputs.dtype in (torch.bfloat16, torch.float16) and self.kernel.dtype == torch.float32
+                and rows >= 8192 and rows % _TallDenseFn.SPLITS == 0 and inputs.is_contiguous())
+        if (tall and activations.serialize(self.activation) == 'softmax' and self.units <= 64
+                and not os.environ.get('QK_NO_FUSED_SOFTMAX')):
+            y = _DenseSoftmaxFn.apply(inputs.reshape(rows, inputs.shape[-1]), self.kernel, self.bias)
+            return y.reshape(tuple(inputs.shape[:-1]) + (self.units,))
+        if tall:
             out = _TallDenseFn.apply(inputs.reshape(rows, inputs.shape[-1]), self.kernel, self.bias)
             return self.activation(out.reshape(tuple(inputs.shape[:-1]) + (self.units,)))
         out = inputs @ self.kernel.to(inputs.dtype)

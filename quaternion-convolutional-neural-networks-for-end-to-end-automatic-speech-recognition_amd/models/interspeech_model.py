@@ -191,9 +191,25 @@ class TimitQCNN(torch.nn.Module):
         head_shape = (shape[0], dl.r.shape[-1], shape[3])                       # (B, units, T): TimeDistributed output, channels_first view
         layers.append((w, dl.bias, dict(strides=1, padding='valid', dilation_rate=1, activation=None, conj=True,
                                         post=self._post(k, (shape[0], shape[3], dl.r.shape[-1])))))
+        k += 1
+        if relu_form and not os.environ.get('QK_NO_DENSE_IN_CHAIN'):
+            # aact == 'none': the second and third TimeDistributed(QuaternionDense(256)) (interspeech_model.py:150-166) are links
+            # of the SAME chain -- 1 x 1 conj-convolutions on the (B, 1, T, 256) tensor, relu (+ dropout behind the second) as the
+            # producing kernel's post-op, its derivative in the consumer's backward-data epilogue: no separate activation /
+            # dropout pass in either direction
+            width = head_shape[1]
+            for i in (1, 2):
+                dn = self.dense[i].layer
+                if not dn.built:
+                    dn._build_device = x.device
+                    dn.build((None, width))
+                width = dn.r.shape[-1]
+                layers.append((dn.r, dn.bias, dict(activation=None, post=self._post(k, (shape[0], shape[3], width), dropout=(i < 2)))))
+                k += 1
+            y = Fq.quaternion_conv_chain(o.movedim(1, -1), layers)              # (B, 1, T, units)
+            return self.pred(y.reshape(y.shape[0], y.shape[2], y.shape[3]))
         y = Fq.quaternion_conv_chain(o.movedim(1, -1), layers)                  # (B, 1, T, units)
         o = y.reshape(y.shape[0], y.shape[2], y.shape[3])
-        k += 1
         for i in (1, 2):
             dn = self.dense[i].layer
             b, t = o.shape[0], o.shape[1]

@@ -413,6 +413,60 @@ def test_fused_ctc_batch_cost_matches_the_keras_restatement(shape, dtype):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16], ids=['bf16', 'fp16'])
+def test_fused_dense_softmax_output_layer_matches_float64(dtype):
+    """TimeDistributed(Dense(62, activation='softmax')) (interspeech_model.py:171-175) through layers._DenseSoftmaxFn -- library
+    GEMMs + qk_softmax_rows_fwd / _bwd -- against a float64 restatement on the same 16-bit operands: posteriors, d input,
+    d kernel, d bias; with the bench's weighted-sum loss (qk_weighted_sum) on top.  Also against the unfused torch path."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    import qcnn_amd
+    from qcnn_amd.layers import Dense
+    Fq = qcnn_amd.functional
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(8)
+    rows, kin, units = 8192, 256, 62
+    x = torch.randn(rows, kin, generator=g).to(dtype)
+    tgt = torch.randn(rows, units, generator=g)
+    np.random.seed(3)
+    layer = Dense(units, activation='softmax', kernel_initializer='random_uniform')
+    layer._build_device = dev
+    layer.build((None, kin))
+    with torch.no_grad():
+        layer.kernel.mul_(20.0)                   # logits of order 1: a softmax that is not flat
+        layer.bias.copy_(torch.randn(units, generator=g).to(dev) * 0.5)
+    outs = {}
+    for fused in (True, False):
+        if not fused:
+            os.environ['QK_NO_FUSED_SOFTMAX'] = '1'
+        try:
+            xd = x.to(dev).requires_grad_(True)
+            layer.zero_grad()
+            y = layer(xd)
+            loss = Fq.weighted_sum(y, tgt.to(dev)) if fused else (y.float() * tgt.to(dev)).sum()
+            loss.backward()
+            outs[fused] = [t.detach().double().cpu() for t in (y, loss, xd.grad, layer.kernel.grad, layer.bias.grad)]
+        finally:
+            os.environ.pop('QK_NO_FUSED_SOFTMAX', None)
+    w64 = layer.kernel.detach().to(dtype).double().cpu().requires_grad_(True)      # the GEMMs multiply the 16-bit image of the kernel
+    b64 = layer.bias.detach().double().cpu().requires_grad_(True)
+    x64 = x.double().requires_grad_(True)
+    y64 = torch.softmax(x64 @ w64 + b64, -1)
+    l64 = (y64 * tgt.double()).sum()
+    l64.backward()
+    want = [y64.detach(), l64.detach(), x64.grad, w64.grad, b64.grad]
+    tol = dict(bfloat16=(8e-3, 2e-3, 2e-2, 1e-2, 1e-2), float16=(1e-3, 5e-4, 4e-3, 2e-3, 2e-3))[str(dtype).split('.')[-1]]
+    for name, got, ref, t in zip(('y', 'loss', 'dx', 'dkernel', 'dbias'), outs[True], want, tol):
+        err = float((got - ref).abs().max() / ref.abs().max())
+        assert err <= t, '%s: %.3g > %.1g' % (name, err, t)
+    # the fused path is at least as close to float64 as the unfused one on the posteriors (fp32 logits instead of 16-bit ones)
+    e_f = float((outs[True][0] - want[0]).abs().max())
+    e_u = float((outs[False][0] - want[0]).abs().max())
+    assert e_f <= e_u * 1.05 + 1e-6, (e_f, e_u)
+    assert abs(float(outs[True][0].sum(-1).mean()) - 1.0) < 2e-3
+
+
+@pytest.mark.gpu
 def test_fused_ctc_degenerate_samples():
     """Samples TensorFlow's ctc_loss raises for (round-3 advisor): a label sequence that does not fit its frames (with the
     blank a repeated label needs) gets cost +inf and NO gradient -- not a finite softmax / (p + eps) row that would steer
