@@ -325,24 +325,35 @@ __global__ void __launch_bounds__(256)
 k_softmax_rows_bwd(const T *__restrict__ y, const T *__restrict__ dy, T *__restrict__ dlogits, float *__restrict__ dbias,
                    long long rows, int cols)
 {
+    // (bias gradient: one atomic per class and workgroup.  The launcher keeps the grid at <= 512 workgroups: 3200 of them
+    //  x 62 atomics on two cache lines cost 80 us; a last-workgroup-reduces scheme cost more still -- its agent-scope
+    //  release per workgroup writes the L2 back 2048 times -- measured, round 4)
     __shared__ float part[4][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const long long wave = (long long)blockIdx.x * 4 + w, nwaves = (long long)gridDim.x * 4;
     const bool live = lane < cols;
     float db = 0.f;
-    for (long long r = wave; r < rows; r += nwaves) {
-        const float yv = live ? to_f32(y[r * cols + lane]) : 0.f;
-        const float gv = live ? to_f32(dy[r * cols + lane]) : 0.f;
-        const float dot = wave_sum64(yv * gv);
-        const T q = from_f32<T>(yv * (gv - dot));
-        if (live) dlogits[r * cols + lane] = q;
-        db += to_f32(q);                              // the bias gradient is the column sum of what the GEMMs see
+    for (long long r0 = wave * 4; r0 < rows; r0 += nwaves * 4) {          // four rows in flight per wave
+        float yv[4], gv[4], dot[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool ok = live && r0 + k < rows;
+            yv[k] = ok ? to_f32(y[(r0 + k) * cols + lane]) : 0.f;
+            gv[k] = ok ? to_f32(dy[(r0 + k) * cols + lane]) : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dot[k] = wave_sum64(yv[k] * gv[k]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const T q = from_f32<T>(yv[k] * (gv[k] - dot[k]));
+            if (live && r0 + k < rows) dlogits[(r0 + k) * cols + lane] = q;
+            db += to_f32(q);                          // the bias gradient is the column sum of what the GEMMs see
+        }
     }
-    if (dbias) {
-        part[w][lane] = db;
-        __syncthreads();
-        if (w == 0 && live) atomicAdd(dbias + lane, part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane]);
-    }
+    if (!dbias) return;
+    part[w][lane] = db;
+    __syncthreads();
+    if (w == 0 && live) atomicAdd(dbias + lane, part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane]);
 }
 
 // sum_i a_i * w_i of a T tensor and an fp32 weight tensor, ADDED to *out (the bench's linear stand-in loss)
@@ -352,7 +363,13 @@ k_weighted_sum(const T *__restrict__ a, const float *__restrict__ w, float *__re
 {
     __shared__ float part[4];
     float s = 0.f;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) s = fmaf(to_f32(a[i]), w[i], s);
+    const long long n4 = n / 4;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const float4 wv = reinterpret_cast<const float4 *>(w)[i];
+        const T *ap = a + 4 * i;
+        s = fmaf(to_f32(ap[0]), wv.x, s); s = fmaf(to_f32(ap[1]), wv.y, s); s = fmaf(to_f32(ap[2]), wv.z, s); s = fmaf(to_f32(ap[3]), wv.w, s);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (unsigned)(n - 4 * n4)) s = fmaf(to_f32(a[4 * n4 + threadIdx.x]), w[4 * n4 + threadIdx.x], s);
     s = wave_sum64(s);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
     __syncthreads();
@@ -447,7 +464,8 @@ int launch_softmax_rows(int dtype, bool backward, const void *a, const void *b, 
                         hipStream_t stream)
 {
     long long blocks = (rows + 15) / 16;              // four rows per wave at least
-    if (blocks > 4096) blocks = 4096;
+    const long long cap = backward ? 512 : 2048;      // (backward: one atomic per class and workgroup)
+    if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
 #define QK_SM(T) do { if (backward) hipLaunchKernelGGL((k_softmax_rows_bwd<T>), dim3((unsigned)blocks), dim3(256), 0, stream, (const T *)a, (const T *)b, (T *)out, dbias, rows, cols); \
                       else hipLaunchKernelGGL((k_softmax_rows_fwd<T>), dim3((unsigned)blocks), dim3(256), 0, stream, (const float *)a, (const float *)b, (T *)out, rows, cols); } while (0)
@@ -458,8 +476,8 @@ int launch_softmax_rows(int dtype, bool backward, const void *a, const void *b, 
 
 int launch_weighted_sum(int dtype, const void *a, const float *w, float *out, long long n, hipStream_t stream)
 {
-    long long blocks = (n + 256 * 16 - 1) / (256 * 16);
-    if (blocks > 1024) blocks = 1024;
+    long long blocks = (n / 4 + 255) / 256;
+    if (blocks > 512) blocks = 512;                   // one atomic per workgroup on ONE address: keep them few
     if (blocks < 1) blocks = 1;
     if (dtype == QK_F32) hipLaunchKernelGGL((k_weighted_sum<float>), dim3((unsigned)blocks), dim3(256), 0, stream, (const float *)a, w, out, n);
     else if (dtype == QK_BF16) hipLaunchKernelGGL((k_weighted_sum<bf16>), dim3((unsigned)blocks), dim3(256), 0, stream, (const bf16 *)a, w, out, n);
