@@ -39,8 +39,18 @@ def leaves(p):
     return out + (list(p['alphas']) if p['alphas'] is not None else [])
 
 
-def timit_forward(x, p, act='relu'):
-    """x (B, 4, 41, T) channels_first -> posteriors (B, T, 62)."""
+def ctc_cost(pred, labels, input_length, label_length):
+    """K.ctc_batch_cost (interspeech_model.py:37-39) restated on torch-CPU: Keras hands log(y_pred + 1e-7) to tf.nn.ctc_loss
+    as logits, which normalises them again; blank = last class.  Per-sample cost (B,)."""
+    logp = torch.log_softmax(torch.log(pred + 1e-7), dim=-1).transpose(0, 1)
+    return torch.nn.functional.ctc_loss(logp, labels.long(), input_length.reshape(-1).long(), label_length.reshape(-1).long(),
+                                        blank=pred.shape[-1] - 1, reduction='none', zero_infinity=False)
+
+
+def timit_forward(x, p, act='relu', dropout=0.0):
+    """x (B, 4, 41, T) channels_first -> posteriors (B, T, 62).  dropout: Dropout(d.dropout) behind every body convolution
+    and the first two dense layers (interspeech_model.py:117-121,131-137,150-154), training mode."""
+    drop = (lambda h: torch.nn.functional.dropout(h, dropout, True)) if dropout > 0 else (lambda h: h)
     alphas = p['alphas']
     a = None if alphas is not None else act
     pl = (lambda h, k: torch.relu(h) - alphas[k] * torch.relu(-h)) if alphas is not None else (lambda h, k: h)
@@ -49,9 +59,11 @@ def timit_forward(x, p, act='relu'):
     h = torch.nn.functional.max_pool2d(h, (3, 1), (3, 1), ceil_mode=True)     # 'same': high-side padding only (41 -> 14)
     n = len(p['convs'])
     for i, (w, b) in enumerate(p['convs']):
-        h = pl(ref_port.conv_forward(h, w, b, 2, **kw), 1 + i)
+        h = drop(pl(ref_port.conv_forward(h, w, b, 2, **kw), 1 + i))
     bsz, t = h.shape[0], h.shape[3]
     h = h.permute(0, 3, 1, 2).reshape(bsz, t, -1)
     for i, (w, b) in enumerate(p['dense']):
         h = pl(ref_port.dense_forward(h.reshape(bsz * t, -1), w, b, activation=a).reshape(bsz, t, -1), 1 + n + i)
+        if i < 2:
+            h = drop(h)
     return torch.softmax(h @ p['pred'][0] + p['pred'][1], dim=-1)

@@ -308,12 +308,92 @@ class TimitQCNN(torch.nn.Module):
         return self.ctc_loss(x, labels, input_length, label_length).mean() + self.regularization_loss()
 
 
+class _RealConv2D(Layer):
+    """keras Conv2D(filters, (3, 5), data_format='channels_first', padding='same') of the reference's `d.model == "real"`
+    branch (interspeech_model.py:92-96,109-113,124-128): a stock real-valued layer, outside the quaternion hot path -- torch's
+    own convolution with TensorFlow's 'same' rule (odd kernels: symmetric padding)."""
+
+    def __init__(self, filters, kernel_size, activation=None, kernel_regularizer=None, **kwargs):
+        super(_RealConv2D, self).__init__(**kwargs)
+        from ..keras_like import activations, initializers
+        self.filters, self.kernel_size = filters, tuple(kernel_size)
+        self.activation = activations.get(activation)
+        self.kernel_regularizer = regularizers.get(kernel_regularizer)
+        self._init = initializers.get('random_uniform')
+        self._zeros = initializers.get('zeros')
+
+    def build(self, input_shape):
+        self.add_weight('kernel', self.kernel_size + (input_shape[1], self.filters), initializer=self._init,
+                        regularizer=self.kernel_regularizer)                 # Keras layout (kh, kw, in, out)
+        self.add_weight('bias', (self.filters,), initializer=self._zeros)
+        self.built = True
+
+    def call(self, inputs):
+        w = self.kernel.permute(3, 2, 0, 1).to(inputs.dtype)
+        y = torch.nn.functional.conv2d(inputs, w, self.bias.to(inputs.dtype), padding=(self.kernel_size[0] // 2, self.kernel_size[1] // 2))
+        return self.activation(y)
+
+    def compute_output_shape(self, input_shape):
+        return (input_shape[0], self.filters) + tuple(input_shape[2:])
+
+
+class TimitRealCNN(torch.nn.Module):
+    """The `d.model == "real"` branch of getTimitModel2D (interspeech_model.py:92-96,109-113,124-128,159-169): Conv2D stack
+    on (B, 3, 41, T), the same frequency pooling, three TimeDistributed(Dense(1024)), Dense(62, softmax), CTC.  Stock
+    real-valued layers throughout (torch ops): the comparison network of the paper, not part of the Hamilton hot path."""
+
+    def __init__(self, num_layers=10, start_filter=32, act='relu', aact='none', dropout=0.0, l2=0.0):
+        super(TimitRealCNN, self).__init__()
+        n, sf = num_layers, start_filter
+        if aact != 'none':
+            act = 'linear'
+        reg = regularizers.l2(l2) if l2 else None
+        self.conv = _RealConv2D(sf, (3, 5), activation=act, kernel_regularizer=reg)
+        self.pool = MaxPooling2D(pool_size=(1, 3), padding='same')
+        widths = [sf] * (n // 2) + [2 * sf] * (n // 2)
+        self.convs = torch.nn.ModuleList([_RealConv2D(w, (3, 5), activation=act, kernel_regularizer=reg) for w in widths])
+        dense_args = dict(activation=act, kernel_regularizer=reg, kernel_initializer='random_uniform', bias_initializer='zeros', use_bias=True)
+        self.dense = torch.nn.ModuleList([TimeDistributed(Dense(1024, **dense_args)) for _ in range(3)])
+        self.prelu = torch.nn.ModuleList([PReLU(shared_axes=[1, 0]) for _ in range(1 + len(widths) + 3)]) if aact == 'prelu' else None
+        self.drop = Dropout(dropout)
+        self.pred = TimeDistributed(Dense(62, activation='softmax', kernel_regularizer=reg, use_bias=True,
+                                          bias_initializer='zeros', kernel_initializer='random_uniform'))
+
+    def _act(self, x, i):
+        return self.prelu[i](x) if self.prelu is not None else x
+
+    def forward(self, x):
+        o = self.pool(self._act(self.conv(x), 0))
+        k = 1
+        for c in self.convs:
+            o = self.drop(self._act(c(o), k))
+            k += 1
+        o = o.permute(0, 3, 1, 2)
+        o = o.reshape(o.shape[0], o.shape[1], o.shape[2] * o.shape[3])
+        for i, dl in enumerate(self.dense):
+            o = self._act(dl(o), k)
+            k += 1
+            if i < 2:
+                o = self.drop(o)
+        return self.pred(o)
+
+    ctc_loss = TimitQCNN.ctc_loss
+    regularization_loss = TimitQCNN.regularization_loss
+    training_loss = TimitQCNN.training_loss
+
+
 def getTimitModel2D(d):
     """(model, val_function) like the reference: `model(x)` gives the (B, T, 62) posteriors,
     `model.ctc_loss(...)` the CTC cost of interspeech_model.py:178, `model.training_loss(...)` that cost
-    averaged over the batch plus the l2 terms Keras adds (d.l2); val_function(x) == model(x)."""
-    if getattr(d, 'model', 'quaternion') != 'quaternion':
-        raise NotImplementedError('only the quaternion branch of getTimitModel2D is provided')
+    averaged over the batch plus the l2 terms Keras adds (d.l2); val_function(x) == model(x).
+    d.model == 'quaternion' builds the engine's TimitQCNN on (B, 4, 41, T); d.model == 'real' the stock-layer comparison
+    network on (B, 3, 41, T) (TimitRealCNN)."""
+    kind = getattr(d, 'model', 'quaternion')
+    if kind == 'real':
+        m = TimitRealCNN(d.num_layers, d.start_filter, d.act, d.aact, d.dropout, getattr(d, 'l2', 0.0))
+        return m, (lambda x: m(x))
+    if kind != 'quaternion':
+        raise ValueError("d.model must be 'quaternion' or 'real', got %r" % (kind,))
     m = TimitQCNN(d.num_layers, d.start_filter, d.act, d.aact, d.dropout, getattr(d, 'l2', 0.0),
                   getattr(d, 'quat_init', 'quaternion'))
     return m, (lambda x: m(x))

@@ -572,7 +572,7 @@ def test_bench_prints_one_contract_line():
         assert k in d, k
     assert (d['n_gpus'], d['steps'], d['warmup'], d['unit'], d['dtype'], d['data'], d['scaling']) == (1, 3, 1, 'samples/s', 'bf16', 'synthetic', 'weak')
     assert d['config']['workload'] == 'cfg3_qcnn_relu_dropout_b256_bf16' and d['vs_baseline'] is None and d['higher_is_better'] is True
-    assert d['config']['dropout'] == 0.3 and d['config']['l2'] > 0 and d['config']['loss'] == 'sum' and d['config']['rccl_ranks'] is None
+    assert d['config']['dropout'] == 0.3 and d['config']['l2'] > 0 and d['config']['loss'] == 'ctc' and d['config']['rccl_ranks'] is None
     assert d['config']['input'] == [256, 4, 41, 200] and d['config']['input_layout'].startswith('channels_first')
     assert abs(d['value'] - 256 * 1e3 / d['ms_per_step']) <= 1e-6 * d['value']
     calls = d['in_step_kernels']['calls']
@@ -597,3 +597,57 @@ def test_timit_training_example_runs_and_learns():
     assert out.returncode == 0, out.stderr[-2000:]
     costs = [float(v) for v in re.findall(r'ctc cost ([0-9.]+)', out.stdout)]
     assert len(costs) >= 3 and costs[-1] < 0.5 * costs[0], costs
+
+
+def test_real_branch_of_getTimitModel2D_builds_and_trains_on_cpu():
+    """`d.model == "real"` (interspeech_model.py:92-96,109-113,124-128,159-169): the stock-layer comparison network the reference
+    builds beside the quaternion one -- Conv2D stack on (B, 3, 41, T), Dense(1024) x 3, Dense(62, softmax), CTC.  Plain torch
+    layers (it is not the Hamilton hot path), so it runs anywhere: shapes, parameter count of the Keras graph, a finite
+    training loss with every parameter receiving a gradient."""
+    from qcnn_amd.models.interspeech_model import getTimitModel2D, TimitRealCNN
+    np.random.seed(0)
+    torch.manual_seed(0)
+    d = types.SimpleNamespace(model='real', num_layers=4, start_filter=8, act='relu', aact='prelu', dropout=0.2, l2=1e-4)
+    m, val = getTimitModel2D(d)
+    assert isinstance(m, TimitRealCNN)
+    x = torch.randn(2, 3, 41, 30)
+    y = val(x)
+    assert tuple(y.shape) == (2, 30, 62) and abs(float(y.sum(-1).mean()) - 1.0) < 1e-5
+    convs = 15 * 3 * 8 + 8 + 2 * (15 * 8 * 8 + 8) + (15 * 8 * 16 + 16) + (15 * 16 * 16 + 16)
+    dense = (14 * 16 * 1024 + 1024) + 2 * (1024 * 1024 + 1024) + 1024 * 62 + 62
+    prelu = 41 + 4 * 14 + 3 * 1                        # PReLU(shared_axes=[1, 0]): one slope per frequency row / one per dense layer
+    assert sum(p.numel() for p in m.parameters()) == convs + dense + prelu
+    labels, il, ll = torch.randint(0, 61, (2, 5)), torch.full((2, 1), 30), torch.full((2, 1), 5)
+    loss = m.training_loss(x, labels, il, ll)
+    loss.backward()
+    assert torch.isfinite(loss) and all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+    with pytest.raises(ValueError):
+        getTimitModel2D(types.SimpleNamespace(model='complex', num_layers=2, start_filter=4, act='relu', aact='none', dropout=0.0))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('model', ['QDNN', 'QCNN'])
+def test_working_example_script_runs_one_epoch_on_the_decoda_fixture(tmp_path, model):
+    """examples/working_example.py -- the counterpart of the reference's only runnable entry point (working_example.py:88-137,
+    BASELINE configs[0]) -- end to end on the 8-document DECODA fixture (the first lines of the reference's own DEV file):
+    data prep, the example network on the engine's layers, Adam, categorical cross-entropy, evaluation.  The reference ships
+    no TRAIN file either, so the script trains on DEV, as it says."""
+    import shutil
+    import subprocess
+    import sys
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, 'tests', 'golden', 'decoda_dev_head8.data')
+    for split in ('DEV', 'TEST'):
+        shutil.copy(src, tmp_path / ('250_%s_Q.data' % split))
+    out = subprocess.run([sys.executable, os.path.join(root, 'examples', 'working_example.py'), '--model', model, '--decoda', str(tmp_path),
+                          '--epochs', '1', '--batch-size', '3'], capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert 'Train size : 8' in out.stdout and 'training on DEV' in out.stdout
+    ep = [l for l in out.stdout.splitlines() if l.startswith('epoch  1')]
+    assert len(ep) == 1 and 'dev loss' in ep[0]
+    last = [l for l in out.stdout.splitlines() if l.startswith('Test Loss')]
+    assert len(last) == 1
+    loss, acc = float(last[0].split('=')[1].split('|')[0]), float(last[0].split('=')[2])
+    assert np.isfinite(loss) and 0.0 < loss < 5.0 and 0.0 <= acc <= 1.0

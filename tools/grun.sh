@@ -4,4 +4,5 @@
 set -e
 cd "$(dirname "$0")/.."
 python -c "import __graft_entry__ as g; g.build()" | tail -1
+[ tools/probe/libenergy_probe.so -nt tools/probe/energy_probe.hip ] || hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC tools/probe/energy_probe.hip -o tools/probe/libenergy_probe.so
 exec /usr/local/graft/bin/gpurun --timeout "$1" -- "$2"
