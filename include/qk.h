@@ -129,6 +129,7 @@ const char *qk_last_error(void);
 #define QK_DBG_WGRAD16_ONE_TAP 8u
 #define QK_DBG_NO_WGRAD_BAND 32u   /* 16-bit backward-weight: one block per tap (k_wgrad16) instead of the band kernel */
 #define QK_DBG_NO_POINT16 64u
+#define QK_DBG_CTC_TWO_SWEEPS 128u /* qk_ctc_batch_cost: the round-3 form (alpha then beta, gradient inside the backward sweep; env QK_CTC_TWO_SWEEPS) */
 #define QK_DBG_DETERMINISTIC 0x10000u /* bit-reproducible gradients (env QK_DETERMINISTIC): every backward-weight kernel runs
                                          * ONE split of the reduction per gradient tile and one owner per bias column, so
                                          * each element of dw / dbias receives exactly one (atomic) addition -- no
@@ -373,7 +374,7 @@ int qk_adam_step_zero_grad(float *param, float *grad, float *m, float *v, size_t
  * for it) gets cost = +inf and a ZERO gradient row; input_length == 0 gives cost 0 for an empty label sequence, +inf
  * otherwise; labels outside [0, classes - 2] are clamped (TensorFlow raises).
  * max_label_len <= 127, classes <= 256, frames up to ~15 000 (LDS); QK_ERR_UNSUPPORTED beyond.
- * Workspace: qk_ctc_workspace_bytes (the alpha lattice, frames x (2 max_label_len + 1) floats per sample). */
+ * Workspace: qk_ctc_workspace_bytes (the alpha and beta lattices, 2 x frames x (2 max_label_len + 1) floats per sample). */
 size_t qk_ctc_workspace_bytes(int32_t batch, int32_t frames, int32_t max_label_len);
 int qk_ctc_batch_cost(int32_t dtype, int32_t batch, int32_t frames, int32_t classes, const void *y_pred, const int32_t *labels,
                       int32_t max_label_len, const int32_t *input_length, const int32_t *label_length, float *cost, void *dy_pred,

@@ -18,6 +18,7 @@ QK_BWD_MASK_DX, QK_BWD_DY_PREMASKED, QK_BWD_ACCUMULATE = 1, 2, 4      # flags of
 QK_DBG_NO_MFMA16, QK_DBG_NO_BAND16, QK_DBG_NO_BAND32, QK_DBG_WGRAD16_ONE_TAP, QK_DBG_BAND16_8WAVES = 1, 2, 4, 8, 16   # qk_set_debug_flags
 QK_DBG_NO_WGRAD_BAND = 32
 QK_DBG_NO_POINT16 = 64
+QK_DBG_CTC_TWO_SWEEPS = 128
 QK_DBG_DETERMINISTIC = 0x10000
 QK_PATH_NAMES = {0: 'none', 1: 'mfma16', 2: 'mfma16_band', 3: 'fp32_mfma', 4: 'mfma16_point'}               # qk_last_path
 

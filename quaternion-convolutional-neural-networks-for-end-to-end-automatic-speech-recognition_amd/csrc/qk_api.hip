@@ -28,6 +28,7 @@ unsigned env_flags()
     if (getenv("QK_BAND16_8WAVES")) f |= kDbgBand8Waves;
     if (getenv("QK_NO_WGRAD_BAND")) f |= kDbgNoWgradBand;
     if (getenv("QK_NO_POINT16")) f |= kDbgNoPoint16;
+    if (getenv("QK_CTC_TWO_SWEEPS")) f |= kDbgCtcTwoSweeps;
     if (getenv("QK_DETERMINISTIC")) f |= kDbgDeterministic;
     if (const char *ab = getenv("QK_ABLATE")) f |= ((unsigned)atoi(ab) << kDbgAblateShift) & kDbgAblateMask;
     return f;

@@ -178,9 +178,137 @@ k_ctc(const T *__restrict__ pred, const int *__restrict__ labels, const int *__r
     (void)bprev;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 4: the fast form, taken whenever the sample's (T, C) table fits LDS twice (TIMIT: 2 x 50 KB).  k_ctc above walks the
+// lattice twice, one after the other (2 T dependent steps), and computes the gradient of a frame INSIDE the backward sweep
+// (62 exp / div, the stores and two barriers per frame): 233 us at B = 256, T = 200 -- 1200 cycles per dependent step.  Here
+//   * the alpha sweep (threads 0 .. 255) and the beta sweep (threads 256 .. 511) run CONCURRENTLY, frame i and frame
+//     Tn - 1 - i in the same step: T dependent steps, one barrier each, nothing but the recursion inside;
+//   * both lattices go to the workspace; the posterior occupancies of ALL frames are then formed in parallel (a wave takes
+//     64 consecutive states of one frame: blanks reduced in the wave, labels by LDS atomics into an occupancy table
+//     occ[t][c]) and the gradient table is written in one coalesced pass.
+// Same arithmetic, same results as k_ctc (tests/test_models.py pins both to the Keras restatement).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int CTCF_THREADS = 512;
+
+template <typename T>
+__global__ void __launch_bounds__(CTCF_THREADS)
+k_ctc_fast(const T *__restrict__ pred, const int *__restrict__ labels, const int *__restrict__ in_len, const int *__restrict__ lab_len,
+           float *__restrict__ cost, T *__restrict__ dpred, float *__restrict__ alpha_ws, float *__restrict__ beta_ws, const CtcGeom g)
+{
+    extern __shared__ float smem[];
+    // LDS: lse[T] | aa[2][Smax] | bb[2][Smax] | cls[Smax] (int) | 4 floats | lp[T][C] | occ[T][C]
+    float *lse = smem;
+    float *aa = lse + g.T;
+    float *bb = aa + 2 * g.Smax;
+    int *cls_l = reinterpret_cast<int *>(bb + 2 * g.Smax);
+    float *nll_s = reinterpret_cast<float *>(cls_l + g.Smax);
+    float *lpt = nll_s + 4;
+    float *occ = lpt + g.T * g.C;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int Tn = min(max(in_len[b], 0), g.T);
+    const int Ln = min(max(lab_len[b], 0), g.Lmax);
+    const int S = 2 * Ln + 1;
+    const int blank = g.C - 1;
+    const T *p = pred + (long long)b * g.T * g.C;
+    const bool beta_half = tid >= 256;
+    const int s = tid & 255;
+    const bool live = s < S;
+    const int lab_s = (live && (s & 1)) ? labels[b * g.Lmax + (s >> 1)] : 0;
+    const int cls = live ? ((s & 1) ? min(max(lab_s, 0), g.C - 1) : blank) : blank;
+    // alpha: s - 2 -> s allowed when state s is a label different from the previous label; beta looks the other way
+    const bool skip_bw = live && (s & 1) && s >= 3 && lab_s != labels[b * g.Lmax + (s >> 1) - 1];
+    const bool skip_fw = live && (s & 1) && s + 2 < S && lab_s != labels[b * g.Lmax + (s >> 1) + 1];
+    if (!beta_half && s < g.Smax) cls_l[s] = cls;
+
+    // ---- phase 0: u = log(p + eps), per-frame normaliser, lp = u - lse; occupancy table cleared ------------------------
+    for (int e = tid; e < Tn * g.C; e += CTCF_THREADS) { lpt[e] = __logf(to_f32(p[e]) + g.eps); occ[e] = 0.f; }
+    __syncthreads();
+    for (int t = tid; t < Tn; t += CTCF_THREADS) {
+        float m = kNegInf;
+        for (int c = 0; c < g.C; ++c) m = fmaxf(m, lpt[t * g.C + c]);
+        float sum = 0.f;
+        for (int c = 0; c < g.C; ++c) sum += __expf(lpt[t * g.C + c] - m);
+        lse[t] = m + __logf(sum);
+    }
+    __syncthreads();
+    for (int e = tid; e < Tn * g.C; e += CTCF_THREADS) lpt[e] -= lse[e / g.C];
+    if (Tn == 0) {             // no frames: the empty labelling has probability 1, any other is impossible
+        if (tid == 0) cost[b] = S > 1 ? INFINITY : 0.f;
+        if (dpred) for (int e = tid; e < g.T * g.C; e += CTCF_THREADS) dpred[(long long)b * g.T * g.C + e] = from_f32<T>(0.f);
+        return;
+    }
+    __syncthreads();
+
+    // ---- phase 1: both sweeps at once ------------------------------------------------------------------------------------
+    float *lat = (beta_half ? beta_ws : alpha_ws) + (long long)b * g.T * g.Smax;
+    float *buf = beta_half ? bb : aa;
+    for (int i = 0; i < Tn; ++i) {
+        const int t = beta_half ? Tn - 1 - i : i;
+        const float *prev = buf + ((i + 1) & 1) * g.Smax;
+        float v = kNegInf;
+        if (live) {
+            const float e = lpt[t * g.C + cls];
+            if (i == 0) {
+                const bool start = beta_half ? (s == S - 1 || s == S - 2) : s < 2;
+                v = start ? e : kNegInf;
+            } else if (beta_half) {
+                const float a = lse3(prev[s], s + 1 < S ? prev[s + 1] : kNegInf, skip_fw ? prev[s + 2] : kNegInf);
+                v = a <= -1e29f ? kNegInf : a + e;
+            } else {
+                const float a = lse3(prev[s], s >= 1 ? prev[s - 1] : kNegInf, skip_bw ? prev[s - 2] : kNegInf);
+                v = a <= -1e29f ? kNegInf : a + e;
+            }
+            buf[(i & 1) * g.Smax + s] = v;
+            lat[(long long)t * g.Smax + s] = v;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const float *al = aa + ((Tn - 1) & 1) * g.Smax;
+        const float ll = lse2(al[S - 1], S >= 2 ? al[S - 2] : kNegInf);
+        nll_s[0] = -ll;
+        cost[b] = ll <= -1e29f ? INFINITY : -ll;
+    }
+    __syncthreads();
+    if (!dpred) return;
+    const float nll = nll_s[0];
+    T *dp = dpred + (long long)b * g.T * g.C;
+    for (int e = Tn * g.C + tid; e < g.T * g.C; e += CTCF_THREADS) dp[e] = from_f32<T>(0.f);       // frames past the input length
+    if (nll >= 1e29f) {        // no alignment fits: +inf cost, no gradient (see k_ctc)
+        for (int e = tid; e < Tn * g.C; e += CTCF_THREADS) dp[e] = from_f32<T>(0.f);
+        return;
+    }
+
+    // ---- phase 2: occupancies of every (frame, state) in parallel, then the gradient table -----------------------------------
+    const float *al = alpha_ws + (long long)b * g.T * g.Smax, *be = beta_ws + (long long)b * g.T * g.Smax;
+    const int Sp = (S + 63) & ~63;                   // a wave = 64 consecutive states of ONE frame
+    for (int idx = tid; idx < Tn * Sp; idx += CTCF_THREADS) {
+        const int t = idx / Sp, st = idx - t * Sp;
+        float q = 0.f;
+        int c = blank;
+        if (st < S) {
+            c = cls_l[st];
+            const float a = al[(long long)t * g.Smax + st], bt = be[(long long)t * g.Smax + st];
+            if (a > -1e29f && bt > -1e29f) q = __expf(a + bt - lpt[t * g.C + c] + nll);       // both hold frame t's emission
+        }
+        float qb = (st & 1) ? 0.f : q;               // blanks: half of the states, one class -- reduce inside the wave
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) qb += __shfl_xor(qb, o);
+        if (lane == 0 && qb != 0.f) atomicAdd(&occ[t * g.C + blank], qb);
+        if ((st & 1) && q != 0.f) atomicAdd(&occ[t * g.C + c], q);
+    }
+    __syncthreads();
+    for (int e = tid; e < Tn * g.C; e += CTCF_THREADS) {
+        const float l = lpt[e];
+        const float soft = __expf(l), pc = __expf(l + lse[e / g.C]);
+        dp[e] = from_f32<T>((soft - occ[e]) / pc);
+    }
+}
+
 }  // namespace
 
-size_t ctc_workspace_bytes(int B, int T, int Lmax) { return (size_t)B * T * (2 * Lmax + 1) * sizeof(float); }
+size_t ctc_workspace_bytes(int B, int T, int Lmax) { return 2 * (size_t)B * T * (2 * Lmax + 1) * sizeof(float); }   // alpha and beta lattices
 
 int launch_ctc(int dtype, int B, int T, int C, const void *pred, const int *labels, int Lmax, const int *in_len, const int *lab_len,
                float *cost, void *dpred, float *ws, hipStream_t stream)
@@ -190,6 +318,23 @@ int launch_ctc(int dtype, int B, int T, int C, const void *pred, const int *labe
     const size_t base = (size_t)(T + 2 * g.Smax + C + 4) * sizeof(float);
     const size_t full = base + (size_t)T * C * sizeof(float);
     if (g.Smax > CTC_THREADS || C > CTC_THREADS || base > 64 * 1024) return QK_ERR_UNSUPPORTED;
+    // fast form: both tables (log-probabilities, occupancies) of the sample in LDS
+    const size_t fast_lds = (size_t)(T + 5 * g.Smax + 4 + 2 * (size_t)T * C) * sizeof(float);
+    if (fast_lds <= 150 * 1024 && !(debug_flags() & kDbgCtcTwoSweeps)) {
+        float *beta_ws = ws + (size_t)B * T * g.Smax;
+        dim3 grid((unsigned)B), block(CTCF_THREADS);
+        // (more than 64 KB of dynamic LDS must be asked for explicitly; idempotent, a few hundred ns)
+#define QK_CTCF(TT) do { if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ctc_fast<TT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast_lds) != hipSuccess) return QK_ERR_LAUNCH; \
+        hipLaunchKernelGGL((k_ctc_fast<TT>), grid, block, fast_lds, stream, (const TT *)pred, labels, in_len, lab_len, cost, (TT *)dpred, ws, beta_ws, g); } while (0)
+        switch (dtype) {
+        case QK_F32: QK_CTCF(float); break;
+        case QK_BF16: QK_CTCF(bf16); break;
+        case QK_F16: QK_CTCF(f16); break;
+        default: return QK_ERR_INVALID_ARG;
+        }
+#undef QK_CTCF
+        return hipGetLastError() == hipSuccess ? 0 : QK_ERR_LAUNCH;
+    }
     const bool lps = full <= 64 * 1024;
     const size_t lds = lps ? full : base;
     dim3 grid((unsigned)B), block(CTC_THREADS);

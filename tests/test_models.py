@@ -392,22 +392,28 @@ def test_fused_ctc_batch_cost_matches_the_keras_restatement(shape, dtype):
     ll[1, 0] = 0 if b > 1 else ll[0, 0]                                # an empty label sequence
     il = torch.randint(max(2 * lmax + 2, t // 2), t + 1, (b, 1), generator=g).clamp(max=t)
     w = torch.rand(b, 1, generator=g).to(dev) + 0.5                    # upstream gradient of the cost
+    from qcnn_amd import _lib
     outs = {}
-    for fused in (True, False):
+    for fused in (True, 'two_sweeps', False):
         if not fused:
             os.environ['QK_NO_FUSED_CTC'] = '1'
         try:
-            p = pred.clone().requires_grad_(True)
-            cost = ctc_batch_cost(p, labels.to(dev), il, ll)
-            (cost * w).sum().backward()
+            with _lib.debug_flags(_lib.QK_DBG_CTC_TWO_SWEEPS if fused == 'two_sweeps' else 0):
+                p = pred.clone().requires_grad_(True)
+                cost = ctc_batch_cost(p, labels.to(dev), il, ll)
+                (cost * w).sum().backward()
+                torch.cuda.synchronize()
             outs[fused] = (cost.detach().double().cpu(), p.grad.detach().double().cpu())
         finally:
             os.environ.pop('QK_NO_FUSED_CTC', None)
-    (cf, gf), (ct, gt) = outs[True], outs[False]
-    assert tuple(cf.shape) == (b, 1) and torch.isfinite(cf).all()
-    assert float((cf - ct).abs().max() / ct.abs().max()) <= (1e-5 if dtype == torch.float32 else 1e-5)     # same 16-bit inputs, fp32 math
-    tol = 2e-4 if dtype == torch.float32 else 1e-2                                                          # bf16: the gradient is stored in bf16
-    assert float((gf - gt).abs().max() / gt.abs().max()) <= tol
+    (ct, gt) = outs[False]
+    for form in (True, 'two_sweeps'):       # the concurrent-sweep kernel (round 4; long utterances fall back) and the round-3 form
+        cf, gf = outs[form]
+        assert tuple(cf.shape) == (b, 1) and torch.isfinite(cf).all()
+        assert float((cf - ct).abs().max() / ct.abs().max()) <= 1e-5, form              # same 16-bit inputs, fp32 math
+        tol = 2e-4 if dtype == torch.float32 else 1e-2                                    # bf16: the gradient is stored in bf16
+        assert float((gf - gt).abs().max() / gt.abs().max()) <= tol, form
+    gf = outs[True][1]
     for i in range(b):                                                 # frames past the input length get no gradient
         assert float(gf[i, int(il[i]):].abs().sum()) == 0.0
 
