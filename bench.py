@@ -512,7 +512,7 @@ def in_step_kernel_times(job, dev, peak, steps=3):
 class GpuTelemetry(object):
     """Socket power and shader clock of the card this rank computes on, sampled from the amdgpu hwmon / sysfs files every 10 ms
     while the timed region runs (a thread: the GPU work is asynchronous anyway).  The body kernels sit at the socket's power
-    cap and run at whatever clock that allows (DESIGN.md 3.6c), so the box-to-box spread of ms_per_step is a spread of
+    cap and run at whatever clock that allows (DESIGN.md 3.10-3.11), so the box-to-box spread of ms_per_step is a spread of
     sustained clocks: the line carries the evidence.  Silent when the files are not there."""
 
     def __init__(self, dev):

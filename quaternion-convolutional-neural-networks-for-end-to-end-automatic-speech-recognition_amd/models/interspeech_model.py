@@ -238,7 +238,7 @@ class TimitQCNN(torch.nn.Module):
     def _convs_as_chain(self, o):
         """The n body convolutions (interspeech_model.py:105-137 with no advanced activation and no active
         dropout) through functional.quaternion_conv_chain: same values and gradients as calling the layers
-        one by one, but each relu derivative is applied where it is cheapest (DESIGN.md section 3.6b).
+        one by one, but each relu derivative is applied where it is cheapest (DESIGN.md section 3.6.1).
         With fuse_head the first TimeDistributed dense layer (as an (F, 1) convolution) is the last link
         of the chain, so the last body convolution's relu derivative also moves into a backward-data
         epilogue.  Returns (tensor, head_included)."""

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Power / shader-clock trace of ONE hot kernel on different operand VALUES (DESIGN.md 3.6: "these kernels are
+"""Power / shader-clock trace of ONE hot kernel on different operand VALUES (DESIGN.md 3.10-3.11: "these kernels are
 power-bound").  The 64 -> 64 forward band kernel (716 800 x 256 x 3840, bf16) is launched back to back for a few
 seconds per data set -- all zeros, relu(normal) (half zeros), relu + dropout 0.3 (65 % zeros: what the headline step
 feeds it), dense normal -- while a sampler thread reads the GPU's socket power and shader clock (amdgpu hwmon / sysfs;

@@ -1,6 +1,6 @@
 // Energy-apportioning probe (diagnostic, not product code): where do the watts of the band kernels go?
 //
-// The body kernels sit at the 1.4 kW socket cap and run at whatever clock that allows (DESIGN.md 3.6c), so what bounds
+// The body kernels sit at the 1.4 kW socket cap and run at whatever clock that allows (DESIGN.md 3.10-3.11), so what bounds
 // them is ENERGY PER FLOP.  This probe runs the inner loop of k_hgemm16_band (qk_hgemm_bf16mfma.hip) in isolation, in
 // variants that add one energy consumer at a time, on zero and on random operands:
 //   kind 0  MFMA only: 7 accumulator tiles per 32-row block, operands fixed in registers          (the power-limited MFMA roof)

@@ -52,7 +52,7 @@ if has 8; then
 python bench.py --loss sum --no-extras --no-standalone --no-cpu-baseline > $O/r04_bench_sumloss_builder_run.json 2>/dev/null
 python bench.py --workload cfg5_stack_b32_fp16 --no-cpu-baseline > $O/r04_bench_cfg5_stack_builder_run.json 2>/dev/null
 for lay in channels_last native; do python bench.py --workload cfg3_body_qconv2d_b256_bf16 --layout $lay --no-cpu-baseline > $O/r04_bench_cfg3body_${lay}_builder_run.json 2>/dev/null; done
-QK_DP_FORCE_COLLECTIVES=1 python bench.py --gpus 1 --steps 30 --warmup 5 --no-cpu-baseline --no-kernel-timing > $O/r04_bench_one_rank_rccl_builder_run.json 2>/dev/null
+QK_DP_FORCE_COLLECTIVES=1 python bench.py --gpus 1 --steps 30 --warmup 5 --no-cpu-baseline --no-kernel-timing 2>/dev/null | grep "^{" > $O/r04_bench_one_rank_rccl_builder_run.json
 cat $O/bench_default.time
 fi
 ls -la $O
