@@ -137,6 +137,9 @@ const char *qk_last_error(void);
                                          * no longer spread over the CUs): for debugging and for repeatability tests. */
 #define QK_DBG_BAND16_8WAVES 16u   /* 16-bit band kernels: 8-wave workgroups (one per CU) instead of 4-wave (two per CU) */
 unsigned qk_set_debug_flags(unsigned flags);
+/* Profiling only: a device buffer (32 bytes per workgroup) into which the 16-bit band kernels drop shader-clock time stamps of their
+ * phases (start, prologue done, K loop done, end); NULL switches it off. */
+void qk_set_debug_buffer(void *device_buffer, size_t bytes);
 unsigned qk_get_debug_flags(void);
 
 /* Which kernel family served the most recent qk_* compute call of the calling thread (thread-local, like

@@ -72,6 +72,7 @@ SYMBOLS = {
     'qk_last_error': (ctypes.c_char_p, []),
     'qk_set_debug_flags': (ctypes.c_uint, [ctypes.c_uint]),
     'qk_get_debug_flags': (ctypes.c_uint, []),
+    'qk_set_debug_buffer': (None, [_VP, _SZ]),
     'qk_last_path': (ctypes.c_int, []),
     'qk_conv_workspace_bytes': (_SZ, [_CD, ctypes.c_int]),
     'qk_dense_workspace_bytes': (_SZ, [_DD, ctypes.c_int]),

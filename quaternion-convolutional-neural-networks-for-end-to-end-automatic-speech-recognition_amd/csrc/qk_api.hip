@@ -51,6 +51,9 @@ const ForceCfg &force_cfg()
 }  // namespace
 
 unsigned debug_flags() { return dbg_word().load(std::memory_order_relaxed); }
+static std::atomic<unsigned long long *> g_dbg_buf{nullptr};
+static std::atomic<size_t> g_dbg_bytes{0};
+unsigned long long *debug_buffer(size_t *bytes) { if (bytes) *bytes = g_dbg_bytes.load(); return g_dbg_buf.load(); }
 
 // ---- per-call timing (qk_prof_*, include/qk.h) ------------------------------------------------------------------
 // Off: one relaxed atomic load per compute call.  On: a pair of HIP events around the call's launches ON THE CALLER'S
@@ -603,6 +606,7 @@ int qk_version(void) { return QK_VERSION; }
 const char *qk_last_error(void) { return g_err; }
 
 unsigned qk_set_debug_flags(unsigned flags) { return dbg_word().exchange(flags, std::memory_order_relaxed); }
+void qk_set_debug_buffer(void *device_buffer, size_t bytes) { g_dbg_buf.store(static_cast<unsigned long long *>(device_buffer)); g_dbg_bytes.store(bytes); }
 unsigned qk_get_debug_flags(void) { return debug_flags(); }
 int qk_last_path(void) { return g_path; }
 

@@ -62,6 +62,7 @@ struct GemmGeom {
     int has_bias;
     int has_mask;       // gathered value is zeroed where mask[same index] <= 0 (relu backward)
     int ablate;         // profiling only (env QK_ABLATE): 4 = skip the MFMA loop, 8 = skip the epilogue
+    unsigned long long *dbg_ts;          // profiling only (qk_set_debug_buffer): per-workgroup phase time stamps of the band kernel
     int w_swapped;      // Wk is the compact kernel itself, read with q/j swapped (backward-data): no transposed copy
     int w_prepped;      // 16-bit path: the workspace already holds the re-laid-out kernel (qk_conv_desc_t.ws_has_kernel)
     // band variant of the 16-bit kernel (qk_hgemm_bf16mfma.hip): rows of M run over PADDED lines of the
@@ -264,6 +265,7 @@ enum : unsigned {
     kDbgNoPoint16 = QK_DBG_NO_POINT16, kDbgCtcTwoSweeps = QK_DBG_CTC_TWO_SWEEPS, kDbgDeterministic = QK_DBG_DETERMINISTIC, kDbgAblateShift = 8, kDbgAblateMask = 0xffu << 8
 };
 unsigned debug_flags();
+unsigned long long *debug_buffer(size_t *bytes);      // qk_set_debug_buffer (qk_api.hip)
 inline int debug_ablate() { return (int)((debug_flags() & kDbgAblateMask) >> kDbgAblateShift); }
 // QK_FORCE_CFG (fp32 tiling sweep, tools/gpu_cfgsweep.sh): parsed once; false when unset
 bool debug_force_cfg(int *policy, int *bq);

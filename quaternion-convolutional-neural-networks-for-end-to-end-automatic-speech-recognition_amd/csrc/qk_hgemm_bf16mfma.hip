@@ -582,6 +582,13 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
     const int p0 = mtile * BMU;
     const int j0 = blockIdx.y * BF;
     const int nkc = g.Q / 32;
+#ifdef QK_PHASE_STAMPS       // probe builds only (tools/probe/phase_stamps.py): the stamps cost two registers, i.e. spills in the 64-row kernels
+    unsigned long long *ts = (g.dbg_ts && blockIdx.x < 65536 && blockIdx.y == 0 && tid == 0) ? g.dbg_ts + 4 * blockIdx.x : nullptr;
+#define QK_STAMP(i) do { if (ts) ts[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define QK_STAMP(i) do { } while (0)
+#endif
+    QK_STAMP(0);
 
     // ---- band rows of this thread (decoded once) ------------------------------------------------
     // register staging: 8 threads per row, NTHR / 8 rows per pass
@@ -716,6 +723,11 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
     a_prep();
 #pragma unroll
     for (int r = 0; r < RPT3; ++r) load_a(r);
+    // this thread's bias value for the epilogue's LDS table, fetched NOW instead of behind the K loop (one L2 round trip off the
+    // epilogue; measured worth 0 - 3 %: the forward epilogue's 7 k cycles against backward-data's 3.6 k -- phase stamps,
+    // tools/probe/phase_stamps.py -- are the bias table's barrier, LDS reads and adds themselves, not the load)
+    float bias_pre = 0.f;
+    if (g.has_bias && tid < 4 * BF) bias_pre = bias[(tid / BF) * g.J + j0 + tid % BF];
     b_prep();
 #pragma unroll
     for (int k = 0; k < BU; ++k) load_b1(k);
@@ -731,6 +743,7 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
     b_advance_if_more();
     __syncthreads();
 
+    QK_STAMP(1);
     static_assert(band_op(RPT3, KIN, 0, 0) != -2, "no staging schedule for this (row passes, inner taps)");
     static_assert(kBandOpsMax + 2 * BU <= 16, "one staging slot after every second MFMA");
 
@@ -791,6 +804,7 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
     // v_permlane32_swap per packed dword pairs the lh halves: lanes 0..31 end up with channels 16q .. 16q+7, lanes
     // 32..63 with 16q+8 .. 16q+15 of their row -- two 16-byte stores per component and no trip through LDS (the
     // per-wave transpose patches were 8 - 18 % of these kernels by ablation).
+    QK_STAMP(2);
     if ((g.ablate & 8) && acc[0][0] != 123.456f) return;              // (ablate 8: profiling, no epilogue)
     const bool post_on = (EPM || POSTF) && g.post.kind != 0;
     const int tr = wm * 32 + lr;                                     // row inside the tile
@@ -814,7 +828,7 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
     float *bias_s = reinterpret_cast<float *>(reinterpret_cast<char *>(lds) + 34816);  // this tile's 4 x BF bias values
     if ((EPM || POSTF) && post_on && g.post.alpha) a_val = g.post.alpha[a_key];
     // (the K loop's last barrier is behind every wave: the tile buffers are free)
-    if (g.has_bias && tid < 4 * BF) bias_s[tid] = bias[(tid / BF) * g.J + j0 + tid % BF];
+    if (g.has_bias && tid < 4 * BF) bias_s[tid] = bias_pre;          // (fetched in the prologue: the load's latency is long gone)
     if (EPM && post_on && g.dalpha && tid < 256) aslab[tid] = 0.f;
     if (g.has_bias || (EPM && post_on && g.dalpha)) __syncthreads();
     uint4 em[EPM ? 4 : 1][2];
@@ -876,6 +890,11 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
             if (tid < g.post.alpha_len && aslab[tid] != 0.f) atomicAdd(g.dalpha + tid, aslab[tid]);
         }
     }
+#ifdef QK_PHASE_STAMPS
+    __builtin_amdgcn_s_waitcnt(0);
+#endif
+    QK_STAMP(3);
+#undef QK_STAMP
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1157,6 +1176,7 @@ int go16(const void *in, const void *mask, const float *w, const float *bias, vo
 {
     GemmGeom g = g_in;
     g.ablate = debug_ablate();
+    { size_t nb = 0; g.dbg_ts = debug_buffer(&nb); if (nb < 32u * 65536u) g.dbg_ts = nullptr; }     // (room for 65536 workgroups)
     // One sign table for every 16-bit kernel: the plain table is the conjugate one applied to the conjugated kernel
     // quaternion (S_conv[a][b] = S_conj[a][b] * s[a ^ b] with s = (+, -, -, -)), so the i, j, k components are negated
     // while the kernel is re-laid out (exact in bf16 / fp16) and only the CONJ instantiations exist -- the conjugate
