@@ -137,8 +137,8 @@ const char *qk_last_error(void);
                                          * no longer spread over the CUs): for debugging and for repeatability tests. */
 #define QK_DBG_BAND16_8WAVES 16u   /* 16-bit band kernels: 8-wave workgroups (one per CU) instead of 4-wave (two per CU) */
 unsigned qk_set_debug_flags(unsigned flags);
-/* Profiling only: a device buffer (32 bytes per workgroup) into which the 16-bit band kernels drop shader-clock time stamps of their
- * phases (start, prologue done, K loop done, end); NULL switches it off. */
+/* Profiling only: a device buffer (64 bytes per workgroup, 65536 workgroups) into which the 16-bit band kernels drop shader-clock time stamps of their
+ * phases (start, prologue done, K loop done, end) and the CU they ran on -- probe builds only (tools/probe/build_variant.sh); NULL switches it off. */
 void qk_set_debug_buffer(void *device_buffer, size_t bytes);
 unsigned qk_get_debug_flags(void);
 

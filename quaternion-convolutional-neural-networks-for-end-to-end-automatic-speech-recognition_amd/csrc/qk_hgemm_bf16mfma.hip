@@ -583,7 +583,8 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
     const int j0 = blockIdx.y * BF;
     const int nkc = g.Q / 32;
 #ifdef QK_PHASE_STAMPS       // probe builds only (tools/probe/phase_stamps.py): the stamps cost two registers, i.e. spills in the 64-row kernels
-    unsigned long long *ts = (g.dbg_ts && blockIdx.x < 65536 && blockIdx.y == 0 && tid == 0) ? g.dbg_ts + 4 * blockIdx.x : nullptr;
+    unsigned long long *ts = (g.dbg_ts && blockIdx.x < 65536 && blockIdx.y == 0 && tid == 0) ? g.dbg_ts + 8 * blockIdx.x : nullptr;
+    if (ts) ts[4] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | (unsigned)__builtin_amdgcn_s_getreg(63492);   // XCC_ID | HW_ID
 #define QK_STAMP(i) do { if (ts) ts[i] = __builtin_readcyclecounter(); } while (0)
 #else
 #define QK_STAMP(i) do { } while (0)
@@ -710,6 +711,10 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
         uint4 *Bs = lds + 2 * A_U + buf * B_U;
         Bs[tid + k * NTHR] = k == 0 ? br0 : k == 1 ? br1 : k == 2 ? br2 : br3;
     };
+    // The accumulators START at the bias (round 4): a lane's register r of component b holds channel (r & 3) + 8 (r >> 2) + 4 lh of
+    // the wave's 32-channel block, i.e. four float4 pieces of the bias vector per component -- 16 L2-resident loads issued at the
+    // end of the prologue (below), in flight across its barrier.  Added in the epilogue instead (LDS table + barrier + 16 ds_read_b128 + 64 adds) the
+    // bias was HALF of the forward epilogue: 7.0 k cycles against backward-data's 3.6 k (tools/probe/phase_stamps.py).
     floatx16 acc[4], accn[4];
 #pragma unroll
     for (int b = 0; b < 4; ++b)
@@ -723,11 +728,6 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
     a_prep();
 #pragma unroll
     for (int r = 0; r < RPT3; ++r) load_a(r);
-    // this thread's bias value for the epilogue's LDS table, fetched NOW instead of behind the K loop (one L2 round trip off the
-    // epilogue; measured worth 0 - 3 %: the forward epilogue's 7 k cycles against backward-data's 3.6 k -- phase stamps,
-    // tools/probe/phase_stamps.py -- are the bias table's barrier, LDS reads and adds themselves, not the load)
-    float bias_pre = 0.f;
-    if (g.has_bias && tid < 4 * BF) bias_pre = bias[(tid / BF) * g.J + j0 + tid % BF];
     b_prep();
 #pragma unroll
     for (int k = 0; k < BU; ++k) load_b1(k);
@@ -741,6 +741,17 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
 #pragma unroll
     for (int k = 0; k < BU; ++k) load_b1(k);
     b_advance_if_more();
+    // (the bias loads go out LAST: issued in front of the band fetch they held up its LDS stores -- prologue +1.4 k cycles)
+    if (g.has_bias) {
+        const float *bp = bias + j0 + wn * 32 + 4 * (lane >> 5);
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const float4 bb = *reinterpret_cast<const float4 *>(bp + b * g.J + 8 * gq);
+                acc[b][4 * gq] = bb.x; acc[b][4 * gq + 1] = bb.y; acc[b][4 * gq + 2] = bb.z; acc[b][4 * gq + 3] = bb.w;
+            }
+    }
     __syncthreads();
 
     QK_STAMP(1);
@@ -825,12 +836,10 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
     }
     float a_val = 0.f, dal = 0.f;
     float *aslab = reinterpret_cast<float *>(reinterpret_cast<char *>(lds) + 32768);   // 256 d-alpha sums (backward post-op)
-    float *bias_s = reinterpret_cast<float *>(reinterpret_cast<char *>(lds) + 34816);  // this tile's 4 x BF bias values
     if ((EPM || POSTF) && post_on && g.post.alpha) a_val = g.post.alpha[a_key];
     // (the K loop's last barrier is behind every wave: the tile buffers are free)
-    if (g.has_bias && tid < 4 * BF) bias_s[tid] = bias_pre;          // (fetched in the prologue: the load's latency is long gone)
     if (EPM && post_on && g.dalpha && tid < 256) aslab[tid] = 0.f;
-    if (g.has_bias || (EPM && post_on && g.dalpha)) __syncthreads();
+    if (EPM && post_on && g.dalpha) __syncthreads();
     uint4 em[EPM ? 4 : 1][2];
     if (EPM && g.ep_mask) {
 #pragma unroll
@@ -840,7 +849,6 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
                 em[b][q] = o_ok ? *reinterpret_cast<const uint4 *>(static_cast<const T *>(g.ep_mask) + o_row + b * g.J + q * 16)
                                 : make_uint4(0u, 0u, 0u, 0u);
     }
-    const float4 *bias_rd = reinterpret_cast<const float4 *>(bias_s) + wn * 8 + lh;
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
         unsigned pk[4][2];
@@ -848,11 +856,7 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
         for (int gq = 0; gq < 4; ++gq) {
             float v[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = acc[b][4 * gq + e] - accn[b][4 * gq + e];
-            if (g.has_bias) {
-                const float4 bb = bias_rd[b * (BF / 4) + 2 * gq];
-                v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
-            }
+            for (int e = 0; e < 4; ++e) v[e] = acc[b][4 * gq + e] - accn[b][4 * gq + e];       // (the bias went in with the first MFMA)
             if (g.relu) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
@@ -1176,7 +1180,7 @@ int go16(const void *in, const void *mask, const float *w, const float *bias, vo
 {
     GemmGeom g = g_in;
     g.ablate = debug_ablate();
-    { size_t nb = 0; g.dbg_ts = debug_buffer(&nb); if (nb < 32u * 65536u) g.dbg_ts = nullptr; }     // (room for 65536 workgroups)
+    { size_t nb = 0; g.dbg_ts = debug_buffer(&nb); if (nb < 64u * 65536u) g.dbg_ts = nullptr; }     // (room for 65536 workgroups x 8 words)
     // One sign table for every 16-bit kernel: the plain table is the conjugate one applied to the conjugated kernel
     // quaternion (S_conv[a][b] = S_conj[a][b] * s[a ^ b] with s = (+, -, -, -)), so the i, j, k components are negated
     // while the kernel is re-laid out (exact in bf16 / fp16) and only the CONJ instantiations exist -- the conjugate

@@ -18,14 +18,15 @@ from ab_layers import SHAPES
 dev = torch.device('cuda:0')
 dt = torch.bfloat16
 g = torch.Generator(device=dev).manual_seed(0)
-buf = torch.zeros(4 * 65536, dtype=torch.int64, device=dev)
+buf = torch.zeros(8 * 65536, dtype=torch.int64, device=dev)
 for n in (sys.argv[1:] or ['c64', 'c32', 'c32to64']):
     s = SHAPES[n]
     keep = (torch.rand(s['x'], device=dev, generator=g) >= 0.3)
     x = (torch.relu(torch.randn(s['x'], device=dev, generator=g)) * keep).to(dt)           # relu + dropout: what the step feeds the kernels
     w = torch.randn(s['w'], device=dev, generator=g) / 30
-    b = torch.zeros(s['w'][-1], device=dev)
-    call = F.conv_call(tuple(s['x']), tuple(s['w']), dt, 2, 1, s['pad'], 'channels_last', 1, 'linear', True, s['conj'])
+    nobias = bool(os.environ.get('STAMPS_NO_BIAS'))
+    b = None if nobias else torch.zeros(s['w'][-1], device=dev)
+    call = F.conv_call(tuple(s['x']), tuple(s['w']), dt, 2, 1, s['pad'], 'channels_last', 1, 'linear', not nobias, s['conj'])
     call.static_buffers = True
     y = call.fwd(x, w, b)
     dy = (torch.randn(y.shape, device=dev, generator=g) * (torch.rand(y.shape, device=dev, generator=g) >= 0.65)).to(dt)
@@ -39,12 +40,29 @@ for n in (sys.argv[1:] or ['c64', 'c32', 'c32to64']):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); fn(); e1.record(); e1.synchronize()
         _lib.lib().qk_set_debug_buffer(None, 0)
-        t = buf.view(-1, 4).cpu()
+        t = buf.view(-1, 8).cpu()
         t = t[t[:, 3] > 0]
         pro, loop, epi = (t[:, 1] - t[:, 0]).float(), (t[:, 2] - t[:, 1]).float(), (t[:, 3] - t[:, 2]).float()
         span = int(t[:, 3].max() - t[:, 0].min())
         taps, cq, f4 = s['w'][0] * s['w'][1], s['w'][2], s['w'][3]
         mfma_per_wave = taps * (cq // 32) * 2 * 16            # per tile: sub-steps x 2 ks x 16 MFMAs (a wave tile is 32 rows x 128 columns)
+        # residency per CU: how long 2 / 1 / 0 workgroups were resident, and were in their K loop (sweep over the stamps of each CU)
+        hw = t[:, 4]
+        cu = ((hw >> 32) & 0xf) * 4096 + ((hw >> 13) & 7) * 512 + ((hw >> 12) & 1) * 256 + ((hw >> 8) & 0xf)      # xcc | se | sh | cu
+        res, inloop, tot = [0.0, 0.0, 0.0], [0.0, 0.0, 0.0], 0.0
+        for c in cu.unique().tolist():
+            q = t[cu == c]
+            ev = sorted([(int(a), 0, +1) for a in q[:, 0]] + [(int(a), 0, -1) for a in q[:, 3]] + [(int(a), 1, +1) for a in q[:, 1]] + [(int(a), 1, -1) for a in q[:, 2]])
+            nn = [0, 0]
+            last = ev[0][0]
+            for when, kind, d in ev:
+                res[min(nn[0], 2)] += when - last
+                inloop[min(nn[1], 2)] += when - last
+                last = when
+                nn[kind] += d
+            tot += ev[-1][0] - ev[0][0]
+        print('         CUs %d  resident workgroups 2/1/0: %.1f / %.1f / %.1f %%   in K loop 2/1/0: %.1f / %.1f / %.1f %%' % (
+            len(cu.unique()), 100 * res[2] / tot, 100 * res[1] / tot, 100 * res[0] / tot, 100 * inloop[2] / tot, 100 * inloop[1] / tot, 100 * inloop[0] / tot))
         print('%-8s %-9s workgroups %5d  us %7.1f  span %8d cyc (%.2f GHz)   prologue %6.0f   K loop %6.0f (ideal 2 waves/SIMD: %6d = %.0f %%)   epilogue %6.0f   sum %6.0f' % (
             n, name, len(t), 1e3 * e0.elapsed_time(e1), span, span / (1e3 * e0.elapsed_time(e1)) / 1e3, float(pro.mean()), float(loop.mean()),
             mfma_per_wave * 64, 100.0 * mfma_per_wave * 64 / float(loop.mean()), float(epi.mean()), float((pro + loop + epi).mean())))
