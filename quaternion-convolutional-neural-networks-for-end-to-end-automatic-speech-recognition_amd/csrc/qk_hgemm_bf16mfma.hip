@@ -598,8 +598,30 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
     const int s_row = tid >> 3, s8 = tid & 7;
     int base_off[RPT3];
     unsigned omask[RPT3];                           // bit (t0 * ks1 + t1): outer tap inside the tensor
-#pragma unroll
-    for (int r = 0; r < RPT3; ++r) {
+    // Outer taps no row of this band can use are skipped altogether (see k_hgemm16): border image rows.  Round 4: the set is
+    // computed from the tile's GEOMETRY -- the padded lines it touches, wave-uniform scalar code -- instead of OR-ing the rows'
+    // masks through LDS behind a barrier: the first band's loads no longer wait for every row to be decoded (they are issued
+    // pass by pass, right behind each pass's decode, below).  A line whose positions inside the tile are all padding columns may
+    // add a tap nobody uses: its loads read zeros, nothing else changes.
+    unsigned tile_ot = 0;
+    {
+        const int last_p = min(p0 + BAND - 1, total_p - 1);
+        const int line_lo = fastdiv(p0, g.dv_mul[0], g.dv_shr[0]);
+        const int line_hi = min(fastdiv(last_p, g.dv_mul[0], g.dv_shr[0]), g.b_nlines - 1);
+        for (int line = line_lo; line <= line_hi; ++line) {
+            const int l2 = fastdiv(line, g.dv_mul[1], g.dv_shr[1]), o1 = line - l2 * g.osp[1];
+            const int n = fastdiv(l2, g.dv_mul[2], g.dv_shr[2]), o0 = l2 - n * g.osp[0];
+            const int q0 = o0 * g.pa[0] + g.pc[0], q1 = o1 * g.pa[1] + g.pc[1];
+            int t = 0;
+            for (int t0 = 0; t0 < g.ks[0]; ++t0)
+                for (int t1 = 0; t1 < g.ks[1]; ++t1, ++t) {
+                    const int i0 = q0 + t0 * g.pb[0], i1 = q1 + t1 * g.pb[1];
+                    if (i0 >= 0 && i0 < g.isp[0] && i1 >= 0 && i1 < g.isp[1]) tile_ot |= 1u << t;
+                }
+        }
+        tile_ot = __builtin_amdgcn_readfirstlane(tile_ot);
+    }
+    auto decode_row = [&](int r) {
         const int j = s_row + r * RPP;
         base_off[r] = 0; omask[r] = 0;
         const int P = p0 + j;
@@ -618,16 +640,7 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
                     omask[r] |= (ok ? 1u : 0u) << t;
                 }
         }
-    }
-    // outer taps no row of this band can use are skipped altogether (see k_hgemm16): border image rows.
-    // (The per-wave words live at the start of B buffer 1, which is first written inside the K loop.)
-    unsigned tile_ot;
-    {
-        unsigned mine = 0;
-#pragma unroll
-        for (int r = 0; r < RPT3; ++r) mine |= omask[r];
-        tile_ot = wg_or_mask<NW>(mine, g.ks[0] * g.ks[1], reinterpret_cast<unsigned *>(lds + 2 * A_U + B_U), wave, lane);
-    }
+    };
     const int groups = __builtin_popcount(tile_ot) * nkc;
     const int substeps = groups * KIN;
     const int cmp_lo = s8 >> 2, sub = (s8 & 3) * 8;
@@ -725,12 +738,12 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
     const int b_rd0 = 2 * A_U + wn * 32 + lr;
 
     // ---- prologue: band 0, B tile 0 in LDS; B tile 1 in registers ---------------------------------
-    a_prep();
-#pragma unroll
-    for (int r = 0; r < RPT3; ++r) load_a(r);
-    b_prep();
+    b_prep();                                        // (the B tile needs no row decode: its loads lead)
 #pragma unroll
     for (int k = 0; k < BU; ++k) load_b1(k);
+    a_prep();
+#pragma unroll
+    for (int r = 0; r < RPT3; ++r) { decode_row(r); load_a(r); }
 #pragma unroll
     for (int r = 0; r < RPT3; ++r) store_a(r, 0);
     a_advance_if_more();
