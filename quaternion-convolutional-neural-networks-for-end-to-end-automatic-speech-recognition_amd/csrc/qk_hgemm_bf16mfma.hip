@@ -744,8 +744,10 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
     a_prep();
 #pragma unroll
     for (int r = 0; r < RPT3; ++r) { decode_row(r); load_a(r); }
+    QK_STAMP(5);
 #pragma unroll
     for (int r = 0; r < RPT3; ++r) store_a(r, 0);
+    QK_STAMP(6);
     a_advance_if_more();
 #pragma unroll
     for (int k = 0; k < BU; ++k) store_b1(k, 0);

@@ -43,6 +43,9 @@ for n in (sys.argv[1:] or ['c64', 'c32', 'c32to64']):
         t = buf.view(-1, 8).cpu()
         t = t[t[:, 3] > 0]
         pro, loop, epi = (t[:, 1] - t[:, 0]).float(), (t[:, 2] - t[:, 1]).float(), (t[:, 3] - t[:, 2]).float()
+        if int(t[:, 5].max()) > 0:        # finer prologue stamps: loads issued, band in LDS
+            print('         prologue: start -> loads issued %.0f -> band stored %.0f -> barrier passed %.0f cycles' % (
+                float((t[:, 5] - t[:, 0]).float().mean()), float((t[:, 6] - t[:, 5]).float().mean()), float((t[:, 1] - t[:, 6]).float().mean())))
         span = int(t[:, 3].max() - t[:, 0].min())
         taps, cq, f4 = s['w'][0] * s['w'][1], s['w'][2], s['w'][3]
         mfma_per_wave = taps * (cq // 32) * 2 * 16            # per tile: sub-steps x 2 ks x 16 MFMAs (a wave tile is 32 rows x 128 columns)
