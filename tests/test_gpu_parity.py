@@ -134,6 +134,10 @@ ORACLE_CASES = [
      dict(padding='same', strides=(2, 1), activation='relu')),
     ('conv2d_64ch_valid_wide', 2, (1, 6, 70, 256), (3, 5, 64, 128),
      dict(padding='valid', activation=None)),
+    # 16 quaternion channels -> 64 filters, five inner taps, lines longer than a K step (the band backward-weight's carried row
+    # offsets): masked = the one-column-tile-per-wave instantiation that replaced the spilling <2,5,true> (round 4); linear = <2,5,false>
+    ('conv2d_cq16_f64_5tap_relu', 2, (2, 5, 70, 64), (3, 5, 16, 256), dict(padding='same', activation='relu')),
+    ('conv2d_cq16_f64_5tap_linear', 2, (2, 5, 70, 64), (3, 5, 16, 256), dict(padding='same', activation=None)),
     # one tap per produced row: the streaming point-form kernel (k_hgemm16_point) in 16 bit
     ('dense_point_64', 0, (333, 256), (64, 256), dict(activation='relu')),
     ('dense_point_32to128', 0, (200, 128), (32, 512), dict(activation=None)),
@@ -171,7 +175,8 @@ def test_fp32_matches_oracle(case):
 HALF_CASES = [c for c in ORACLE_CASES if c[0] in (
     'cfg2_conv1d_b8_f64', 'conv1d_odd_channels', 'conv2d_body_small', 'conv2d_body64_small', 'conv2d_32to64', 'conv1d_64to32_valid',
     'conv2d_chfirst_body_small',
-    'conv2d_first_layer', 'dense_timit_head', 'dense_point_64', 'dense_point_32to128', 'conv2d_head_valid_conj', 'conv1d_1x1_64', 'conv3d_32ch', 'conv2d_32ch_outer_stride_dil', 'conv2d_64ch_valid_wide')]
+    'conv2d_first_layer', 'dense_timit_head', 'dense_point_64', 'dense_point_32to128', 'conv2d_head_valid_conj', 'conv1d_1x1_64', 'conv3d_32ch', 'conv2d_32ch_outer_stride_dil', 'conv2d_64ch_valid_wide',
+    'conv2d_cq16_f64_5tap_relu', 'conv2d_cq16_f64_5tap_linear')]
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16], ids=['bf16', 'fp16'])
