@@ -62,6 +62,7 @@ struct GemmGeom {
     int has_bias;
     int has_mask;       // gathered value is zeroed where mask[same index] <= 0 (relu backward)
     int ablate;         // profiling only (env QK_ABLATE): 4 = skip the MFMA loop, 8 = skip the epilogue
+    unsigned b_rep;     // band kernels: sum over outer tap t0 of 2^(t0 * ks[1]) (0: more than 32 outer taps -- loop form)
     unsigned long long *dbg_ts;          // profiling only (qk_set_debug_buffer): per-workgroup phase time stamps of the band kernel
     int w_swapped;      // Wk is the compact kernel itself, read with q/j swapped (backward-data): no transposed copy
     int w_prepped;      // 16-bit path: the workspace already holds the re-laid-out kernel (qk_conv_desc_t.ws_has_kernel)
@@ -113,6 +114,8 @@ inline bool band_geom(const GemmGeom &g, int esize, GemmGeom *o)
     }
     const int k = o->ks[2];
     if (o->ks[0] * o->ks[1] > 32) return false;             // outer-tap bit mask
+    o->b_rep = 0;
+    for (int t0 = 0; t0 < o->ks[0]; ++t0) o->b_rep |= 1u << (t0 * o->ks[1]);
     o->b_wp = o->osp[2] + k - 1;
     if ((k - 1) * 12 > o->b_wp) return false;                // > 8 % of the rows would be padding
     const long long lines = (long long)g.batch * o->osp[0] * o->osp[1];

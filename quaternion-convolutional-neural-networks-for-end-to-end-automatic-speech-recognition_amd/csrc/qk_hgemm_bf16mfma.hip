@@ -525,6 +525,33 @@ __device__ __forceinline__ void buf_store16b(__amdgpu_buffer_rsrc_t r, unsigned 
     __builtin_amdgcn_raw_buffer_store_b128(d, r, (int)(voff + soff), 0, 0);
 }
 
+// Bit (t0 * ks1 + t1) set iff outer tap (t0, t1) of a row whose tap-0 input coordinates are (q0, q1) falls inside the tensor.
+// With dilation +-1 on both outer axes the valid taps of an axis are a RANGE, so the mask is a product of two bit ranges --
+// no loop, no branch (the loops with their run-time trip counts were ~40 taken branches per wave in the band kernel's prologue,
+// which is instruction-issue bound: tools/probe/phase_stamps.py).  `rep` = sum over t0 of 2^(t0 * ks1) (host: GemmGeom::b_rep).
+__device__ __forceinline__ unsigned outer_tap_mask(int q0, int q1, const GemmGeom &g)
+{
+    const bool u0 = g.pb[0] == 1 || g.pb[0] == -1, u1 = g.pb[1] == 1 || g.pb[1] == -1;
+    if (u0 && u1 && g.b_rep != 0u) {
+        // input coordinate q + pb t with pb = +1 (forward) or -1 (backward-data): taps [lo, hi) are inside [0, extent)
+        const int lo0 = g.pb[0] > 0 ? max(0, -q0) : max(0, q0 - g.isp[0] + 1), hi0 = g.pb[0] > 0 ? min(g.ks[0], g.isp[0] - q0) : min(g.ks[0], q0 + 1);
+        const int lo1 = g.pb[1] > 0 ? max(0, -q1) : max(0, q1 - g.isp[1] + 1), hi1 = g.pb[1] > 0 ? min(g.ks[1], g.isp[1] - q1) : min(g.ks[1], q1 + 1);
+        if (lo0 >= hi0 || lo1 >= hi1) return 0u;
+        const unsigned m1 = ((hi1 >= 32 ? 0u : (1u << hi1)) - 1u) & ~((1u << lo1) - 1u);
+        const int b0 = lo0 * g.ks[1], e0 = hi0 * g.ks[1];
+        const unsigned r0 = ((e0 >= 32 ? 0u : (1u << e0)) - 1u) & ~((1u << b0) - 1u);
+        return (m1 * g.b_rep) & r0;
+    }
+    unsigned m = 0;
+    int t = 0;
+    for (int t0 = 0; t0 < g.ks[0]; ++t0)
+        for (int t1 = 0; t1 < g.ks[1]; ++t1, ++t) {
+            const int i0 = q0 + t0 * g.pb[0], i1 = q1 + t1 * g.pb[1];
+            if (i0 >= 0 && i0 < g.isp[0] && i1 >= 0 && i1 < g.isp[1]) m |= 1u << t;
+        }
+    return m;
+}
+
 // A-band staging schedule of one group: op code q < R loads row pass q of the NEXT band into its
 // registers, R <= q < 2R stores pass q - R into the other band buffer, -1 = nothing.  A store comes at
 // least one sub-step after its load (so it never waits on it), and at most three passes are in flight
@@ -612,12 +639,7 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
             const int l2 = fastdiv(line, g.dv_mul[1], g.dv_shr[1]), o1 = line - l2 * g.osp[1];
             const int n = fastdiv(l2, g.dv_mul[2], g.dv_shr[2]), o0 = l2 - n * g.osp[0];
             const int q0 = o0 * g.pa[0] + g.pc[0], q1 = o1 * g.pa[1] + g.pc[1];
-            int t = 0;
-            for (int t0 = 0; t0 < g.ks[0]; ++t0)
-                for (int t1 = 0; t1 < g.ks[1]; ++t1, ++t) {
-                    const int i0 = q0 + t0 * g.pb[0], i1 = q1 + t1 * g.pb[1];
-                    if (i0 >= 0 && i0 < g.isp[0] && i1 >= 0 && i1 < g.isp[1]) tile_ot |= 1u << t;
-                }
+            tile_ot |= outer_tap_mask(q0, q1, g);
         }
         tile_ot = __builtin_amdgcn_readfirstlane(tile_ot);
     }
@@ -632,13 +654,7 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
             const int n = fastdiv(l2, g.dv_mul[2], g.dv_shr[2]), o0 = l2 - n * g.osp[0];
             const int q0 = o0 * g.pa[0] + g.pc[0], q1 = o1 * g.pa[1] + g.pc[1];
             base_off[r] = n * (int)g.in_sn + q0 * (int)g.in_ss[0] + q1 * (int)g.in_ss[1] + col * (int)g.in_ss[2];
-            int t = 0;
-            for (int t0 = 0; t0 < g.ks[0]; ++t0)
-                for (int t1 = 0; t1 < g.ks[1]; ++t1, ++t) {
-                    const int i0 = q0 + t0 * g.pb[0], i1 = q1 + t1 * g.pb[1];
-                    const bool ok = i0 >= 0 && i0 < g.isp[0] && i1 >= 0 && i1 < g.isp[1];
-                    omask[r] |= (ok ? 1u : 0u) << t;
-                }
+            omask[r] = outer_tap_mask(q0, q1, g);
         }
     };
     const int groups = __builtin_popcount(tile_ot) * nkc;
