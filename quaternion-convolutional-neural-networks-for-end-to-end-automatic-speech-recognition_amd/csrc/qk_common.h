@@ -114,6 +114,8 @@ inline bool band_geom(const GemmGeom &g, int esize, GemmGeom *o)
     }
     const int k = o->ks[2];
     if (o->ks[0] * o->ks[1] > 32) return false;             // outer-tap bit mask
+    for (int i = 0; i < 2; ++i)                              // ... built from tap RANGES: dilation +-1 on the outer axes (else the general kernel)
+        if (o->pb[i] != 1 && o->pb[i] != -1) return false;
     o->b_rep = 0;
     for (int t0 = 0; t0 < o->ks[0]; ++t0) o->b_rep |= 1u << (t0 * o->ks[1]);
     o->b_wp = o->osp[2] + k - 1;
@@ -143,7 +145,11 @@ inline void fastdiv_of(unsigned d, unsigned *mul, unsigned *shr)
 }
 __device__ __forceinline__ int fastdiv(int n, unsigned mul, unsigned shr)
 {
-    return mul ? (int)(__umulhi((unsigned)n, mul) >> shr) : n;
+    // branch-free: `mul` is wave-uniform, and hipcc turns `mul ? ... : n` into a scalar BRANCH around the multiply -- three
+    // per decoded row in the prologues, which are instruction-issue bound (tools/probe/phase_stamps.py).  One bit-select instead.
+    const unsigned q = __umulhi((unsigned)n, mul) >> shr;
+    const unsigned id = (unsigned)-(int)(mul == 0u);            // all ones for the identity divisor
+    return (int)((q & ~id) | ((unsigned)n & id));
 }
 
 struct WgradGeom {

@@ -531,25 +531,16 @@ __device__ __forceinline__ void buf_store16b(__amdgpu_buffer_rsrc_t r, unsigned 
 // which is instruction-issue bound: tools/probe/phase_stamps.py).  `rep` = sum over t0 of 2^(t0 * ks1) (host: GemmGeom::b_rep).
 __device__ __forceinline__ unsigned outer_tap_mask(int q0, int q1, const GemmGeom &g)
 {
-    const bool u0 = g.pb[0] == 1 || g.pb[0] == -1, u1 = g.pb[1] == 1 || g.pb[1] == -1;
-    if (u0 && u1 && g.b_rep != 0u) {
-        // input coordinate q + pb t with pb = +1 (forward) or -1 (backward-data): taps [lo, hi) are inside [0, extent)
-        const int lo0 = g.pb[0] > 0 ? max(0, -q0) : max(0, q0 - g.isp[0] + 1), hi0 = g.pb[0] > 0 ? min(g.ks[0], g.isp[0] - q0) : min(g.ks[0], q0 + 1);
-        const int lo1 = g.pb[1] > 0 ? max(0, -q1) : max(0, q1 - g.isp[1] + 1), hi1 = g.pb[1] > 0 ? min(g.ks[1], g.isp[1] - q1) : min(g.ks[1], q1 + 1);
-        if (lo0 >= hi0 || lo1 >= hi1) return 0u;
-        const unsigned m1 = ((hi1 >= 32 ? 0u : (1u << hi1)) - 1u) & ~((1u << lo1) - 1u);
-        const int b0 = lo0 * g.ks[1], e0 = hi0 * g.ks[1];
-        const unsigned r0 = ((e0 >= 32 ? 0u : (1u << e0)) - 1u) & ~((1u << b0) - 1u);
-        return (m1 * g.b_rep) & r0;
-    }
-    unsigned m = 0;
-    int t = 0;
-    for (int t0 = 0; t0 < g.ks[0]; ++t0)
-        for (int t1 = 0; t1 < g.ks[1]; ++t1, ++t) {
-            const int i0 = q0 + t0 * g.pb[0], i1 = q1 + t1 * g.pb[1];
-            if (i0 >= 0 && i0 < g.isp[0] && i1 >= 0 && i1 < g.isp[1]) m |= 1u << t;
-        }
-    return m;
+    // input coordinate q + pb t with pb = +1 (forward) or -1 (backward-data) -- band_geom admits nothing else on the outer axes.
+    // pb = -1 is pb = +1 on the mirrored coordinate isp - 1 - q: ONE multiply-add by wave-uniform values instead of selects on a
+    // uniform condition (which hipcc compiles to scalar branches); taps [lo, hi) are then inside [0, extent).
+    const int m0 = q0 * g.pb[0] + (g.pb[0] > 0 ? 0 : g.isp[0] - 1), m1q = q1 * g.pb[1] + (g.pb[1] > 0 ? 0 : g.isp[1] - 1);
+    const int lo0 = max(0, -m0), hi0 = min(g.ks[0], g.isp[0] - m0);
+    const int lo1 = max(0, -m1q), hi1 = min(g.ks[1], g.isp[1] - m1q);
+    const unsigned m1 = ((hi1 >= 32 ? 0u : (1u << hi1)) - 1u) & ~((1u << lo1) - 1u);
+    const int b0 = lo0 * g.ks[1], e0 = hi0 * g.ks[1];
+    const unsigned r0 = ((e0 >= 32 ? 0u : (1u << e0)) - 1u) & ~((1u << b0) - 1u);
+    return (lo0 >= hi0 || lo1 >= hi1) ? 0u : (m1 * g.b_rep) & r0;
 }
 
 // A-band staging schedule of one group: op code q < R loads row pass q of the NEXT band into its
