@@ -732,8 +732,7 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
         Bs[tid + k * NTHR] = k == 0 ? br0 : k == 1 ? br1 : k == 2 ? br2 : br3;
     };
     // The accumulators START at the bias (round 4): a lane's register r of component b holds channel (r & 3) + 8 (r >> 2) + 4 lh of
-    // the wave's 32-channel block, i.e. four float4 pieces of the bias vector per component -- 16 L2-resident loads issued at the
-    // end of the prologue (below), in flight across its barrier.  Added in the epilogue instead (LDS table + barrier + 16 ds_read_b128 + 64 adds) the
+    // the wave's 32-channel block.  Added in the epilogue instead (LDS table + barrier + 16 ds_read_b128 + 64 adds) the
     // bias was HALF of the forward epilogue: 7.0 k cycles against backward-data's 3.6 k (tools/probe/phase_stamps.py).
     floatx16 acc[4], accn[4];
 #pragma unroll
@@ -752,6 +751,12 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
 #pragma unroll
     for (int r = 0; r < RPT3; ++r) { decode_row(r); load_a(r); }
     QK_STAMP(5);
+    // Bias -> accumulators, through LDS: one value per thread fetched behind the band's loads, parked at the start of band
+    // buffer 1 (first written by the staging of inner tap 1, i.e. behind the NEXT barrier) and read back as 16 broadcast
+    // ds_read_b128 per lane right behind the prologue's barrier.  (16 vector float4 loads per lane moved 64 KB per workgroup into
+    // registers and cost 1.4 k cycles; wave-uniform scalar loads + a move and a select per register 1.2 k.)
+    float bias_v = 0.f;
+    if (g.has_bias && tid < 4 * BF) bias_v = bias[(tid / BF) * g.J + j0 + tid % BF];
 #pragma unroll
     for (int r = 0; r < RPT3; ++r) store_a(r, 0);
     QK_STAMP(6);
@@ -763,18 +768,18 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
 #pragma unroll
     for (int k = 0; k < BU; ++k) load_b1(k);
     b_advance_if_more();
-    // (the bias loads go out LAST: issued in front of the band fetch they held up its LDS stores -- prologue +1.4 k cycles)
+    if (g.has_bias && tid < 4 * BF) reinterpret_cast<float *>(lds + A_U)[tid] = bias_v;
+    __syncthreads();
     if (g.has_bias) {
-        const float *bp = bias + j0 + wn * 32 + 4 * (lane >> 5);
+        const float4 *br = reinterpret_cast<const float4 *>(lds + A_U) + wn * 8 + (lane >> 5);
 #pragma unroll
         for (int b = 0; b < 4; ++b)
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
-                const float4 bb = *reinterpret_cast<const float4 *>(bp + b * g.J + 8 * gq);
+                const float4 bb = br[b * (BF / 4) + 2 * gq];
                 acc[b][4 * gq] = bb.x; acc[b][4 * gq + 1] = bb.y; acc[b][4 * gq + 2] = bb.z; acc[b][4 * gq + 3] = bb.w;
             }
     }
-    __syncthreads();
 
     QK_STAMP(1);
     static_assert(band_op(RPT3, KIN, 0, 0) != -2, "no staging schedule for this (row passes, inner taps)");
