@@ -452,13 +452,17 @@ def cpu_baseline(cfg, seconds, loss='ctc'):
     activation; autograd backward) on this host's cores, fp32, bounded to ~`seconds` in total, for the SAME workload:
     the single layer (oracle/ref_port.py) or the full TIMIT model's TRAINING STEP -- dropout, loss, backward, l2, Adam --
     on a batch of 32 (oracle/ref_model.py).  oneDNN does not scale these problems linearly to hundreds of threads, so the
-    thread counts {16, 64, 128, all} are tried and the best is reported (`cores` = the thread count that produced `value`)."""
+    thread counts {16, 64, 128, all} are tried in ascending order -- a count is skipped (None) once the previous one was 1.5x
+    slower than the best so far -- and the best is reported (`cores` = the thread count that produced `value`)."""
     ncpu = os.cpu_count() or 1
     is_model = cfg.get('kind') == 'model'
     tries = sorted({min(ncpu, t) for t in ((16, 64, 128, ncpu) if is_model else (8, 32, 64, ncpu))})
     sample_b = 32 if is_model else cfg['batch']
-    best, per = None, {}
+    best, per, rising = None, {}, False
     for th in tries:
+        if best is not None and is_model and rising:
+            per[str(th)] = None            # the curve is already going up steeply (oneDNN on this model): 256 threads took 88 s per step
+            continue
         if is_model:
             ms, n = _cpu_model_pass_time(cfg, th, seconds / len(tries), sample_b, loss)
         else:
@@ -466,6 +470,7 @@ def cpu_baseline(cfg, seconds, loss='ctc'):
         per[str(th)] = round(ms, 2)
         if best is None or ms < best[0]:
             best = (ms, n, th)
+        rising = ms > 1.5 * best[0]
     ms, n, th = best
     what = ('the full TIMIT QCNN (n=%d, sf=%d, %d frames) through oracle/ref_model.py' % (cfg['layers'], cfg['sf'], cfg['frames'])
             if is_model else 'the same layer through oracle/ref_port.py')

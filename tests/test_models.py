@@ -374,7 +374,8 @@ def test_tall_dense_split_reduction_matches_plain_autograd():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['fp32', 'bf16'])
-@pytest.mark.parametrize('shape', [(5, 30, 10, 6), (3, 27, 62, 9), (256, 200, 62, 50), (2, 300, 62, 20)], ids=['small', 'odd', 'timit_b256', 'long_lp_from_global'])
+@pytest.mark.parametrize('shape', [(5, 30, 10, 6), (3, 27, 62, 9), (256, 200, 62, 50), (2, 300, 62, 20), (3, 160, 20, 70)],
+                         ids=['small', 'odd', 'timit_b256', 'long_lp_from_global', 'more_than_63_labels'])
 def test_fused_ctc_batch_cost_matches_the_keras_restatement(shape, dtype):
     """qk_ctc_batch_cost (K.ctc_batch_cost of interspeech_model.py:37-39 as one launch: cost and d cost / d y_pred) against the
     torch restatement of the Keras / TensorFlow op that the golden fixture G17 pins (layers.ctc_batch_cost with the fused path
