@@ -10,9 +10,10 @@
 # 6. the energy-apportioning probe (tools/probe: MFMA only / + LDS reads / + staging, 32- and 64-row wave tiles); -> r04_energy_probe.txt
 # 7. per-phase ablation of the 16-bit kernels (tools/ablate16.py);                             -> r04_ablation.txt
 # 8. the bench lines: default (CTC), --loss sum, cfg5 stack, native-layout layer (builder runs).  -> r04_bench_*.json
+# 9. phase time stamps of the band kernels (probe build, tools/probe/phase_stamps.py) and the sum / CTC loss A-B with telemetry (ab_loss.py)  -> r04_phase_stamps.txt, r04_loss_ab.txt
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; cd $R; O=gpurun_out/r04; rm -rf $O; mkdir -p $O
-STEPS="${STEPS:-1 2 3 4 5 6 7 8}"
+STEPS="${STEPS:-1 2 3 4 5 6 7 8 9}"
 has() { [[ " $STEPS " == *" $1 "* ]]; }
 if has 1; then
 timeout 900 rocprofv3 --kernel-trace --stats -d $O -o ks_qcnn --output-format csv -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras --no-standalone > $O/log_qcnn.txt 2>&1; echo "qcnn trace rc=$?"
@@ -54,5 +55,10 @@ python bench.py --workload cfg5_stack_b32_fp16 --no-cpu-baseline > $O/r04_bench_
 for lay in channels_last native; do python bench.py --workload cfg3_body_qconv2d_b256_bf16 --layout $lay --no-cpu-baseline > $O/r04_bench_cfg3body_${lay}_builder_run.json 2>/dev/null; done
 QK_DP_FORCE_COLLECTIVES=1 python bench.py --gpus 1 --steps 30 --warmup 5 --no-cpu-baseline --no-kernel-timing 2>/dev/null | grep "^{" > $O/r04_bench_one_rank_rccl_builder_run.json
 cat $O/bench_default.time
+fi
+if has 9; then
+QK_LIB=$R/tools/probe/libqk_stamps.so python tools/probe/phase_stamps.py c64 c32 c32to64 2>&1 | grep -v amdgpu.ids > $O/r04_phase_stamps.txt
+python tools/probe/ab_loss.py 2>&1 | grep -v amdgpu.ids > $O/r04_loss_ab.txt
+python tools/probe/grad_stats.py 2>&1 | grep -v amdgpu.ids >> $O/r04_loss_ab.txt
 fi
 ls -la $O
