@@ -865,6 +865,9 @@ def main():
             if 'ms_per_step' in other:
                 out['loss_variants']['sum' if args.loss == 'ctc' else 'ctc'] = {'ms_per_step': other['ms_per_step'], 'samples_per_s': other['samples_per_s'],
                                                                                'headline': False}
+            out['loss_variants']['note'] = ('BENCH_r01..r03 timed the `sum` loss (a linear stand-in); since round 4 the headline is the CTC cost the reference model '
+                                            'outputs (interspeech_model.py:37-39,178).  Like-for-like with earlier rounds: loss_variants.sum.  The CTC step is slower than '
+                                            'kernel(0.12 ms) + glue: its gradient distribution makes the backward kernels draw more power (DESIGN.md 3.11).')
             try:        # BASELINE configs[1]: the single QuaternionConv1D layer, step + kernels
                 c2 = dict(WORKLOADS['cfg2_qconv1d_timit_b64_fp32'], activation='relu')
                 j2 = LayerTrainStep(c2, dev, 0, 1)
