@@ -74,59 +74,87 @@ struct C1 {
     static_assert(TAPS <= 16 && KW - 1 <= 4, "one 16-deep MFMA step holds the taps");
     static constexpr int PATCH_BYTES = NR * C1_PW * 8;
 
-    // x rows [PH*ho - PADH, +NR) x positions [t0 - PADW, +C1_PW) of sample n -> LDS, zeros outside the tensor
+    // x rows [PH*ho - PADH, +NR) x positions [t0 - PADW, +C1_PW) of sample n -> LDS, zeros outside the tensor; in two halves so
+    // that a persistent workgroup can have the NEXT segment's loads in flight under this segment's MFMAs (patch_load: global ->
+    // registers, nothing consumes them; patch_store: registers -> LDS).
     // x_planes: the r, i, j, k planes are read as they lie -- per plane and patch row a run of consecutive positions,
     // two positions (4 bytes) per lane and plane, i.e. coalesced 256-byte segments per wave and plane, the four loads of a
     // lane in flight together -- and interleaved with v_perm_b32 into the same [position][component] LDS image (two 8-byte
     // stores); odd W or an odd first position falls back to one position per load.
-    static __device__ __forceinline__ void stage_patch(const T *__restrict__ x, char *patch, const C1Geom &g, int n, int ho, int t0, int tid, int nthr)
+    static constexpr int HALF = C1_PW / 2;
+    static_assert(C1_PW % 2 == 0, "patch width in position pairs");
+    static constexpr int PRE_IT = (NR * C1_PW + 447) / 448;        // units per thread, channels_last (8 bytes each); planes: 16 bytes each
+    struct Pre { unsigned v[PRE_IT][4]; };
+    static __device__ __forceinline__ void patch_load(const T *__restrict__ x, const C1Geom &g, int n, int ho, int t0, int tid, Pre &p)
     {
         const int f_lo = PH * ho - PADH;
         if (g.x_planes) {
-            constexpr int HALF = C1_PW / 2;
-            static_assert(C1_PW % 2 == 0, "patch width in position pairs");
             const bool pairs = ((g.W | (t0 - PADW)) & 1) == 0;             // both positions of a pair share the 4-byte word
             const long long plane = (long long)g.H * g.W;
-            for (int e0 = tid; e0 < NR * HALF; e0 += nthr) {
-                int e = e0;
-                asm volatile("" : "+v"(e));
+#pragma unroll
+            for (int it = 0; it < (NR * HALF + 447) / 448; ++it) {
+                const int e = tid + it * 448;
                 const int r = e / HALF, c2 = e - r * HALF;
                 const int f = f_lo + r, t = t0 - PADW + 2 * c2;
-                unsigned w4[4] = {0u, 0u, 0u, 0u};                          // plane a: positions t (low half), t + 1 (high half)
-                if (f >= 0 && f < g.H) {
+#pragma unroll
+                for (int a = 0; a < 4; ++a) p.v[it][a] = 0u;               // plane a: positions t (low half), t + 1 (high half)
+                if (e < NR * HALF && f >= 0 && f < g.H) {
                     const T *row = x + ((long long)n * 4 * g.H + f) * g.W;
                     if (pairs && t >= 0 && t + 1 < g.W) {
 #pragma unroll
-                        for (int a = 0; a < 4; ++a) w4[a] = *reinterpret_cast<const unsigned *>(row + a * plane + t);   // four loads in flight
+                        for (int a = 0; a < 4; ++a) p.v[it][a] = *reinterpret_cast<const unsigned *>(row + a * plane + t);   // four loads in flight
                     } else {
 #pragma unroll
                         for (int a = 0; a < 4; ++a) {
                             unsigned lo = 0u, hi = 0u;
                             if (t >= 0 && t < g.W) lo = __builtin_bit_cast(unsigned short, row[a * plane + t]);
                             if (t + 1 >= 0 && t + 1 < g.W) hi = __builtin_bit_cast(unsigned short, row[a * plane + t + 1]);
-                            w4[a] = lo | (hi << 16);
+                            p.v[it][a] = lo | (hi << 16);
                         }
                     }
                 }
-                // [position][component] image: two 8-byte stores (r | i, j | k of position t, then of position t + 1)
-                const uint2 p0 = make_uint2(__builtin_amdgcn_perm(w4[1], w4[0], 0x05040100u), __builtin_amdgcn_perm(w4[3], w4[2], 0x05040100u));
-                const uint2 p1 = make_uint2(__builtin_amdgcn_perm(w4[1], w4[0], 0x07060302u), __builtin_amdgcn_perm(w4[3], w4[2], 0x07060302u));
-                char *dst = patch + (r * C1_PW + 2 * c2) * 8;
-                *reinterpret_cast<uint2 *>(dst) = p0;
-                *reinterpret_cast<uint2 *>(dst + 8) = p1;
             }
             return;
         }
-        for (int e0 = tid; e0 < NR * C1_PW; e0 += nthr) {
-            int e = e0;
-            asm volatile("" : "+v"(e));                            // (opaque, see k_conv1_pool_bwd)
+#pragma unroll
+        for (int it = 0; it < PRE_IT; ++it) {
+            const int e = tid + it * 448;
             const int r = e / C1_PW, c = e - r * C1_PW;
             const int f = f_lo + r, t = t0 - PADW + c;
             uint2 v = make_uint2(0u, 0u);
-            if (f >= 0 && f < g.H && t >= 0 && t < g.W)
+            if (e < NR * C1_PW && f >= 0 && f < g.H && t >= 0 && t < g.W)
                 v = *reinterpret_cast<const uint2 *>(x + (((long long)n * g.H + f) * g.W + t) * 4);
-            *reinterpret_cast<uint2 *>(patch + e * 8) = v;
+            p.v[it][0] = v.x; p.v[it][1] = v.y;
         }
+    }
+    static __device__ __forceinline__ void patch_store(char *patch, const C1Geom &g, int tid, const Pre &p)
+    {
+        if (g.x_planes) {
+#pragma unroll
+            for (int it = 0; it < (NR * HALF + 447) / 448; ++it) {
+                const int e = tid + it * 448;
+                if (e < NR * HALF) {
+                    const unsigned *w4 = p.v[it];
+                    // [position][component] image: two 8-byte stores (r | i, j | k of position t, then of position t + 1)
+                    const uint2 p0 = make_uint2(__builtin_amdgcn_perm(w4[1], w4[0], 0x05040100u), __builtin_amdgcn_perm(w4[3], w4[2], 0x05040100u));
+                    const uint2 p1 = make_uint2(__builtin_amdgcn_perm(w4[1], w4[0], 0x07060302u), __builtin_amdgcn_perm(w4[3], w4[2], 0x07060302u));
+                    *reinterpret_cast<uint2 *>(patch + e * 16) = p0;        // (r * C1_PW + 2 c2) * 8 == e * 16
+                    *reinterpret_cast<uint2 *>(patch + e * 16 + 8) = p1;
+                }
+            }
+            return;
+        }
+#pragma unroll
+        for (int it = 0; it < PRE_IT; ++it) {
+            const int e = tid + it * 448;
+            if (e < NR * C1_PW) *reinterpret_cast<uint2 *>(patch + e * 8) = make_uint2(p.v[it][0], p.v[it][1]);
+        }
+    }
+    static __device__ __forceinline__ void stage_patch(const T *__restrict__ x, char *patch, const C1Geom &g, int n, int ho, int t0, int tid)
+    {
+        Pre p;
+        patch_load(x, g, n, ho, t0, tid, p);
+        patch_store(patch, g, tid, p);
     }
     // byte offset (relative to the lane's position) of tap k inside the patch; taps >= TAPS are clamped (their B row is zero)
     static __device__ __forceinline__ int tap_off(int k)
@@ -175,7 +203,8 @@ struct C1 {
         for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const uint2 *>(lane_base + fi * (C1_PW * 8) + toff[i]);
         split4(v, A);
     }
-    static __device__ __forceinline__ floatx16 conv_b(const uint4 (&A)[4], const uint4 (&B)[4], int b)
+    template <int NBN>
+    static __device__ __forceinline__ floatx16 conv_b(const uint4 (&A)[4], const uint4 (&B)[4], const uint4 (&Bn)[NBN], int b)
     {
         floatx16 acc;
 #pragma unroll
@@ -183,120 +212,198 @@ struct C1 {
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
             const bool ng = (kSignConv >> (a * 4 + b)) & 1u;
-            acc = c1_mfma(T(), A[a], ng ? c1_neg(B[a ^ b]) : B[a ^ b], acc);
+            acc = c1_mfma(T(), A[a], ng ? (NBN == 4 ? Bn[(a ^ b) % NBN] : c1_neg(B[a ^ b])) : B[a ^ b], acc);
         }
         return acc;
     }
 };
 
 // ---------------------------------------------------------------------------------------------------------------
+// The arg-max side tensor ("aux"): per wave tile and lane six words = three ONE-HOT planes (window row 0 / 1 / 2 held the
+// maximum AND the output is alive: relu did not kill it), two words each.  The lane's 64 elements are (component b, accumulator
+// register r = 2 j + odd); word h = b >> 1 of a plane holds element (b, 2 j) at bit 8 (1 - (b & 1)) + j and element (b, 2 j + 1)
+// sixteen bits above it -- so that the backward masks a PACKED pair of 16-bit gradients with `(word >> k) & 0x00010001` and one
+// v_pk_mul_lo_u16.  Stored [tile][plane][lane] as 8-byte words.
+//
+// The forward builds the planes by SHIFTING comparison results in: v_cmp + v_addc_co_u32 (word = 2 word + carry) is two
+// instructions per element and window row, where the read-modify-write of a 2-bit field was four (the kernel is bound by VALU
+// issue: 30 VALU instructions per MFMA before).
+__device__ __forceinline__ void c1_max_shift_in(unsigned &w, float &m, float a)        // w = 2 w + (a > m);  m = max(m, a)
+{
+    // The compare is the COMPILER's instruction: it reads an MFMA result, and the wait states that takes are inserted for
+    // instructions the hazard recogniser can see -- inside an asm block they are not (a first version with the compare in the
+    // block read accumulator registers 14 / 15 of a tile before the MFMA had written them).  The block only consumes the lane mask.
+    const unsigned long long gt = __builtin_amdgcn_fcmpf(a, m, 2 /* ordered greater-than */);
+    asm("v_addc_co_u32_e64 %0, vcc, %0, %0, %2\n\tv_cndmask_b32_e64 %1, %1, %3, %2" : "+v"(w), "+v"(m) : "s"(gt), "v"(a) : "vcc");
+}
+__device__ __forceinline__ void c1_shift_in(unsigned &w, bool c) { w = (w << 1) | (c ? 1u : 0u); }
+__device__ __forceinline__ unsigned c1_relu_pk(unsigned pk)                              // relu of two packed bf16 / fp16: sign-magnitude, so max
+{                                                                                        // with 0 as 16-bit integers
+    typedef short s2 __attribute__((ext_vector_type(2)));
+    const s2 z = {0, 0};
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s2, pk), z));
+}
+// raw planes (even / odd registers apart; bit 8 (3 - b) + j) -> the two stored words of one plane
+__device__ __forceinline__ uint2 c1_plane_words(unsigned e, unsigned o)
+{
+    return make_uint2((e >> 16) | (o & 0xFFFF0000u), (e & 0xFFFFu) | (o << 16));
+}
+
 // PRELU: the layer is linear + PReLU (interspeech_model.py:97-103 with aact == 'prelu'): the window maximum is taken over
 // prelu(conv + bias) with the slope of each row, and the PRE-activation at the arg-max is written beside the pooled
 // tensor (`pre_out`): the backward needs it for the derivative and the slope gradient (with the Keras initial slope 0
 // it cannot be recovered from the output).
+//
+// Persistent: a workgroup walks over pooled line segments; the kernel fragments are built once, and the next segment's
+// patch is in flight (registers) under this segment's MFMAs, two patch buffers in LDS, one barrier per segment.
 template <typename T, int KH, int KW, int PH, bool PRELU>
 __global__ void __launch_bounds__(448) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_conv1_pool_fwd(const T *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias, T *__restrict__ out,
-                 T *__restrict__ pre_out, uint4 *__restrict__ argbits, const C1Geom g)
+                 T *__restrict__ pre_out, uint2 *__restrict__ argbits, const C1Geom g)
 {
     typedef C1<T, KH, KW, PH> K;
     constexpr int EP_PITCH = 80;
-    __shared__ __attribute__((aligned(16))) char lds[K::PATCH_BYTES + 7 * 32 * EP_PITCH];
+    constexpr int PATCH_SLOT = (K::PATCH_BYTES + 15) / 16 * 16;
+    __shared__ __attribute__((aligned(16))) char lds[2 * PATCH_SLOT + 7 * 32 * EP_PITCH];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 31, lh = lane >> 5;
-    const int item = blockIdx.x;                                  // (n, ho, chunk)
-    const int chunk = item % g.n_chunks, line = item / g.n_chunks;
-    const int ho = line % g.Ho, n = line / g.Ho;
-    const int t0 = chunk * C1_TW;
     const int j0 = blockIdx.y * 32;
-    K::stage_patch(x, lds, g, n, ho, t0, tid, 448);
-    uint4 B[4];
+    int item = blockIdx.x;                                        // (n, ho, chunk)
+    if (item >= g.n_lines) return;
+    typename K::Pre pre;
+    {
+        const int chunk = item % g.n_chunks, line = item / g.n_chunks;
+        K::patch_load(x, g, line / g.Ho, line % g.Ho, chunk * C1_TW, tid, pre);
+    }
+    uint4 B[4], Bn[PRELU ? 1 : 4];                                // (PRELU negates on the fly: it has no 16 registers to spare)
     K::load_w(w, g.F, j0 + lr, lh, B);
+    if constexpr (!PRELU) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) Bn[p] = c1_neg(B[p]);
+    }
     int toff[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) toff[i] = K::tap_off(8 * lh + i);
+    float bia4[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) bia4[b] = g.has_bias ? bias[b * g.F + j0 + lr] : 0.f;
+    K::patch_store(lds, g, tid, pre);
     __syncthreads();
+    char *ep = lds + 2 * PATCH_SLOT + wave * (32 * EP_PITCH);
+    const int e_row = lane >> 2, e_chunk = lane & 3;
 
-    const int tw = t0 + wave * 32;                                // first position of this wave's tile
-    if (tw < g.W) {
-        const char *lane_base = lds + (wave * 32 + lr) * 8;
-        // window maximum and WHICH row tile holds it (first maximum wins, as in TF / torch): 2 bits per element, kept for
-        // the backward (argbits: 16 bytes per lane and tile); 3 = nothing flows back (relu: max + bias <= 0)
-        floatx16 pooled[4], presel[PRELU ? 4 : 1];
-        unsigned argw[4] = {0u, 0u, 0u, 0u};
-        float bia4[4];
+#pragma unroll 1
+    for (int it = 0;; ++it) {
+        const int next = item + (int)gridDim.x;
+        const bool has_next = next < g.n_lines;
+        if (has_next) {
+            const int chunk = next % g.n_chunks, line = next / g.n_chunks;
+            K::patch_load(x, g, line / g.Ho, line % g.Ho, chunk * C1_TW, tid, pre);
+        }
+        const int chunk = item % g.n_chunks, line = item / g.n_chunks;
+        const int ho = line % g.Ho, n = line / g.Ho;
+        const int t0 = chunk * C1_TW;
+        const int tw = t0 + wave * 32;                            // first position of this wave's tile
+        if (tw < g.W) {
+            const char *lane_base = lds + (it & 1) * PATCH_SLOT + (wave * 32 + lr) * 8;
+            // window maximum and WHICH row tile holds it (first maximum wins, as in TF / torch), one component b at a time: the
+            // fragments of the window's rows are built once, the maxima of one component live in 16 registers
+            const int n_fi = min(PH, g.H - PH * ho);              // partial last window ('same' pooling: high side only)
+            uint4 A[PH][4];
+            float af[PH];
 #pragma unroll
-        for (int b = 0; b < 4; ++b) bia4[b] = g.has_bias ? bias[b * g.F + j0 + lr] : 0.f;
+            for (int fi = 0; fi < PH; ++fi) {
+                K::tap_frags(lane_base, toff, fi < n_fi ? fi : 0, A[fi]);
+                af[fi] = PRELU ? g.alpha[g.alpha_len > 1 ? min(PH * ho + fi, g.alpha_len - 1) : 0] : 0.f;
+            }
+            unsigned ue[PH], uo[PH];                              // [fi >= 1]: "row fi beat the rows before it", shifted in b ascending, r descending
 #pragma unroll
-        for (int fi = 0; fi < PH; ++fi) {
-            if (PH * ho + fi >= g.H) break;                       // partial last window ('same' pooling: high side only)
-            uint4 A[4];
-            K::tap_frags(lane_base, toff, fi, A);
-            const float af = PRELU ? g.alpha[g.alpha_len > 1 ? PH * ho + fi : 0] : 0.f;
+            for (int fi = 0; fi < PH; ++fi) { ue[fi] = 0u; uo[fi] = 0u; }
+            uint2 alive = PRELU ? make_uint2(~0u, ~0u) : make_uint2(0u, 0u);                    // in the stored layout
+            T *line_out = out + (((long long)n * g.Ho + ho) * g.W) * (4 * g.F) + j0;           // (wave-uniform: 32-bit lane offsets below)
+            T *line_pre = PRELU && pre_out ? pre_out + (((long long)n * g.Ho + ho) * g.W) * (4 * g.F) + j0 : nullptr;
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
-                const floatx16 acc = K::conv_b(A, B, b);
+                floatx16 pooled = K::conv_b(A[0], B, Bn, b), presel;
+                if constexpr (PRELU) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    if constexpr (PRELU) {
-                        const float pre = acc[r] + bia4[b];
-                        const float act = fmaxf(pre, 0.f) + af * fminf(pre, 0.f);
-                        const bool up = fi == 0 || act > pooled[b][r];
-                        pooled[b][r] = up ? act : pooled[b][r];
-                        presel[b][r] = up ? pre : presel[b][r];
-                        if (fi) argw[b] = up ? ((argw[b] & ~(3u << (2 * r))) | ((unsigned)fi << (2 * r))) : argw[b];
-                    } else if (fi == 0) pooled[b][r] = acc[r];
-                    else {
-                        const bool up = acc[r] > pooled[b][r];
-                        pooled[b][r] = up ? acc[r] : pooled[b][r];
-                        argw[b] = up ? ((argw[b] & ~(3u << (2 * r))) | ((unsigned)fi << (2 * r))) : argw[b];
+                    for (int r = 0; r < 16; ++r) {
+                        presel[r] = pooled[r] + bia4[b];
+                        pooled[r] = fmaxf(presel[r], 0.f) + af[0] * fminf(presel[r], 0.f);
+                    }
+                }
+#pragma unroll
+                for (int fi = 1; fi < PH; ++fi) {
+                    if (fi >= n_fi) break;
+                    const floatx16 acc = K::conv_b(A[fi], B, Bn, b);
+#pragma unroll
+                    for (int r = 15; r >= 0; --r) {
+                        unsigned &u = (r & 1) ? uo[fi] : ue[fi];
+                        if constexpr (PRELU) {
+                            const float pv = acc[r] + bia4[b];
+                            const float act = fmaxf(pv, 0.f) + af[fi] * fminf(pv, 0.f);
+                            const bool up = act > pooled[r];
+                            pooled[r] = up ? act : pooled[r];
+                            presel[r] = up ? pv : presel[r];
+                            c1_shift_in(u, up);
+                        } else {
+                            float m = pooled[r];
+                            c1_max_shift_in(u, m, acc[r]);
+                            pooled[r] = m;
+                        }
+                    }
+                }
+                // relu(max + bias) (== max of relu(conv + bias)) on the PACKED 16-bit pairs, and which outputs are alive: min(value, 1)
+                // as 16-bit integers is the pair's two alive bits, sixteen bits apart -- shifted in as they will be stored
+                unsigned pk[8];
+                if constexpr (!PRELU) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) pooled[r] += bia4[b];
+#pragma unroll
+                    for (int j = 7; j >= 0; --j) {
+                        typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+                        pk[j] = c1_relu_pk(c1_pack(T(), pooled[2 * j], pooled[2 * j + 1]));
+                        const us2 one = {1, 1};
+                        const unsigned t = __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(us2, pk[j]), one));
+                        unsigned &ax = (b >> 1) ? alive.y : alive.x;
+                        ax = (ax << 1) | t;
+                    }
+                }
+                // transpose through LDS, 16-byte stores
+#pragma unroll
+                for (int which = 0; which < (PRELU ? 2 : 1); ++which) {
+                    T *dst_t = which ? line_pre : line_out;
+                    if (which && !line_pre) break;
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        if constexpr (PRELU) pk[r >> 1] = which ? c1_pack(T(), presel[r], presel[r + 1]) : c1_pack(T(), pooled[r], pooled[r + 1]);
+                        char *dst = ep + mfma32_row(r, lane) * EP_PITCH + lr * 2;
+                        *reinterpret_cast<unsigned short *>(dst) = (unsigned short)pk[r >> 1];
+                        *reinterpret_cast<unsigned short *>(dst + EP_PITCH) = (unsigned short)(pk[r >> 1] >> 16);
+                    }
+#pragma unroll
+                    for (int pass = 0; pass < 2; ++pass) {
+                        const int row = e_row + 16 * pass;
+                        const uint4 v = *reinterpret_cast<const uint4 *>(ep + row * EP_PITCH + e_chunk * 16);
+                        const int t = tw + row;
+                        if (t < g.W) *reinterpret_cast<uint4 *>(dst_t + (unsigned)(t * (4 * g.F) + b * g.F + e_chunk * 8)) = v;
                     }
                 }
             }
-        }
-        // relu(max + bias) (== max of relu(conv + bias)), transpose through LDS, 16-byte stores
-        char *ep = lds + K::PATCH_BYTES + wave * (32 * EP_PITCH);
-        const int e_row = lane >> 2, e_chunk = lane & 3;
-        if (argbits) {
-            if constexpr (!PRELU) {
-#pragma unroll
-                for (int b = 0; b < 4; ++b)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) argw[b] |= pooled[b][r] + bia4[b] > 0.f ? 0u : (3u << (2 * r));
-            }
-            argbits[(((long long)blockIdx.y * g.n_lines + item) * 7 + wave) * 64 + lane] = make_uint4(argw[0], argw[1], argw[2], argw[3]);
-        }
-#pragma unroll
-        for (int which = 0; which < (PRELU ? 2 : 1); ++which) {
-            T *dst_t = which ? pre_out : out;
-            if (which && !pre_out) break;
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-#pragma unroll
-                for (int r = 0; r < 16; r += 2) {
-                    float v0, v1;
-                    if constexpr (PRELU) {
-                        v0 = which ? presel[b][r] : pooled[b][r];
-                        v1 = which ? presel[b][r + 1] : pooled[b][r + 1];
-                    } else {
-                        v0 = fmaxf(pooled[b][r] + bia4[b], 0.f);
-                        v1 = fmaxf(pooled[b][r + 1] + bia4[b], 0.f);
-                    }
-                    const unsigned pk = c1_pack(T(), v0, v1);
-                    char *dst = ep + mfma32_row(r, lane) * EP_PITCH + lr * 2;
-                    *reinterpret_cast<unsigned short *>(dst) = (unsigned short)pk;
-                    *reinterpret_cast<unsigned short *>(dst + EP_PITCH) = (unsigned short)(pk >> 16);
-                }
-#pragma unroll
-                for (int pass = 0; pass < 2; ++pass) {
-                    const int row = e_row + 16 * pass;
-                    const uint4 v = *reinterpret_cast<const uint4 *>(ep + row * EP_PITCH + e_chunk * 16);
-                    const int t = tw + row;
-                    if (t < g.W)
-                        *reinterpret_cast<uint4 *>(dst_t + (((long long)n * g.Ho + ho) * g.W + t) * (4 * g.F) + b * g.F + j0 + e_chunk * 8) = v;
-                }
+            if (argbits) {
+                static_assert(PH == 3, "three one-hot planes");
+                uint2 *ab = argbits + ((((long long)blockIdx.y * g.n_lines + item) * 7 + wave) * 3) * 64 + lane;
+                const uint2 u1 = c1_plane_words(ue[1], uo[1]), u2 = c1_plane_words(ue[2], uo[2]);
+                ab[0] = make_uint2(alive.x & ~(u1.x | u2.x), alive.y & ~(u1.y | u2.y));
+                ab[64] = make_uint2(alive.x & u1.x & ~u2.x, alive.y & u1.y & ~u2.y);
+                ab[128] = make_uint2(alive.x & u2.x, alive.y & u2.y);
             }
         }
+        if (!has_next) break;
+        // the other patch buffer was last read one segment ago, before that segment's barrier
+        K::patch_store(lds + ((it + 1) & 1) * PATCH_SLOT, g, tid, pre);
+        __syncthreads();
+        item = next;
     }
 }
 
@@ -307,31 +414,43 @@ k_conv1_pool_fwd(const T *__restrict__ x, const float *__restrict__ w, const flo
 // part of the loop is the relu variant's, unchanged.
 template <typename T, int KH, int KW, int PH, bool PRELU>
 __global__ void __launch_bounds__(448) __attribute__((amdgpu_waves_per_eu(2, 2)))
-k_conv1_pool_bwd(const T *__restrict__ x, const T *__restrict__ dout, const T *__restrict__ pre_sel, const uint4 *__restrict__ argbits,
+k_conv1_pool_bwd(const T *__restrict__ x, const T *__restrict__ dout, const T *__restrict__ pre_sel, const uint2 *__restrict__ argbits,
                  float *__restrict__ dw, float *__restrict__ dbias, float *__restrict__ dalpha, const C1Geom g)
 {
     typedef C1<T, KH, KW, PH> K;
-    constexpr int DP_PITCH = 4 * 32 * 2 + 16;                     // one dpool row of this column tile: 4 components x 32 filters (+ pad)
-    constexpr int DP_BYTES = 7 * 32 * DP_PITCH;
-    constexpr int AW_BYTES = PRELU ? 7 * 64 * 16 : 0;             // the waves' arg-max words
-    __shared__ __attribute__((aligned(16))) char lds[K::PATCH_BYTES + DP_BYTES + AW_BYTES + (PRELU ? 256 : 0)];
-    float *dal_s = reinterpret_cast<float *>(lds + K::PATCH_BYTES + DP_BYTES + AW_BYTES);     // PRELU: 64 slope-gradient sums
+    // a wave's dpool tile: [component 4][position 32][filter 32] 16-bit values, rows of 64 bytes (four rows = all 64 banks: the
+    // transposing reads below are conflict free), components 64 bytes askew (so are the 16-byte staging stores)
+    constexpr int DP_COMP = 32 * 64 + 64, DP_WAVE = 4 * DP_COMP;
+    constexpr int DP_BYTES = 7 * DP_WAVE;
+    constexpr int ONES_BYTES = C1_PW * 8;                         // a patch row of (1, 0, 0, 0): the bias gradient's "tap" (below)
+    constexpr int PATCH_SLOT = (K::PATCH_BYTES + 15) / 16 * 16;
+    constexpr int AW_BYTES = PRELU ? 7 * 64 * 24 : 0;             // the waves' arg-max planes
+    __shared__ __attribute__((aligned(16))) char lds[PATCH_SLOT + ONES_BYTES + DP_BYTES + AW_BYTES + (PRELU ? 256 : 0)];
+    constexpr int DP_AT = PATCH_SLOT + ONES_BYTES, AW_AT = DP_AT + DP_BYTES;
+    float *dal_s = reinterpret_cast<float *>(lds + AW_AT + AW_BYTES);                           // PRELU: 64 slope-gradient sums
     if (PRELU && threadIdx.x < 64) dal_s[threadIdx.x] = 0.f;       // (the loop's first barrier orders it)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 31, lh = lane >> 5;
     const int j0 = blockIdx.y * 32;
-    // backward A operand (x^T): this lane's row = tap lr & 15 (lanes 16 - 31 repeat them; their accumulator rows are ignored)
-    const int my_tap_off = K::tap_off(lr & 15);
+    for (int e = tid; e < C1_PW; e += 448)
+        *reinterpret_cast<uint2 *>(lds + PATCH_SLOT + e * 8) = make_uint2(c1_pack(T(), 1.f, 0.f), 0u);
+    // backward A operand (x^T): this lane's row = tap lr (rows 0 - 14).  Row 16 reads the row of ones instead (component 0
+    // only): accumulator row 16 of part b is then sum over positions of dy_b -- the BIAS gradient comes out of the same MFMAs
+    // (it was two conversions and two adds per element).  Rows 17 - 31 repeat it and are ignored, row 15 is the zero tap.
+    const int my_tap_off = lr < 16 ? K::tap_off(lr) : PATCH_SLOT;
+    const int my_fi_pitch = lr < 16 ? C1_PW * 8 : 0;
     floatx16 dwacc[4];                                            // [part p]: rows = taps, columns = filters
-    float dbacc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int p = 0; p < 4; ++p)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dwacc[p][r] = 0.f;
+    // transposing read (ds_read_b64_tr_b16): lane L of a 16-lane group addresses row L >> 2, filters 4 (L & 3) .. + 3 of the
+    // group's 16 filters and receives ITS filter at the group's four rows: a lane's dy fragment of one 16-deep K step is two
+    // such reads (rows 16 s + 4 lh + 0..3 and + 8..11: the accumulator order of the forward, which the arg-max planes are in)
+    const int tr_off = DP_AT + wave * DP_WAVE + (4 * lh + ((lane & 15) >> 2)) * 64 + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
 
     // Persistent: a workgroup walks over pooled line segments and keeps the gradients in registers (one flush of 2 K
-    // atomics per workgroup instead of per segment).  `item` is made opaque so that no per-segment address is
-    // hoisted out of the loop as a loop invariant (that cost ~50 spilled registers).
+    // atomics per workgroup instead of per segment).
 #pragma unroll 1
     for (int item0 = blockIdx.x; item0 < g.n_lines; item0 += gridDim.x) {
         int item = item0;
@@ -340,46 +459,52 @@ k_conv1_pool_bwd(const T *__restrict__ x, const T *__restrict__ dout, const T *_
         const int ho = line % g.Ho, n = line / g.Ho;
         const int t0 = chunk * C1_TW;
         __syncthreads();                                          // the previous segment's LDS reads are done
-        K::stage_patch(x, lds, g, n, ho, t0, tid, 448);
+        K::stage_patch(x, lds, g, n, ho, t0, tid);
         // this wave's dpool tile: 32 positions x (4 x 32) channels, rows past W are zero
-        char *dp = lds + K::PATCH_BYTES + wave * (32 * DP_PITCH);
+        char *dp = lds + DP_AT + wave * DP_WAVE;
         const int tw = t0 + wave * 32;
-        uint4 aw = make_uint4(~0u, ~0u, ~0u, ~0u);                // 3 everywhere: nothing flows
-        if (tw < g.W) aw = argbits[(((long long)blockIdx.y * g.n_lines + item) * 7 + wave) * 64 + lane];
+        uint2 X[3] = {make_uint2(0u, 0u), make_uint2(0u, 0u), make_uint2(0u, 0u)};          // no plane set: nothing flows
+        if (tw < g.W) {
+            const uint2 *ab = argbits + ((((long long)blockIdx.y * g.n_lines + item) * 7 + wave) * 3) * 64 + lane;
+            X[0] = ab[0]; X[1] = ab[64]; X[2] = ab[128];
+        }
         float a3[3] = {0.f, 0.f, 0.f}, dal3[3] = {0.f, 0.f, 0.f};
         if constexpr (PRELU) {
             // (a wave's own LDS accesses execute in order: the reads below see these writes without a barrier)
-            *reinterpret_cast<uint4 *>(lds + K::PATCH_BYTES + DP_BYTES + (wave * 64 + lane) * 16) = aw;
+            unsigned *awp = reinterpret_cast<unsigned *>(lds + AW_AT + (wave * 64 + lane) * 24);
+            awp[0] = X[0].x; awp[1] = X[0].y; awp[2] = X[1].x; awp[3] = X[1].y; awp[4] = X[2].x; awp[5] = X[2].y;
 #pragma unroll
             for (int fi = 0; fi < 3; ++fi) a3[fi] = g.alpha[g.alpha_len > 1 ? min(PH * ho + fi, g.alpha_len - 1) : 0];
         }
-#pragma unroll 2
-        for (int u0 = lane; u0 < 32 * 16; u0 += 64) {              // 16-byte units: row u / 16, (component, 8 filters) u % 16
-            int u = u0;
-            asm volatile("" : "+v"(u));                            // (opaque: the per-iteration addresses must not be hoisted out
-                                                                   //  of the persistent loop as eight 64-bit values -- they spilled)
+        const T *line_in = dout + (((long long)n * g.Ho + ho) * g.W) * (4 * g.F) + j0;          // (wave-uniform)
+        const T *line_pre = PRELU ? pre_sel + (((long long)n * g.Ho + ho) * g.W) * (4 * g.F) + j0 : nullptr;
+#pragma unroll
+        for (int u0 = 0; u0 < 8; ++u0) {                           // 16-byte units: row u / 16, (component, 8 filters) u % 16
+            const int u = lane + 64 * u0;
             const int row = u >> 4, q = u & 15, b = q >> 2, sub = (q & 3) * 8;
             uint4 v = make_uint4(0u, 0u, 0u, 0u);
             if (tw + row < g.W) {
-                const long long o = (((long long)n * g.Ho + ho) * g.W + tw + row) * (4 * g.F) + b * g.F + j0 + sub;
-                v = *reinterpret_cast<const uint4 *>(dout + o);
+                const unsigned o = (unsigned)((tw + row) * (4 * g.F) + b * g.F + sub);
+                v = *reinterpret_cast<const uint4 *>(line_in + o);
                 if constexpr (PRELU) {
-                    const uint4 pv = *reinterpret_cast<const uint4 *>(pre_sel + o);
+                    const uint4 pv = *reinterpret_cast<const uint4 *>(line_pre + o);
                     // element (row, filter sub + e) sits in lane (sub + e) + 32 lh', register r' of the accumulator layout
-                    const int r2 = 2 * ((row & 3) + 4 * (row >> 3));
-                    const char *awb = lds + K::PATCH_BYTES + DP_BYTES + (wave * 64 + 32 * ((row >> 2) & 1) + sub) * 16 + b * 4;
+                    const int rr = (row & 3) + 4 * (row >> 3);
+                    const int bit = 8 * (1 - (b & 1)) + (rr >> 1) + 16 * (rr & 1);
+                    const char *awb = lds + AW_AT + (wave * 64 + 32 * ((row >> 2) & 1) + sub) * 24 + (b >> 1) * 4;
                     unsigned dv[4] = {v.x, v.y, v.z, v.w}, pw[4] = {pv.x, pv.y, pv.z, pv.w};
 #pragma unroll
                     for (int e = 0; e < 8; e += 2) {
                         float gq[2];
 #pragma unroll
                         for (int h = 0; h < 2; ++h) {
-                            const unsigned arg = (*reinterpret_cast<const unsigned *>(awb + (e + h) * 16) >> r2) & 3u;
+                            const unsigned *pl = reinterpret_cast<const unsigned *>(awb + (e + h) * 24);
+                            const bool is0 = (pl[0] >> bit) & 1u, is1 = (pl[2] >> bit) & 1u, is2 = (pl[4] >> bit) & 1u;
                             const unsigned short db_ = (unsigned short)(dv[e >> 1] >> (16 * h)), pb_ = (unsigned short)(pw[e >> 1] >> (16 * h));
                             const float d = to_f32(__builtin_bit_cast(T, db_)), pr = to_f32(__builtin_bit_cast(T, pb_));
-                            const float al = arg == 0 ? a3[0] : arg == 1 ? a3[1] : a3[2];
+                            const float al = is0 ? a3[0] : is1 ? a3[1] : a3[2];
                             const float hneg = d * fminf(pr, 0.f);
-                            dal3[0] += arg == 0 ? hneg : 0.f; dal3[1] += arg == 1 ? hneg : 0.f; dal3[2] += arg == 2 ? hneg : 0.f;
+                            dal3[0] += is0 ? hneg : 0.f; dal3[1] += is1 ? hneg : 0.f; dal3[2] += is2 ? hneg : 0.f;
                             gq[h] = d * (pr > 0.f ? 1.f : (pr < 0.f ? al : 0.f));
                         }
                         dv[e >> 1] = c1_pack(T(), gq[0], gq[1]);
@@ -387,7 +512,7 @@ k_conv1_pool_bwd(const T *__restrict__ x, const T *__restrict__ dout, const T *_
                     v = make_uint4(dv[0], dv[1], dv[2], dv[3]);
                 }
             }
-            *reinterpret_cast<uint4 *>(dp + row * DP_PITCH + (b * 32 + sub) * 2) = v;
+            *reinterpret_cast<uint4 *>(dp + b * DP_COMP + row * 64 + sub * 2) = v;
         }
         if constexpr (PRELU) {
             if (dalpha) {                                          // wave sums -> one LDS atomic per (wave, window row)
@@ -400,13 +525,24 @@ k_conv1_pool_bwd(const T *__restrict__ x, const T *__restrict__ dout, const T *_
                 }
             }
         }
-        const unsigned argw[4] = {aw.x, aw.y, aw.z, aw.w};
         __syncthreads();
         const int n_fi = tw < g.W ? min(PH, g.H - PH * ho) : 0;
-        // accumulator row 4 lh + ..., column lr of this wave's tile, as ONE opaque LDS byte offset (a pointer would turn
-        // generic behind the asm and cost flat loads with 64-bit addresses)
-        int dp_off = K::PATCH_BYTES + wave * (32 * DP_PITCH) + 4 * lh * DP_PITCH + lr * 2;
-        asm volatile("" : "+v"(dp_off));
+        // the pooled gradient of this lane's filter in K (= accumulator) order: D[b][s], read ONCE for the three window rows
+        uint4 D[4][2];
+        if (n_fi > 0) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    typedef short v4s __attribute__((ext_vector_type(4)));
+                    typedef __attribute__((address_space(3))) v4s lds_v4s;
+                    const char *src = lds + tr_off + b * DP_COMP + (16 * s) * 64;
+                    const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s *)(src));
+                    const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s *)(src + 8 * 64));
+                    const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+                    D[b][s] = make_uint4(l2.x, l2.y, h2.x, h2.y);
+                }
+        }
 #pragma unroll 1
         for (int fi = 0; fi < n_fi; ++fi) {                        // dy of row tile fi (where fi is the window's arg-max), dW += x^T dy
             // x^T fragments: row = this lane's tap, K slot i of step s = position 16 s + 4 lh + (i & 3) + 8 (i >> 2)
@@ -414,31 +550,26 @@ k_conv1_pool_bwd(const T *__restrict__ x, const T *__restrict__ dout, const T *_
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 uint2 v[8];
-                const char *xb = lds + (wave * 32 + 16 * s + 4 * lh) * 8 + fi * (C1_PW * 8) + my_tap_off;
+                const char *xb = lds + (wave * 32 + 16 * s + 4 * lh) * 8 + fi * my_fi_pitch + my_tap_off;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const uint2 *>(xb + ((i & 3) + 8 * (i >> 2)) * 8);
                 K::split4(v, XT[s]);
             }
+            const uint2 Xf = fi == 0 ? X[0] : fi == 1 ? X[1] : X[2];
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
-                __builtin_amdgcn_sched_barrier(0);                 // (one component at a time: all 64 LDS reads hoisted up front spill)
-                unsigned d[8];                                     // dy of component b, K = positions in accumulator order
-                float sum = 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; r += 2) {
-                    // (one per-lane base + compile-time offsets: 64 separately hoisted addresses spilled)
-                    const char *src = lds + dp_off + ((r & 3) + 8 * (r >> 2)) * DP_PITCH + b * 64;
-                    const unsigned v0 = *reinterpret_cast<const unsigned short *>(src);
-                    const unsigned v1 = *reinterpret_cast<const unsigned short *>(src + DP_PITCH);
-                    const unsigned g0 = ((argw[b] >> (2 * r)) & 3u) == (unsigned)fi ? v0 : 0u;
-                    const unsigned g1 = ((argw[b] >> (2 * r + 2)) & 3u) == (unsigned)fi ? v1 : 0u;
-                    d[r >> 1] = g0 | (g1 << 16);
-                    sum += to_f32(__builtin_bit_cast(T, (unsigned short)g0)) + to_f32(__builtin_bit_cast(T, (unsigned short)g1));
-                }
-                dbacc[b] += sum;
+                const unsigned xw = (b >> 1) ? Xf.y : Xf.x;
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    const uint4 dy = make_uint4(d[4 * s], d[4 * s + 1], d[4 * s + 2], d[4 * s + 3]);
+                    const unsigned dd[4] = {D[b][s].x, D[b][s].y, D[b][s].z, D[b][s].w};
+                    unsigned d[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {                  // registers 8 s + 2 i, + 1: pair j = 4 s + i
+                        typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+                        const unsigned m = (xw >> (8 * (1 - (b & 1)) + 4 * s + i)) & 0x00010001u;
+                        d[i] = __builtin_bit_cast(unsigned, __builtin_bit_cast(us2, dd[i]) * __builtin_bit_cast(us2, m));
+                    }
+                    const uint4 dy = make_uint4(d[0], d[1], d[2], d[3]);
                     const uint4 dyn = c1_neg(dy);
 #pragma unroll
                     for (int a = 0; a < 4; ++a) {
@@ -456,16 +587,19 @@ k_conv1_pool_bwd(const T *__restrict__ x, const T *__restrict__ dout, const T *_
         }
     }
     // ---- flush: every wave parks its gradients in its own LDS slab (taps = accumulator rows 0 .. 15 = registers 0 .. 7,
-    // columns = filters), the workgroup sums the seven slabs and issues one atomic per element
+    // the bias sums = row 16 = register 8 of the lanes lh == 0; columns = filters), the workgroup sums the seven slabs and
+    // issues one atomic per element
     __syncthreads();
     constexpr int SLAB = 4 * 16 * 32 + 4 * 64;                    // [part 4][tap 16][filter 32] + [component 4][lane 64] floats
+    static_assert(7 * SLAB * 4 <= (int)sizeof(lds), "flush slabs fit");
     float *slab = reinterpret_cast<float *>(lds) + wave * SLAB;
 #pragma unroll
     for (int p = 0; p < 4; ++p)
 #pragma unroll
         for (int r = 0; r < 8; ++r) slab[(p * 16 + mfma32_row(r, lane)) * 32 + lr] = dwacc[p][r];
 #pragma unroll
-    for (int b = 0; b < 4; ++b) slab[4 * 16 * 32 + b * 64 + lane] = dbacc[b];
+    for (int b = 0; b < 4; ++b) slab[4 * 16 * 32 + b * 64 + lane] = lh == 0 ? dwacc[b][8] : 0.f;     // (a = 0 carries no sign: kSignConv bits 0 - 3)
+    static_assert((kSignConv & 0xFu) == 0u, "component 0 of x enters every part with +");
     __syncthreads();
     const float *all = reinterpret_cast<const float *>(lds);
     for (int e = tid; e < 4 * 16 * 32; e += 448) {
@@ -489,16 +623,18 @@ int run_conv1_pool(bool backward, const void *x, const float *w, const float *bi
                    float *dbias, float *dalpha, const C1Geom &g, hipStream_t stream)
 {
     if (!backward) {
-        dim3 grid((unsigned)g.n_lines, (unsigned)(g.F / 32), 1);
+        int blocks = device_cu_count();                            // persistent, 159 - 239 registers: one 7-wave workgroup per CU
+        if (blocks > g.n_lines) blocks = g.n_lines;
+        dim3 grid((unsigned)blocks, (unsigned)(g.F / 32), 1);
         hipLaunchKernelGGL((k_conv1_pool_fwd<T, 3, 5, 3, PRELU>), grid, dim3(448), 0, stream, (const T *)x, w, bias, (T *)const_cast<void *>(io),
-                           (T *)const_cast<void *>(pre), (uint4 *)argbits, g);
+                           (T *)const_cast<void *>(pre), (uint2 *)argbits, g);
     } else {
         int blocks = 2 * device_cu_count();                        // 70 - 78 KB of LDS: two workgroups per CU
         if (blocks > g.n_lines) blocks = g.n_lines;
         if (debug_flags() & kDbgDeterministic) blocks = 1;         // one flush per gradient element: no order-dependent sums
         dim3 grid((unsigned)blocks, (unsigned)(g.F / 32), 1);
         hipLaunchKernelGGL((k_conv1_pool_bwd<T, 3, 5, 3, PRELU>), grid, dim3(448), 0, stream, (const T *)x, (const T *)io, (const T *)pre,
-                           (const uint4 *)argbits, dw, dbias, dalpha, g);
+                           (const uint2 *)argbits, dw, dbias, dalpha, g);
     }
     return hipGetLastError() == hipSuccess ? 0 : QK_ERR_LAUNCH;
 }
@@ -512,7 +648,7 @@ int run_conv1_pool(bool backward, const void *x, const float *w, const float *bi
 size_t conv1_pool_argbits_bytes(int N, int H, int W, int F)
 {
     const long long lines = (long long)N * ((H + 2) / 3) * ((W + C1_TW - 1) / C1_TW);
-    return (size_t)(lines * (F / 32) * 7 * 64 * 16);
+    return (size_t)(lines * (F / 32) * 7 * 64 * 24);
 }
 
 int launch_conv1_pool(int dtype, bool backward, const void *x, const float *w, const float *bias, const void *io, void *argbits,
