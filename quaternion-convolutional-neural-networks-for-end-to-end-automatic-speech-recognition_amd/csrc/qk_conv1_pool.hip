@@ -450,7 +450,32 @@ k_conv1_pool_bwd(const T *__restrict__ x, const T *__restrict__ dout, const T *_
     const int tr_off = DP_AT + wave * DP_WAVE + (4 * lh + ((lane & 15) >> 2)) * 64 + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
 
     // Persistent: a workgroup walks over pooled line segments and keeps the gradients in registers (one flush of 2 K
-    // atomics per workgroup instead of per segment).
+    // atomics per workgroup instead of per segment).  The relu form has the NEXT segment's x patch, pooled gradient and planes
+    // in flight (50 registers) under this segment's MFMAs; the PReLU form (which turns dpool into dy while staging, with the
+    // pre-activations beside it) loads and stores back to back.
+    typename K::Pre pre_patch;
+    uint4 pre_dp[8];
+    uint2 pre_X[3];
+    auto load_item = [&](int item) {
+        const int chunk = item % g.n_chunks, line = item / g.n_chunks;
+        const int ho = line % g.Ho, n = line / g.Ho;
+        const int t0 = chunk * C1_TW, tw = t0 + wave * 32;
+        K::patch_load(x, g, n, ho, t0, tid, pre_patch);
+        pre_X[0] = pre_X[1] = pre_X[2] = make_uint2(0u, 0u);                                   // no plane set: nothing flows
+        if (tw < g.W) {
+            const uint2 *ab = argbits + ((((long long)blockIdx.y * g.n_lines + item) * 7 + wave) * 3) * 64 + lane;
+            pre_X[0] = ab[0]; pre_X[1] = ab[64]; pre_X[2] = ab[128];
+        }
+        const T *line_in = dout + (((long long)n * g.Ho + ho) * g.W) * (4 * g.F) + j0;          // (wave-uniform)
+#pragma unroll
+        for (int u0 = 0; u0 < 8; ++u0) {                           // 16-byte units: row u / 16, (component, 8 filters) u % 16
+            const int u = lane + 64 * u0;
+            const int row = u >> 4, q = u & 15, b = q >> 2, sub = (q & 3) * 8;
+            pre_dp[u0] = make_uint4(0u, 0u, 0u, 0u);               // rows past W are zero
+            if (tw + row < g.W) pre_dp[u0] = *reinterpret_cast<const uint4 *>(line_in + (unsigned)((tw + row) * (4 * g.F) + b * g.F + sub));
+        }
+    };
+    if (!PRELU && (int)blockIdx.x < g.n_lines) load_item(blockIdx.x);
 #pragma unroll 1
     for (int item0 = blockIdx.x; item0 < g.n_lines; item0 += gridDim.x) {
         int item = item0;
@@ -458,16 +483,13 @@ k_conv1_pool_bwd(const T *__restrict__ x, const T *__restrict__ dout, const T *_
         const int chunk = item % g.n_chunks, line = item / g.n_chunks;
         const int ho = line % g.Ho, n = line / g.Ho;
         const int t0 = chunk * C1_TW;
-        __syncthreads();                                          // the previous segment's LDS reads are done
-        K::stage_patch(x, lds, g, n, ho, t0, tid);
-        // this wave's dpool tile: 32 positions x (4 x 32) channels, rows past W are zero
+        // this wave's dpool tile: 32 positions x (4 x 32) channels
         char *dp = lds + DP_AT + wave * DP_WAVE;
         const int tw = t0 + wave * 32;
-        uint2 X[3] = {make_uint2(0u, 0u), make_uint2(0u, 0u), make_uint2(0u, 0u)};          // no plane set: nothing flows
-        if (tw < g.W) {
-            const uint2 *ab = argbits + ((((long long)blockIdx.y * g.n_lines + item) * 7 + wave) * 3) * 64 + lane;
-            X[0] = ab[0]; X[1] = ab[64]; X[2] = ab[128];
-        }
+        __syncthreads();                                          // the previous segment's LDS reads are done
+        if constexpr (PRELU) load_item(item);
+        K::patch_store(lds, g, tid, pre_patch);
+        const uint2 X[3] = {pre_X[0], pre_X[1], pre_X[2]};
         float a3[3] = {0.f, 0.f, 0.f}, dal3[3] = {0.f, 0.f, 0.f};
         if constexpr (PRELU) {
             // (a wave's own LDS accesses execute in order: the reads below see these writes without a barrier)
@@ -476,18 +498,15 @@ k_conv1_pool_bwd(const T *__restrict__ x, const T *__restrict__ dout, const T *_
 #pragma unroll
             for (int fi = 0; fi < 3; ++fi) a3[fi] = g.alpha[g.alpha_len > 1 ? min(PH * ho + fi, g.alpha_len - 1) : 0];
         }
-        const T *line_in = dout + (((long long)n * g.Ho + ho) * g.W) * (4 * g.F) + j0;          // (wave-uniform)
         const T *line_pre = PRELU ? pre_sel + (((long long)n * g.Ho + ho) * g.W) * (4 * g.F) + j0 : nullptr;
 #pragma unroll
-        for (int u0 = 0; u0 < 8; ++u0) {                           // 16-byte units: row u / 16, (component, 8 filters) u % 16
+        for (int u0 = 0; u0 < 8; ++u0) {
             const int u = lane + 64 * u0;
             const int row = u >> 4, q = u & 15, b = q >> 2, sub = (q & 3) * 8;
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (tw + row < g.W) {
-                const unsigned o = (unsigned)((tw + row) * (4 * g.F) + b * g.F + sub);
-                v = *reinterpret_cast<const uint4 *>(line_in + o);
-                if constexpr (PRELU) {
-                    const uint4 pv = *reinterpret_cast<const uint4 *>(line_pre + o);
+            uint4 v = pre_dp[u0];
+            if constexpr (PRELU) {
+                if (tw + row < g.W) {
+                    const uint4 pv = *reinterpret_cast<const uint4 *>(line_pre + (unsigned)((tw + row) * (4 * g.F) + b * g.F + sub));
                     // element (row, filter sub + e) sits in lane (sub + e) + 32 lh', register r' of the accumulator layout
                     const int rr = (row & 3) + 4 * (row >> 3);
                     const int bit = 8 * (1 - (b & 1)) + (rr >> 1) + 16 * (rr & 1);
@@ -526,6 +545,9 @@ k_conv1_pool_bwd(const T *__restrict__ x, const T *__restrict__ dout, const T *_
             }
         }
         __syncthreads();
+        if constexpr (!PRELU) {
+            if (item0 + (int)gridDim.x < g.n_lines) load_item(item0 + (int)gridDim.x);
+        }
         const int n_fi = tw < g.W ? min(PH, g.H - PH * ho) : 0;
         // the pooled gradient of this lane's filter in K (= accumulator) order: D[b][s], read ONCE for the three window rows
         uint4 D[4][2];
@@ -629,7 +651,7 @@ int run_conv1_pool(bool backward, const void *x, const float *w, const float *bi
         hipLaunchKernelGGL((k_conv1_pool_fwd<T, 3, 5, 3, PRELU>), grid, dim3(448), 0, stream, (const T *)x, w, bias, (T *)const_cast<void *>(io),
                            (T *)const_cast<void *>(pre), (uint2 *)argbits, g);
     } else {
-        int blocks = 2 * device_cu_count();                        // 70 - 78 KB of LDS: two workgroups per CU
+        int blocks = device_cu_count();                            // persistent, > 200 registers: one 7-wave workgroup per CU
         if (blocks > g.n_lines) blocks = g.n_lines;
         if (debug_flags() & kDbgDeterministic) blocks = 1;         // one flush per gradient element: no order-dependent sums
         dim3 grid((unsigned)blocks, (unsigned)(g.F / 32), 1);
