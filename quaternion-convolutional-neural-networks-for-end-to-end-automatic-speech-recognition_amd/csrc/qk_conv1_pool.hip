@@ -18,6 +18,7 @@
 //                  dy of row tile fi = dpool where fi is the window's arg-max (first maximum wins) and max + bias > 0.
 // Fragments are assembled from 8-byte LDS reads (all four components of one position) with v_perm_b32.
 #include "qk_common.h"
+#include <type_traits>
 
 namespace qk {
 namespace {
@@ -83,58 +84,77 @@ struct C1 {
     // stores); odd W or an odd first position falls back to one position per load.
     static constexpr int HALF = C1_PW / 2;
     static_assert(C1_PW % 2 == 0, "patch width in position pairs");
-    static constexpr int PRE_IT = (NR * C1_PW + 447) / 448;        // units per thread, channels_last (8 bytes each); planes: 16 bytes each
-    struct Pre { unsigned v[PRE_IT][4]; };
-    static __device__ __forceinline__ void patch_load(const T *__restrict__ x, const C1Geom &g, int n, int ho, int t0, int tid, Pre &p)
+    // NT = the threads that share the staging: the workgroup's 448 (backward), or the 64 of the forward's loader wave
+    template <int NT>
+    struct Pre {
+        static constexpr int IT_CL = (NR * C1_PW + NT - 1) / NT;   // units per thread, channels_last (8 bytes each)
+        static constexpr int IT_PL = (NR * HALF + NT - 1) / NT;    // planes (16 bytes each)
+        static constexpr int WORDS = 2 * IT_CL > 4 * IT_PL ? 2 * IT_CL : 4 * IT_PL;
+        unsigned v[WORDS];
+    };
+    template <int NT>
+    static __device__ __forceinline__ void patch_load(const T *__restrict__ x, const C1Geom &g, int n, int ho, int t0, int tid, Pre<NT> &p)
     {
         const int f_lo = PH * ho - PADH;
         if (g.x_planes) {
-            const bool pairs = ((g.W | (t0 - PADW)) & 1) == 0;             // both positions of a pair share the 4-byte word
             const long long plane = (long long)g.H * g.W;
+            if (((g.W | (t0 - PADW)) & 1) == 0) {
+                // both positions of a pair share a 4-byte word, and (W, first position even) a pair is inside or outside the tensor
+                // as a whole: ONE predicated set of loads per unit -- a per-lane fallback inside this branch would run for every
+                // wave that holds a border lane, with its waits (it did: the prefetch was serialised behind vmcnt(0))
 #pragma unroll
-            for (int it = 0; it < (NR * HALF + 447) / 448; ++it) {
-                const int e = tid + it * 448;
+                for (int it = 0; it < Pre<NT>::IT_PL; ++it) {
+                    const int e = tid + it * NT;
+                    const int r = e / HALF, c2 = e - r * HALF;
+                    const int f = f_lo + r, t = t0 - PADW + 2 * c2;
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) p.v[4 * it + a] = 0u;       // plane a: positions t (low half), t + 1 (high half)
+                    if (e < NR * HALF && f >= 0 && f < g.H && t >= 0 && t < g.W) {
+                        const T *row = x + ((long long)n * 4 * g.H + f) * g.W;
+#pragma unroll
+                        for (int a = 0; a < 4; ++a) p.v[4 * it + a] = *reinterpret_cast<const unsigned *>(row + a * plane + t);   // four loads in flight
+                    }
+                }
+                return;
+            }
+#pragma unroll
+            for (int it = 0; it < Pre<NT>::IT_PL; ++it) {                   // odd W or an odd first position: one position per load
+                const int e = tid + it * NT;
                 const int r = e / HALF, c2 = e - r * HALF;
                 const int f = f_lo + r, t = t0 - PADW + 2 * c2;
 #pragma unroll
-                for (int a = 0; a < 4; ++a) p.v[it][a] = 0u;               // plane a: positions t (low half), t + 1 (high half)
-                if (e < NR * HALF && f >= 0 && f < g.H) {
-                    const T *row = x + ((long long)n * 4 * g.H + f) * g.W;
-                    if (pairs && t >= 0 && t + 1 < g.W) {
-#pragma unroll
-                        for (int a = 0; a < 4; ++a) p.v[it][a] = *reinterpret_cast<const unsigned *>(row + a * plane + t);   // four loads in flight
-                    } else {
-#pragma unroll
-                        for (int a = 0; a < 4; ++a) {
-                            unsigned lo = 0u, hi = 0u;
-                            if (t >= 0 && t < g.W) lo = __builtin_bit_cast(unsigned short, row[a * plane + t]);
-                            if (t + 1 >= 0 && t + 1 < g.W) hi = __builtin_bit_cast(unsigned short, row[a * plane + t + 1]);
-                            p.v[it][a] = lo | (hi << 16);
-                        }
+                for (int a = 0; a < 4; ++a) {
+                    unsigned lo = 0u, hi = 0u;
+                    if (e < NR * HALF && f >= 0 && f < g.H) {
+                        const T *row = x + ((long long)n * 4 * g.H + f) * g.W;
+                        if (t >= 0 && t < g.W) lo = __builtin_bit_cast(unsigned short, row[a * plane + t]);
+                        if (t + 1 >= 0 && t + 1 < g.W) hi = __builtin_bit_cast(unsigned short, row[a * plane + t + 1]);
                     }
+                    p.v[4 * it + a] = lo | (hi << 16);
                 }
             }
             return;
         }
 #pragma unroll
-        for (int it = 0; it < PRE_IT; ++it) {
-            const int e = tid + it * 448;
+        for (int it = 0; it < Pre<NT>::IT_CL; ++it) {
+            const int e = tid + it * NT;
             const int r = e / C1_PW, c = e - r * C1_PW;
             const int f = f_lo + r, t = t0 - PADW + c;
             uint2 v = make_uint2(0u, 0u);
             if (e < NR * C1_PW && f >= 0 && f < g.H && t >= 0 && t < g.W)
                 v = *reinterpret_cast<const uint2 *>(x + (((long long)n * g.H + f) * g.W + t) * 4);
-            p.v[it][0] = v.x; p.v[it][1] = v.y;
+            p.v[2 * it] = v.x; p.v[2 * it + 1] = v.y;
         }
     }
-    static __device__ __forceinline__ void patch_store(char *patch, const C1Geom &g, int tid, const Pre &p)
+    template <int NT>
+    static __device__ __forceinline__ void patch_store(char *patch, const C1Geom &g, int tid, const Pre<NT> &p)
     {
         if (g.x_planes) {
 #pragma unroll
-            for (int it = 0; it < (NR * HALF + 447) / 448; ++it) {
-                const int e = tid + it * 448;
+            for (int it = 0; it < Pre<NT>::IT_PL; ++it) {
+                const int e = tid + it * NT;
                 if (e < NR * HALF) {
-                    const unsigned *w4 = p.v[it];
+                    const unsigned *w4 = p.v + 4 * it;
                     // [position][component] image: two 8-byte stores (r | i, j | k of position t, then of position t + 1)
                     const uint2 p0 = make_uint2(__builtin_amdgcn_perm(w4[1], w4[0], 0x05040100u), __builtin_amdgcn_perm(w4[3], w4[2], 0x05040100u));
                     const uint2 p1 = make_uint2(__builtin_amdgcn_perm(w4[1], w4[0], 0x07060302u), __builtin_amdgcn_perm(w4[3], w4[2], 0x07060302u));
@@ -145,16 +165,10 @@ struct C1 {
             return;
         }
 #pragma unroll
-        for (int it = 0; it < PRE_IT; ++it) {
-            const int e = tid + it * 448;
-            if (e < NR * C1_PW) *reinterpret_cast<uint2 *>(patch + e * 8) = make_uint2(p.v[it][0], p.v[it][1]);
+        for (int it = 0; it < Pre<NT>::IT_CL; ++it) {
+            const int e = tid + it * NT;
+            if (e < NR * C1_PW) *reinterpret_cast<uint2 *>(patch + e * 8) = make_uint2(p.v[2 * it], p.v[2 * it + 1]);
         }
-    }
-    static __device__ __forceinline__ void stage_patch(const T *__restrict__ x, char *patch, const C1Geom &g, int n, int ho, int t0, int tid)
-    {
-        Pre p;
-        patch_load(x, g, n, ho, t0, tid, p);
-        patch_store(patch, g, tid, p);
     }
     // byte offset (relative to the lane's position) of tap k inside the patch; taps >= TAPS are clamped (their B row is zero)
     static __device__ __forceinline__ int tap_off(int k)
@@ -195,26 +209,13 @@ struct C1 {
             B[p] = make_uint4(d[0], d[1], d[2], d[3]);
         }
     }
-    // A fragments of row tile fi from the lane's 8 tap reads, then the conv values of component b: acc (32 positions x 32 filters)
+    // A fragments of row tile fi from the lane's 8 tap reads
     static __device__ __forceinline__ void tap_frags(const char *lane_base, const int (&toff)[8], int fi, uint4 (&A)[4])
     {
         uint2 v[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const uint2 *>(lane_base + fi * (C1_PW * 8) + toff[i]);
         split4(v, A);
-    }
-    template <int NBN>
-    static __device__ __forceinline__ floatx16 conv_b(const uint4 (&A)[4], const uint4 (&B)[4], const uint4 (&Bn)[NBN], int b)
-    {
-        floatx16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            const bool ng = (kSignConv >> (a * 4 + b)) & 1u;
-            acc = c1_mfma(T(), A[a], ng ? (NBN == 4 ? Bn[(a ^ b) % NBN] : c1_neg(B[a ^ b])) : B[a ^ b], acc);
-        }
-        return acc;
     }
 };
 
@@ -230,11 +231,15 @@ struct C1 {
 // issue: 30 VALU instructions per MFMA before).
 __device__ __forceinline__ void c1_max_shift_in(unsigned &w, float &m, float a)        // w = 2 w + (a > m);  m = max(m, a)
 {
-    // The compare is the COMPILER's instruction: it reads an MFMA result, and the wait states that takes are inserted for
-    // instructions the hazard recogniser can see -- inside an asm block they are not (a first version with the compare in the
-    // block read accumulator registers 14 / 15 of a tile before the MFMA had written them).  The block only consumes the lane mask.
-    const unsigned long long gt = __builtin_amdgcn_fcmpf(a, m, 2 /* ordered greater-than */);
-    asm("v_addc_co_u32_e64 %0, vcc, %0, %0, %2\n\tv_cndmask_b32_e64 %1, %1, %3, %2" : "+v"(w), "+v"(m) : "s"(gt), "v"(a) : "vcc");
+    // all VALU, no lane mask: the SIGN of m - a is the comparison (equal values give +0), v_alignbit_b32 shifts it in.
+    // (v_cmp + v_addc_co_u32 + v_cndmask is the same count, but goes through an SGPR pair per element; fmaxf() costs two more
+    //  v_max_f32 per call that only quiet signalling NaNs, and so does every builtin that folds to it: the maximum is an asm line.)
+    const float d = m - a;
+    w = __builtin_amdgcn_alignbit(w, __builtin_bit_cast(unsigned, d), 31);
+    // (d is an operand only to ORDER the block behind the subtraction: `a` is an MFMA result, and the wait states that takes are
+    //  inserted for instructions the hazard recogniser can see -- a first version that compared inside a block read accumulator
+    //  registers 14 / 15 of a tile before the MFMA had written them)
+    asm("v_max_f32 %0, %0, %1" : "+v"(m) : "v"(a), "v"(d));
 }
 __device__ __forceinline__ void c1_shift_in(unsigned &w, bool c) { w = (w << 1) | (c ? 1u : 0u); }
 __device__ __forceinline__ unsigned c1_relu_pk(unsigned pk)                              // relu of two packed bf16 / fp16: sign-magnitude, so max
@@ -257,7 +262,7 @@ __device__ __forceinline__ uint2 c1_plane_words(unsigned e, unsigned o)
 // Persistent: a workgroup walks over pooled line segments; the kernel fragments are built once, and the next segment's
 // patch is in flight (registers) under this segment's MFMAs, two patch buffers in LDS, one barrier per segment.
 template <typename T, int KH, int KW, int PH, bool PRELU>
-__global__ void __launch_bounds__(448) __attribute__((amdgpu_waves_per_eu(2, 2)))
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_conv1_pool_fwd(const T *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias, T *__restrict__ out,
                  T *__restrict__ pre_out, uint2 *__restrict__ argbits, const C1Geom g)
 {
@@ -270,36 +275,34 @@ k_conv1_pool_fwd(const T *__restrict__ x, const float *__restrict__ w, const flo
     const int j0 = blockIdx.y * 32;
     int item = blockIdx.x;                                        // (n, ho, chunk)
     if (item >= g.n_lines) return;
-    typename K::Pre pre;
-    {
-        const int chunk = item % g.n_chunks, line = item / g.n_chunks;
-        K::patch_load(x, g, line / g.Ho, line % g.Ho, chunk * C1_TW, tid, pre);
+    if (wave == 7) {
+        // The LOADER wave: it alone reads x and fills the patch buffers, one segment ahead of the seven waves that compute.  Its
+        // loads never queue behind the workgroup's output stores (one vmcnt counter per wave: with the loads in the computing
+        // waves, the wait for the next patch was a wait for the 32 stores issued after them as well).
+        typename K::template Pre<64> pre;
+#pragma unroll 1
+        for (int it = 0; item < g.n_lines; ++it, item += (int)gridDim.x) {
+            const int chunk = item % g.n_chunks, line = item / g.n_chunks;
+            K::patch_load(x, g, line / g.Ho, line % g.Ho, chunk * C1_TW, lane, pre);
+            K::patch_store(lds + (it & 1) * PATCH_SLOT, g, lane, pre);   // (this buffer's readers passed the barrier one segment ago)
+            __syncthreads();
+        }
+        return;
     }
-    uint4 B[4], Bn[PRELU ? 1 : 4];                                // (PRELU negates on the fly: it has no 16 registers to spare)
+    uint4 B[4];
     K::load_w(w, g.F, j0 + lr, lh, B);
-    if constexpr (!PRELU) {
-#pragma unroll
-        for (int p = 0; p < 4; ++p) Bn[p] = c1_neg(B[p]);
-    }
     int toff[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) toff[i] = K::tap_off(8 * lh + i);
     float bia4[4];
 #pragma unroll
     for (int b = 0; b < 4; ++b) bia4[b] = g.has_bias ? bias[b * g.F + j0 + lr] : 0.f;
-    K::patch_store(lds, g, tid, pre);
-    __syncthreads();
     char *ep = lds + 2 * PATCH_SLOT + wave * (32 * EP_PITCH);
     const int e_row = lane >> 2, e_chunk = lane & 3;
 
 #pragma unroll 1
-    for (int it = 0;; ++it) {
-        const int next = item + (int)gridDim.x;
-        const bool has_next = next < g.n_lines;
-        if (has_next) {
-            const int chunk = next % g.n_chunks, line = next / g.n_chunks;
-            K::patch_load(x, g, line / g.Ho, line % g.Ho, chunk * C1_TW, tid, pre);
-        }
+    for (int it = 0; item < g.n_lines; ++it, item += (int)gridDim.x) {
+        __syncthreads();                                          // patch `it` is in its buffer
         const int chunk = item % g.n_chunks, line = item / g.n_chunks;
         const int ho = line % g.Ho, n = line / g.Ho;
         const int t0 = chunk * C1_TW;
@@ -322,9 +325,13 @@ k_conv1_pool_fwd(const T *__restrict__ x, const float *__restrict__ w, const flo
             uint2 alive = PRELU ? make_uint2(~0u, ~0u) : make_uint2(0u, 0u);                    // in the stored layout
             T *line_out = out + (((long long)n * g.Ho + ho) * g.W) * (4 * g.F) + j0;           // (wave-uniform: 32-bit lane offsets below)
             T *line_pre = PRELU && pre_out ? pre_out + (((long long)n * g.Ho + ho) * g.W) * (4 * g.F) + j0 : nullptr;
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                floatx16 pooled = K::conv_b(A[0], B, Bn, b), presel;
+            // rows past W fall outside the line's buffer resource: their stores are dropped, no branch splits the schedule below
+            const unsigned line_bytes = (unsigned)((g.W * 4 * g.F - j0) * 2);
+            const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(line_out, 0, (int)line_bytes, 0x00020000);
+            const __amdgpu_buffer_rsrc_t pre_rs = __builtin_amdgcn_make_buffer_rsrc(PRELU && line_pre ? line_pre : line_out, 0, (int)line_bytes, 0x00020000);
+            // behind the MFMAs of one component b, first half: window rows 0 and 1
+            auto fin1 = [&](int b, const floatx16 &a0, const floatx16 &a1, floatx16 &pooled, floatx16 &presel, bool has1) {
+                pooled = a0;
                 if constexpr (PRELU) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
@@ -332,23 +339,40 @@ k_conv1_pool_fwd(const T *__restrict__ x, const float *__restrict__ w, const flo
                         pooled[r] = fmaxf(presel[r], 0.f) + af[0] * fminf(presel[r], 0.f);
                     }
                 }
+                if (!has1) return;
 #pragma unroll
-                for (int fi = 1; fi < PH; ++fi) {
-                    if (fi >= n_fi) break;
-                    const floatx16 acc = K::conv_b(A[fi], B, Bn, b);
+                for (int r = 15; r >= 0; --r) {
+                    unsigned &u = (r & 1) ? uo[1] : ue[1];
+                    if constexpr (PRELU) {
+                        const float pv = a1[r] + bia4[b];
+                        const float act = fmaxf(pv, 0.f) + af[1] * fminf(pv, 0.f);
+                        const bool up = act > pooled[r];
+                        pooled[r] = up ? act : pooled[r];
+                        presel[r] = up ? pv : presel[r];
+                        c1_shift_in(u, up);
+                    } else {
+                        float m = pooled[r];
+                        c1_max_shift_in(u, m, a1[r]);
+                        pooled[r] = m;
+                    }
+                }
+            };
+            // second half: window row 2, relu / alive, transpose through LDS, 16-byte stores
+            auto fin2 = [&](int b, const floatx16 &a2, floatx16 &pooled, floatx16 &presel, bool has2) {
+                if (has2) {
 #pragma unroll
                     for (int r = 15; r >= 0; --r) {
-                        unsigned &u = (r & 1) ? uo[fi] : ue[fi];
+                        unsigned &u = (r & 1) ? uo[2] : ue[2];
                         if constexpr (PRELU) {
-                            const float pv = acc[r] + bia4[b];
-                            const float act = fmaxf(pv, 0.f) + af[fi] * fminf(pv, 0.f);
+                            const float pv = a2[r] + bia4[b];
+                            const float act = fmaxf(pv, 0.f) + af[2] * fminf(pv, 0.f);
                             const bool up = act > pooled[r];
                             pooled[r] = up ? act : pooled[r];
                             presel[r] = up ? pv : presel[r];
                             c1_shift_in(u, up);
                         } else {
                             float m = pooled[r];
-                            c1_max_shift_in(u, m, acc[r]);
+                            c1_max_shift_in(u, m, a2[r]);
                             pooled[r] = m;
                         }
                     }
@@ -369,10 +393,8 @@ k_conv1_pool_fwd(const T *__restrict__ x, const float *__restrict__ w, const flo
                         ax = (ax << 1) | t;
                     }
                 }
-                // transpose through LDS, 16-byte stores
 #pragma unroll
                 for (int which = 0; which < (PRELU ? 2 : 1); ++which) {
-                    T *dst_t = which ? line_pre : line_out;
                     if (which && !line_pre) break;
 #pragma unroll
                     for (int r = 0; r < 16; r += 2) {
@@ -385,9 +407,65 @@ k_conv1_pool_fwd(const T *__restrict__ x, const float *__restrict__ w, const flo
                     for (int pass = 0; pass < 2; ++pass) {
                         const int row = e_row + 16 * pass;
                         const uint4 v = *reinterpret_cast<const uint4 *>(ep + row * EP_PITCH + e_chunk * 16);
-                        const int t = tw + row;
-                        if (t < g.W) *reinterpret_cast<uint4 *>(dst_t + (unsigned)(t * (4 * g.F) + b * g.F + e_chunk * 8)) = v;
+                        typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+                        const u32x4_t vv = {v.x, v.y, v.z, v.w};
+                        __builtin_amdgcn_raw_buffer_store_b128(vv, which ? pre_rs : out_rs, (int)(((tw + row) * (4 * g.F) + b * g.F + e_chunk * 8) * 2), 0, 0);
                     }
+                }
+            };
+            // MFMAs of component b for window rows [f0, f1), round robin (a dependent MFMA is f1 - f0 issues behind its source)
+            auto conv_rows = [&](int b, int f0, int f1, floatx16 (&acc)[PH]) {
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    const bool ng = (kSignConv >> (a * 4 + b)) & 1u;
+                    uint4 bw = B[a ^ b];
+                    if (ng) bw = c1_neg(bw);                      // (four VALU for up to three MFMAs: cheaper than 16 registers of negated fragments)
+#pragma unroll
+                    for (int fi = f0; fi < f1; ++fi) {
+                        if (a == 0) {
+                            floatx16 z;
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) z[r] = 0.f;
+                            acc[fi] = c1_mfma(T(), A[fi][a], bw, z);
+                        } else acc[fi] = c1_mfma(T(), A[fi][a], bw, acc[fi]);
+                    }
+                }
+            };
+            if (n_fi == PH && !PRELU) {
+                // Full windows.  A wave issues in order, and four dependent MFMAs back to back hold it for ~130 cycles: the MFMAs
+                // are therefore ISSUED between the VALU instructions of the step before them --
+                //   rows 0, 1 of component b + 1 (8 MFMAs)  under  row 2, relu, planes, transpose of component b   (~100 VALU)
+                //   row 2 of component b         (4 MFMAs)  under  rows 0, 1 of component b                         (~50 VALU)
+                floatx16 acc[PH], nacc[PH], pooled, presel;
+                conv_rows(0, 0, 2, acc);
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    conv_rows(b, 2, 3, acc);
+                    fin1(b, acc[0], acc[1], pooled, presel, true);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);          // one MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);         // twelve VALU
+                    }
+                    if (b + 1 < 4) conv_rows(b + 1, 0, 2, nacc);
+                    fin2(b, acc[2], pooled, presel, true);
+                    if (b + 1 < 4) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);
+                        }
+                        acc[0] = nacc[0]; acc[1] = nacc[1];
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    floatx16 acc[PH], pooled, presel;
+                    if constexpr (PRELU) __builtin_amdgcn_sched_barrier(0);
+                    conv_rows(b, 0, PH, acc);
+                    fin1(b, acc[0], acc[1], pooled, presel, n_fi > 1);
+                    fin2(b, acc[2], pooled, presel, n_fi > 2);
                 }
             }
             if (argbits) {
@@ -399,11 +477,6 @@ k_conv1_pool_fwd(const T *__restrict__ x, const float *__restrict__ w, const flo
                 ab[128] = make_uint2(alive.x & u2.x, alive.y & u2.y);
             }
         }
-        if (!has_next) break;
-        // the other patch buffer was last read one segment ago, before that segment's barrier
-        K::patch_store(lds + ((it + 1) & 1) * PATCH_SLOT, g, tid, pre);
-        __syncthreads();
-        item = next;
     }
 }
 
@@ -453,7 +526,7 @@ k_conv1_pool_bwd(const T *__restrict__ x, const T *__restrict__ dout, const T *_
     // atomics per workgroup instead of per segment).  The relu form has the NEXT segment's x patch, pooled gradient and planes
     // in flight (50 registers) under this segment's MFMAs; the PReLU form (which turns dpool into dy while staging, with the
     // pre-activations beside it) loads and stores back to back.
-    typename K::Pre pre_patch;
+    typename K::template Pre<448> pre_patch;
     uint4 pre_dp[8];
     uint2 pre_X[3];
     auto load_item = [&](int item) {
@@ -648,7 +721,7 @@ int run_conv1_pool(bool backward, const void *x, const float *w, const float *bi
         int blocks = device_cu_count();                            // persistent, 159 - 239 registers: one 7-wave workgroup per CU
         if (blocks > g.n_lines) blocks = g.n_lines;
         dim3 grid((unsigned)blocks, (unsigned)(g.F / 32), 1);
-        hipLaunchKernelGGL((k_conv1_pool_fwd<T, 3, 5, 3, PRELU>), grid, dim3(448), 0, stream, (const T *)x, w, bias, (T *)const_cast<void *>(io),
+        hipLaunchKernelGGL((k_conv1_pool_fwd<T, 3, 5, 3, PRELU>), grid, dim3(512), 0, stream, (const T *)x, w, bias, (T *)const_cast<void *>(io),
                            (T *)const_cast<void *>(pre), (uint2 *)argbits, g);
     } else {
         int blocks = device_cu_count();                            // persistent, > 200 registers: one 7-wave workgroup per CU
