@@ -34,6 +34,14 @@ __device__ __forceinline__ floatx16 c1_mfma(f16, const uint4 &a, const uint4 &b,
 {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(c1_f16x8, a), __builtin_bit_cast(c1_f16x8, b), c, 0, 0, 0);
 }
+__device__ __forceinline__ floatx4 c1_mfma16(bf16, const uint4 &a, const uint4 &b, const floatx4 &c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(c1_bf16x8, a), __builtin_bit_cast(c1_bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ floatx4 c1_mfma16(f16, const uint4 &a, const uint4 &b, const floatx4 &c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(c1_f16x8, a), __builtin_bit_cast(c1_f16x8, b), c, 0, 0, 0);
+}
 typedef float c1_f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned c1_pack(bf16, float a, float b)
 {
@@ -507,20 +515,29 @@ k_conv1_pool_bwd(const T *__restrict__ x, const T *__restrict__ dout, const T *_
     const int j0 = blockIdx.y * 32;
     for (int e = tid; e < C1_PW; e += 448)
         *reinterpret_cast<uint2 *>(lds + PATCH_SLOT + e * 8) = make_uint2(c1_pack(T(), 1.f, 0.f), 0u);
-    // backward A operand (x^T): this lane's row = tap lr (rows 0 - 14).  Row 16 reads the row of ones instead (component 0
-    // only): accumulator row 16 of part b is then sum over positions of dy_b -- the BIAS gradient comes out of the same MFMAs
-    // (it was two conversions and two adds per element).  Rows 17 - 31 repeat it and are ignored, row 15 is the zero tap.
-    const int my_tap_off = lr < 16 ? K::tap_off(lr) : PATCH_SLOT;
-    const int my_fi_pitch = lr < 16 ? C1_PW * 8 : 0;
-    floatx16 dwacc[4];                                            // [part p]: rows = taps, columns = filters
+    // The gradient GEMM runs on v_mfma_f32_16x16x32: dW_p[tap 16, filter 16 h ..] += x_a^T [tap, 32 positions] * (+-dy_b)[32 positions,
+    // filter] -- the 15 taps + one bias row fill the 16 rows (the 32 x 32 x 16 form spent half of its MFMAs on 16 rows nobody read).
+    //   lane L: row / column L & 15, K group kg = L >> 4: eight of the wave's 32 positions.  WHICH eight is free as long as both operands
+    //   agree; they are the positions of accumulator registers 8 (kg & 1) .. + 7 of the forward's lanes lh = kg >> 1 -- position
+    //   4 (kg >> 1) + 16 (kg & 1) + (i & 3) + 8 (i >> 2) for K slot i -- because that is the order the arg-max planes are in: this
+    //   lane uses the plane words of forward lane (filter, kg >> 1), shifted right by 4 (kg & 1) pairs.
+    // A operand (x^T): this lane's row = tap L & 15 (rows 0 - 14).  Row 15 reads a row of ones instead (component 0 only): accumulator
+    // row 15 of part b is then sum over positions of dy_b -- the BIAS gradient comes out of the same MFMAs.
+    const int kg = lane >> 4, l16 = lane & 15;
+    const int my_tap_off = l16 < 15 ? K::tap_off(l16) : PATCH_SLOT;
+    const int my_fi_pitch = l16 < 15 ? C1_PW * 8 : 0;
+    const int my_pos0 = 4 * (kg >> 1) + 16 * (kg & 1);            // first of this lane's eight positions
+    floatx4 dwacc[4][2];                                          // [part p][filter half h]: rows = taps 4 kg + r, columns = filters 16 h + (L & 15)
 #pragma unroll
     for (int p = 0; p < 4; ++p)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dwacc[p][r] = 0.f;
-    // transposing read (ds_read_b64_tr_b16): lane L of a 16-lane group addresses row L >> 2, filters 4 (L & 3) .. + 3 of the
-    // group's 16 filters and receives ITS filter at the group's four rows: a lane's dy fragment of one 16-deep K step is two
-    // such reads (rows 16 s + 4 lh + 0..3 and + 8..11: the accumulator order of the forward, which the arg-max planes are in)
-    const int tr_off = DP_AT + wave * DP_WAVE + (4 * lh + ((lane & 15) >> 2)) * 64 + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dwacc[p][h][r] = 0.f;
+    // transposing read (ds_read_b64_tr_b16): lane l of a 16-lane group addresses row l >> 2, filters 4 (l & 3) .. + 3 of the
+    // group's 16 filters and receives ITS filter at the group's four rows: a lane's dy fragment is two such reads (its positions
+    // + 0..3 and + 8..11) per filter half
+    const int tr_off = DP_AT + wave * DP_WAVE + (my_pos0 + (l16 >> 2)) * 64 + (4 * (lane & 3)) * 2;
 
     // Persistent: a workgroup walks over pooled line segments and keeps the gradients in registers (one flush of 2 K
     // atomics per workgroup instead of per segment).  The relu form has the NEXT segment's x patch, pooled gradient and planes
@@ -528,16 +545,20 @@ k_conv1_pool_bwd(const T *__restrict__ x, const T *__restrict__ dout, const T *_
     // pre-activations beside it) loads and stores back to back.
     typename K::template Pre<448> pre_patch;
     uint4 pre_dp[8];
-    uint2 pre_X[3];
+    uint2 pre_X[3][2];                                            // [plane][filter half]
     auto load_item = [&](int item) {
         const int chunk = item % g.n_chunks, line = item / g.n_chunks;
         const int ho = line % g.Ho, n = line / g.Ho;
         const int t0 = chunk * C1_TW, tw = t0 + wave * 32;
         K::patch_load(x, g, n, ho, t0, tid, pre_patch);
-        pre_X[0] = pre_X[1] = pre_X[2] = make_uint2(0u, 0u);                                   // no plane set: nothing flows
+#pragma unroll
+        for (int fi = 0; fi < 3; ++fi) pre_X[fi][0] = pre_X[fi][1] = make_uint2(0u, 0u);       // no plane set: nothing flows
         if (tw < g.W) {
-            const uint2 *ab = argbits + ((((long long)blockIdx.y * g.n_lines + item) * 7 + wave) * 3) * 64 + lane;
-            pre_X[0] = ab[0]; pre_X[1] = ab[64]; pre_X[2] = ab[128];
+            const uint2 *ab = argbits + ((((long long)blockIdx.y * g.n_lines + item) * 7 + wave) * 3) * 64 + 32 * (kg >> 1) + l16;
+#pragma unroll
+            for (int fi = 0; fi < 3; ++fi)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) pre_X[fi][h] = ab[fi * 64 + 16 * h];
         }
         const T *line_in = dout + (((long long)n * g.Ho + ho) * g.W) * (4 * g.F) + j0;          // (wave-uniform)
 #pragma unroll
@@ -562,12 +583,22 @@ k_conv1_pool_bwd(const T *__restrict__ x, const T *__restrict__ dout, const T *_
         __syncthreads();                                          // the previous segment's LDS reads are done
         if constexpr (PRELU) load_item(item);
         K::patch_store(lds, g, tid, pre_patch);
-        const uint2 X[3] = {pre_X[0], pre_X[1], pre_X[2]};
+        unsigned X[3][2][2];                                      // [plane][filter half][word], shifted to this lane's registers
+#pragma unroll
+        for (int fi = 0; fi < 3; ++fi)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) { X[fi][h][0] = pre_X[fi][h].x >> (4 * (kg & 1)); X[fi][h][1] = pre_X[fi][h].y >> (4 * (kg & 1)); }
         float a3[3] = {0.f, 0.f, 0.f}, dal3[3] = {0.f, 0.f, 0.f};
         if constexpr (PRELU) {
+            // the planes in the FORWARD's lane order, parked for the staging threads
             // (a wave's own LDS accesses execute in order: the reads below see these writes without a barrier)
             unsigned *awp = reinterpret_cast<unsigned *>(lds + AW_AT + (wave * 64 + lane) * 24);
-            awp[0] = X[0].x; awp[1] = X[0].y; awp[2] = X[1].x; awp[3] = X[1].y; awp[4] = X[2].x; awp[5] = X[2].y;
+            uint2 own[3] = {make_uint2(0u, 0u), make_uint2(0u, 0u), make_uint2(0u, 0u)};
+            if (tw < g.W) {
+                const uint2 *ab = argbits + ((((long long)blockIdx.y * g.n_lines + item) * 7 + wave) * 3) * 64 + lane;
+                own[0] = ab[0]; own[1] = ab[64]; own[2] = ab[128];
+            }
+            awp[0] = own[0].x; awp[1] = own[0].y; awp[2] = own[1].x; awp[3] = own[1].y; awp[4] = own[2].x; awp[5] = own[2].y;
 #pragma unroll
             for (int fi = 0; fi < 3; ++fi) a3[fi] = g.alpha[g.alpha_len > 1 ? min(PH * ho + fi, g.alpha_len - 1) : 0];
         }
@@ -622,46 +653,44 @@ k_conv1_pool_bwd(const T *__restrict__ x, const T *__restrict__ dout, const T *_
             if (item0 + (int)gridDim.x < g.n_lines) load_item(item0 + (int)gridDim.x);
         }
         const int n_fi = tw < g.W ? min(PH, g.H - PH * ho) : 0;
-        // the pooled gradient of this lane's filter in K (= accumulator) order: D[b][s], read ONCE for the three window rows
+        // the pooled gradient of this lane's two filters at its eight positions: D[b][h], read ONCE for the three window rows
         uint4 D[4][2];
         if (n_fi > 0) {
 #pragma unroll
             for (int b = 0; b < 4; ++b)
 #pragma unroll
-                for (int s = 0; s < 2; ++s) {
+                for (int h = 0; h < 2; ++h) {
                     typedef short v4s __attribute__((ext_vector_type(4)));
                     typedef __attribute__((address_space(3))) v4s lds_v4s;
-                    const char *src = lds + tr_off + b * DP_COMP + (16 * s) * 64;
+                    const char *src = lds + tr_off + b * DP_COMP + h * 32;
                     const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s *)(src));
                     const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s *)(src + 8 * 64));
                     const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
-                    D[b][s] = make_uint4(l2.x, l2.y, h2.x, h2.y);
+                    D[b][h] = make_uint4(l2.x, l2.y, h2.x, h2.y);
                 }
         }
 #pragma unroll 1
         for (int fi = 0; fi < n_fi; ++fi) {                        // dy of row tile fi (where fi is the window's arg-max), dW += x^T dy
-            // x^T fragments: row = this lane's tap, K slot i of step s = position 16 s + 4 lh + (i & 3) + 8 (i >> 2)
-            uint4 XT[2][4];
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
+            // x^T fragments: row = this lane's tap, K slot i = position my_pos0 + (i & 3) + 8 (i >> 2)
+            uint4 XT[4];
+            {
                 uint2 v[8];
-                const char *xb = lds + (wave * 32 + 16 * s + 4 * lh) * 8 + fi * my_fi_pitch + my_tap_off;
+                const char *xb = lds + (wave * 32 + my_pos0) * 8 + fi * my_fi_pitch + my_tap_off;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const uint2 *>(xb + ((i & 3) + 8 * (i >> 2)) * 8);
-                K::split4(v, XT[s]);
+                K::split4(v, XT);
             }
-            const uint2 Xf = fi == 0 ? X[0] : fi == 1 ? X[1] : X[2];
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
-                const unsigned xw = (b >> 1) ? Xf.y : Xf.x;
 #pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const unsigned dd[4] = {D[b][s].x, D[b][s].y, D[b][s].z, D[b][s].w};
+                for (int h = 0; h < 2; ++h) {
+                    const unsigned xw = fi == 0 ? X[0][h][b >> 1] : fi == 1 ? X[1][h][b >> 1] : X[2][h][b >> 1];
+                    const unsigned dd[4] = {D[b][h].x, D[b][h].y, D[b][h].z, D[b][h].w};
                     unsigned d[4];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {                  // registers 8 s + 2 i, + 1: pair j = 4 s + i
+                    for (int i = 0; i < 4; ++i) {                  // K slots 2 i, 2 i + 1 = registers 8 (kg & 1) + 2 i, + 1 of the forward
                         typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-                        const unsigned m = (xw >> (8 * (1 - (b & 1)) + 4 * s + i)) & 0x00010001u;
+                        const unsigned m = (xw >> (8 * (1 - (b & 1)) + i)) & 0x00010001u;
                         d[i] = __builtin_bit_cast(unsigned, __builtin_bit_cast(us2, dd[i]) * __builtin_bit_cast(us2, m));
                     }
                     const uint4 dy = make_uint4(d[0], d[1], d[2], d[3]);
@@ -669,7 +698,7 @@ k_conv1_pool_bwd(const T *__restrict__ x, const T *__restrict__ dout, const T *_
 #pragma unroll
                     for (int a = 0; a < 4; ++a) {
                         const bool ng = (kSignConv >> (a * 4 + b)) & 1u;
-                        dwacc[a ^ b] = c1_mfma(T(), XT[s][a], ng ? dyn : dy, dwacc[a ^ b]);
+                        dwacc[a ^ b][h] = c1_mfma16(T(), XT[a], ng ? dyn : dy, dwacc[a ^ b][h]);
                     }
                 }
             }
@@ -681,19 +710,20 @@ k_conv1_pool_bwd(const T *__restrict__ x, const T *__restrict__ dout, const T *_
             if (tid < g.alpha_len && tid < 64 && dal_s[tid] != 0.f) atomicAdd(dalpha + tid, dal_s[tid]);
         }
     }
-    // ---- flush: every wave parks its gradients in its own LDS slab (taps = accumulator rows 0 .. 15 = registers 0 .. 7,
-    // the bias sums = row 16 = register 8 of the lanes lh == 0; columns = filters), the workgroup sums the seven slabs and
-    // issues one atomic per element
+    // ---- flush: every wave parks its gradients in its own LDS slab (accumulator register r of lane L = tap 4 kg + r, filter
+    // 16 h + (L & 15); the bias sums are tap 15), the workgroup sums the seven slabs and issues one atomic per element
     __syncthreads();
-    constexpr int SLAB = 4 * 16 * 32 + 4 * 64;                    // [part 4][tap 16][filter 32] + [component 4][lane 64] floats
+    constexpr int SLAB = 4 * 16 * 32 + 4 * 64;                    // [part 4][tap 16][filter 32] + [component 4][filter 32 (+ 32 unused)] floats
     static_assert(7 * SLAB * 4 <= (int)sizeof(lds), "flush slabs fit");
     float *slab = reinterpret_cast<float *>(lds) + wave * SLAB;
 #pragma unroll
     for (int p = 0; p < 4; ++p)
 #pragma unroll
-        for (int r = 0; r < 8; ++r) slab[(p * 16 + mfma32_row(r, lane)) * 32 + lr] = dwacc[p][r];
+        for (int h = 0; h < 2; ++h) {
 #pragma unroll
-    for (int b = 0; b < 4; ++b) slab[4 * 16 * 32 + b * 64 + lane] = lh == 0 ? dwacc[b][8] : 0.f;     // (a = 0 carries no sign: kSignConv bits 0 - 3)
+            for (int r = 0; r < 4; ++r) slab[(p * 16 + 4 * kg + r) * 32 + 16 * h + l16] = dwacc[p][h][r];
+            if (kg == 3) slab[4 * 16 * 32 + p * 64 + 16 * h + l16] = dwacc[p][h][3];            // (a = 0 carries no sign: kSignConv bits 0 - 3)
+        }
     static_assert((kSignConv & 0xFu) == 0u, "component 0 of x enters every part with +");
     __syncthreads();
     const float *all = reinterpret_cast<const float *>(lds);
@@ -708,7 +738,7 @@ k_conv1_pool_bwd(const T *__restrict__ x, const T *__restrict__ dout, const T *_
         const int b = tid >> 5, f = tid & 31;
         float v = 0.f;
 #pragma unroll
-        for (int wv = 0; wv < 7; ++wv) v += all[wv * SLAB + 4 * 16 * 32 + b * 64 + f] + all[wv * SLAB + 4 * 16 * 32 + b * 64 + 32 + f];
+        for (int wv = 0; wv < 7; ++wv) v += all[wv * SLAB + 4 * 16 * 32 + b * 64 + f];
         atomicAdd(dbias + b * g.F + j0 + f, v);
     }
 }
