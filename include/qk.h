@@ -282,9 +282,10 @@ int qk_postop_bwd(const qk_conv_desc_t *t, const qk_postop_t *post, const void *
  *     QuaternionConv2D(F, (3,5), padding='same', relu) on ONE quaternion channel -> MaxPooling2D over the first
  *     spatial axis with window = stride = `pool`, 'same' (partial last window).
  * The layer is HBM-bound; fused, the forward reads x (N, H, W, 4) and writes only the pooled tensor
- * (N, ceil(H / pool), W, 4F) plus `aux` (2 bits per pooled element: which window row held the maximum, or "relu
- * killed it"), the backward reads x, the pooled gradient and aux and returns dw / dbias (overwritten) -- the 537 MB
- * pre-pool activation of the B = 256 model never exists.  Supported: rank 2, QK_CH_LAST, bf16 / fp16, cq == 1, kernel
+ * (N, ceil(H / pool), W, 4F) plus `aux` (opaque to the caller, qk_conv_relu_pool_aux_bytes: 3 bits per pooled element --
+ * one-hot "window row 0 / 1 / 2 held the maximum and relu let it through", all clear = nothing flows back -- in the
+ * kernels' register order), the backward reads x, the pooled gradient and aux and returns dw / dbias (overwritten) -- the
+ * 537 MB pre-pool activation of the B = 256 model never exists.  Supported: rank 2, QK_CH_LAST, bf16 / fp16, cq == 1, kernel
  * (3,5), unit stride / dilation, pad_lo (1,2), activation RELU, conj 0, fq % 32 == 0, pool == 3, H % 3 != 1 (the
  * kernel's windows are rows [3o, 3o + 2]; TensorFlow's 'same' rule pads one row on the LOW side when H % 3 == 1, so
  * for those heights the windows would start at row -1: not this kernel's -- 41 bins are fine); anything else returns

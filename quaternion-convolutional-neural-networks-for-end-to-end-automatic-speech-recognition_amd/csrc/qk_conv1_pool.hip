@@ -537,6 +537,9 @@ k_conv1_pool_bwd(const T *__restrict__ x, const T *__restrict__ dout, const T *_
     // transposing read (ds_read_b64_tr_b16): lane l of a 16-lane group addresses row l >> 2, filters 4 (l & 3) .. + 3 of the
     // group's 16 filters and receives ITS filter at the group's four rows: a lane's dy fragment is two such reads (its positions
     // + 0..3 and + 8..11) per filter half
+    // Banks: the two K groups of one 32-lane pass read rows 16 apart -- the same banks in 64-byte rows -- so rows 16 - 31 are stored
+    // with their 32-byte halves SWAPPED: a pass then covers all 64 banks once (4.1e6 -> conflict cycles without it, SQ_LDS_BANK_CONFLICT).
+    const int tr_swap = 32 * (kg & 1);                            // my_pos0 & 16
     const int tr_off = DP_AT + wave * DP_WAVE + (my_pos0 + (l16 >> 2)) * 64 + (4 * (lane & 3)) * 2;
 
     // Persistent: a workgroup walks over pooled line segments and keeps the gradients in registers (one flush of 2 K
@@ -635,7 +638,7 @@ k_conv1_pool_bwd(const T *__restrict__ x, const T *__restrict__ dout, const T *_
                     v = make_uint4(dv[0], dv[1], dv[2], dv[3]);
                 }
             }
-            *reinterpret_cast<uint4 *>(dp + b * DP_COMP + row * 64 + sub * 2) = v;
+            *reinterpret_cast<uint4 *>(dp + b * DP_COMP + row * 64 + ((sub * 2 + 2 * (row & 16)) & 63)) = v;     // (rows 16 - 31: halves swapped, see tr_off)
         }
         if constexpr (PRELU) {
             if (dalpha) {                                          // wave sums -> one LDS atomic per (wave, window row)
@@ -662,7 +665,7 @@ k_conv1_pool_bwd(const T *__restrict__ x, const T *__restrict__ dout, const T *_
                 for (int h = 0; h < 2; ++h) {
                     typedef short v4s __attribute__((ext_vector_type(4)));
                     typedef __attribute__((address_space(3))) v4s lds_v4s;
-                    const char *src = lds + tr_off + b * DP_COMP + h * 32;
+                    const char *src = lds + tr_off + b * DP_COMP + ((h * 32) ^ tr_swap);
                     const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s *)(src));
                     const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s *)(src + 8 * 64));
                     const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);

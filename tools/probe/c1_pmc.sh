@@ -15,9 +15,8 @@ for f in sorted(glob.glob('gpurun_out/c1pmc/*counter_collection.csv')):
     for r in csv.DictReader(open(f)):
         k = r['Kernel_Name']
         if 'k_conv1_pool' in k:
-            agg[k[:40]][r['Counter_Name']].append(float(r['Counter_Value']))
-    for k, d in agg.items():
-        print(f.split('/')[-1], k)
+            agg['k_conv1_pool_fwd' if 'pool_fwd' in k else 'k_conv1_pool_bwd'][r['Counter_Name']].append(float(r['Counter_Value']))
+    for k, d in sorted(agg.items()):
         for c, v in d.items():
-            print('    %-32s n=%d median=%.4g' % (c, len(v), sorted(v)[len(v)//2]))
+            print('%-18s %-28s launches=%d median=%.4g' % (k, c, len(v), sorted(v)[len(v)//2]))
 PY

@@ -11,9 +11,10 @@
 # 7. per-phase ablation of the 16-bit kernels (tools/ablate16.py);                             -> r04_ablation.txt
 # 8. the bench lines: default (CTC), --loss sum, cfg5 stack, native-layout layer (builder runs).  -> r04_bench_*.json
 # 9. phase time stamps of the band kernels (probe build, tools/probe/phase_stamps.py) and the sum / CTC loss A-B with telemetry (ab_loss.py)  -> r04_phase_stamps.txt, r04_loss_ab.txt
+# 10. the fused first layer (k_conv1_pool_fwd / _bwd at B = 256): stand-alone times and SQ counters (tools/probe/c1_time.py, c1_pmc.sh)  -> r04_first_layer_pmc.txt
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; cd $R; O=gpurun_out/r04; rm -rf $O; mkdir -p $O
-STEPS="${STEPS:-1 2 3 4 5 6 7 8 9}"
+STEPS="${STEPS:-1 2 3 4 5 6 7 8 9 10}"
 has() { [[ " $STEPS " == *" $1 "* ]]; }
 if has 1; then
 timeout 900 rocprofv3 --kernel-trace --stats -d $O -o ks_qcnn --output-format csv -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras --no-standalone > $O/log_qcnn.txt 2>&1; echo "qcnn trace rc=$?"
@@ -62,3 +63,7 @@ python tools/probe/ab_loss.py 2>&1 | grep -v amdgpu.ids > $O/r04_loss_ab.txt
 python tools/probe/grad_stats.py 2>&1 | grep -v amdgpu.ids >> $O/r04_loss_ab.txt
 fi
 ls -la $O
+if has 10; then
+( python tools/probe/c1_time.py 2>&1 | grep -v amdgpu.ids
+  ./tools/probe/c1_pmc.sh "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES" "GRBM_GUI_ACTIVE SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAVES" 2>&1 ) > $O/r04_first_layer_pmc.txt
+fi
