@@ -508,6 +508,14 @@ def in_step_kernel_times(job, dev, peak, steps=3):
         tf = 2.0 * rows * n * k / (mean * 1e-3) / 1e12
         calls.append({'op': op, 'rows': rows, 'n': n, 'k': k, 'path': path, 'calls_per_step': len(ms) // steps, 'ms': mean,
                       'ms_min': min(ms), 'tflops': tf, 'frac_of_peak': tf / peak})
+        if k == 60 and rows % 41 == 0:
+            # the fused first layer (conv (3,5) on one quaternion channel + relu + (3,1) max-pool, 41 bins): it moves bytes, not
+            # flops -- x (8 B per position), the pooled tensor or its gradient (2 B x n per pooled position) and the arg-max
+            # side tensor (3 bits per pooled element in 24-byte lane words: 7 tiles of 32 positions per 200-position line)
+            pooled_rows = rows // 41 * 14
+            nbytes = rows * 8 + pooled_rows * n * 2 + (pooled_rows + 199) // 200 * 7 * (n // 128) * 64 * 24
+            calls[-1].update({'hbm_bytes': nbytes, 'hbm_tb_s': nbytes / (mean * 1e-3) / 1e12, 'hbm_frac_of_8tb_s': nbytes / (mean * 1e-3) / 8e12,
+                              'bound': 'hbm (algorithmic bytes: x + pooled tensor + arg-max side tensor)'})
     calls.sort(key=lambda c: -c['ms'] * c['calls_per_step'])
     return {'steps': steps, 'calls': calls, 'ms_per_step_in_calls': sum(c['ms'] * c['calls_per_step'] for c in calls),
             'timing': 'qk_prof_*: HIP events on the launch stream around each forward / backward-data / backward-weight call, '
