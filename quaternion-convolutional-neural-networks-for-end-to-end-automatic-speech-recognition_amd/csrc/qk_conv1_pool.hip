@@ -305,8 +305,15 @@ k_conv1_pool_fwd(const T *__restrict__ x, const float *__restrict__ w, const flo
     float bia4[4];
 #pragma unroll
     for (int b = 0; b < 4; ++b) bia4[b] = g.has_bias ? bias[b * g.F + j0 + lr] : 0.f;
+    // The output's way from [filter = lane][positions in registers] to 16-byte runs of filters per position: every lane writes its
+    // filter's row of the wave's slab ([filter][32 positions], 64-byte rows, 8 bytes of skew per four rows: the 8-byte writes and
+    // the transposing reads both cover all banks) and ds_read_b64_tr_b16 hands a lane four FILTERS of one position -- 4 + 4 LDS
+    // instructions per component where 2-byte stores into a [position][filter] slab took 16 + 2.
     char *ep = lds + 2 * PATCH_SLOT + wave * (32 * EP_PITCH);
-    const int e_row = lane >> 2, e_chunk = lane & 3;
+    const int ep_w = lr * 64 + (lr >> 2) * 8 + lh * 8;            // + 16 q: positions 4 lh + 8 q .. + 3
+    const int ep_fr = 8 * (lane & 3) + ((lane & 15) >> 2);        // the filter row this lane ADDRESSES in a transposing read (it receives filters 8 (i >> 2) + 0 .. 3)
+    const int ep_r = ep_fr * 64 + (ep_fr >> 2) * 8 + (lane >> 4) * 8;        // + 32 pass: positions 16 pass + 4 (lane >> 4) .. + 3
+    const int e_row = 4 * (lane >> 4) + (lane & 3), e_chunk = (lane & 15) >> 2;      // what it receives: position e_row (+ 16 pass), filters 8 e_chunk .. + 7
 
 #pragma unroll 1
     for (int it = 0; item < g.n_lines; ++it, item += (int)gridDim.x) {
@@ -404,20 +411,23 @@ k_conv1_pool_fwd(const T *__restrict__ x, const float *__restrict__ w, const flo
 #pragma unroll
                 for (int which = 0; which < (PRELU ? 2 : 1); ++which) {
                     if (which && !line_pre) break;
+                    if constexpr (PRELU) {
 #pragma unroll
-                    for (int r = 0; r < 16; r += 2) {
-                        if constexpr (PRELU) pk[r >> 1] = which ? c1_pack(T(), presel[r], presel[r + 1]) : c1_pack(T(), pooled[r], pooled[r + 1]);
-                        char *dst = ep + mfma32_row(r, lane) * EP_PITCH + lr * 2;
-                        *reinterpret_cast<unsigned short *>(dst) = (unsigned short)pk[r >> 1];
-                        *reinterpret_cast<unsigned short *>(dst + EP_PITCH) = (unsigned short)(pk[r >> 1] >> 16);
+                        for (int r = 0; r < 16; r += 2) pk[r >> 1] = which ? c1_pack(T(), presel[r], presel[r + 1]) : c1_pack(T(), pooled[r], pooled[r + 1]);
                     }
+                    // registers 4 q .. 4 q + 3 are four consecutive positions of this lane's filter: one 8-byte word of its row
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) *reinterpret_cast<uint2 *>(ep + ep_w + q * 16) = make_uint2(pk[2 * q], pk[2 * q + 1]);
 #pragma unroll
                     for (int pass = 0; pass < 2; ++pass) {
-                        const int row = e_row + 16 * pass;
-                        const uint4 v = *reinterpret_cast<const uint4 *>(ep + row * EP_PITCH + e_chunk * 16);
+                        typedef short v4s __attribute__((ext_vector_type(4)));
+                        typedef __attribute__((address_space(3))) v4s lds_v4s;
+                        const v4s f03 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s *)(ep + ep_r + pass * 32));
+                        const v4s f47 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s *)(ep + ep_r + pass * 32 + 4 * 64 + 8));
+                        const uint2 lo = __builtin_bit_cast(uint2, f03), hi = __builtin_bit_cast(uint2, f47);
                         typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-                        const u32x4_t vv = {v.x, v.y, v.z, v.w};
-                        __builtin_amdgcn_raw_buffer_store_b128(vv, which ? pre_rs : out_rs, (int)(((tw + row) * (4 * g.F) + b * g.F + e_chunk * 8) * 2), 0, 0);
+                        const u32x4_t vv = {lo.x, lo.y, hi.x, hi.y};
+                        __builtin_amdgcn_raw_buffer_store_b128(vv, which ? pre_rs : out_rs, (int)(((tw + e_row + 16 * pass) * (4 * g.F) + b * g.F + e_chunk * 8) * 2), 0, 0);
                     }
                 }
             };
