@@ -516,15 +516,16 @@ k_conv1_pool_bwd(const T *__restrict__ x, const T *__restrict__ dout, const T *_
     constexpr int ONES_BYTES = C1_PW * 8;                         // a patch row of (1, 0, 0, 0): the bias gradient's "tap" (below)
     constexpr int PATCH_SLOT = (K::PATCH_BYTES + 15) / 16 * 16;
     constexpr int AW_BYTES = PRELU ? 7 * 64 * 24 : 0;             // the waves' arg-max planes
-    __shared__ __attribute__((aligned(16))) char lds[PATCH_SLOT + ONES_BYTES + DP_BYTES + AW_BYTES + (PRELU ? 256 : 0)];
-    constexpr int DP_AT = PATCH_SLOT + ONES_BYTES, AW_AT = DP_AT + DP_BYTES;
+    // two patch buffers: ONE barrier per segment (the dpool tiles are private to their waves: program order is enough for them)
+    __shared__ __attribute__((aligned(16))) char lds[2 * PATCH_SLOT + ONES_BYTES + DP_BYTES + AW_BYTES + (PRELU ? 256 : 0)];
+    constexpr int ONES_AT = 2 * PATCH_SLOT, DP_AT = ONES_AT + ONES_BYTES, AW_AT = DP_AT + DP_BYTES;
     float *dal_s = reinterpret_cast<float *>(lds + AW_AT + AW_BYTES);                           // PRELU: 64 slope-gradient sums
-    if (PRELU && threadIdx.x < 64) dal_s[threadIdx.x] = 0.f;       // (the loop's first barrier orders it)
+    if (PRELU && threadIdx.x < 64) dal_s[threadIdx.x] = 0.f;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 31, lh = lane >> 5;
     const int j0 = blockIdx.y * 32;
     for (int e = tid; e < C1_PW; e += 448)
-        *reinterpret_cast<uint2 *>(lds + PATCH_SLOT + e * 8) = make_uint2(c1_pack(T(), 1.f, 0.f), 0u);
+        *reinterpret_cast<uint2 *>(lds + ONES_AT + e * 8) = make_uint2(c1_pack(T(), 1.f, 0.f), 0u);
     // The gradient GEMM runs on v_mfma_f32_16x16x32: dW_p[tap 16, filter 16 h ..] += x_a^T [tap, 32 positions] * (+-dy_b)[32 positions,
     // filter] -- the 15 taps + one bias row fill the 16 rows (the 32 x 32 x 16 form spent half of its MFMAs on 16 rows nobody read).
     //   lane L: row / column L & 15, K group kg = L >> 4: eight of the wave's 32 positions.  WHICH eight is free as long as both operands
@@ -534,7 +535,8 @@ k_conv1_pool_bwd(const T *__restrict__ x, const T *__restrict__ dout, const T *_
     // A operand (x^T): this lane's row = tap L & 15 (rows 0 - 14).  Row 15 reads a row of ones instead (component 0 only): accumulator
     // row 15 of part b is then sum over positions of dy_b -- the BIAS gradient comes out of the same MFMAs.
     const int kg = lane >> 4, l16 = lane & 15;
-    const int my_tap_off = l16 < 15 ? K::tap_off(l16) : PATCH_SLOT;
+    const int my_tap_off = l16 < 15 ? K::tap_off(l16) : ONES_AT;
+    const int my_buf_pitch = l16 < 15 ? PATCH_SLOT : 0;
     const int my_fi_pitch = l16 < 15 ? C1_PW * 8 : 0;
     const int my_pos0 = 4 * (kg >> 1) + 16 * (kg & 1);            // first of this lane's eight positions
     floatx4 dwacc[4][2];                                          // [part p][filter half h]: rows = taps 4 kg + r, columns = filters 16 h + (L & 15)
@@ -583,8 +585,10 @@ k_conv1_pool_bwd(const T *__restrict__ x, const T *__restrict__ dout, const T *_
         }
     };
     if (!PRELU && (int)blockIdx.x < g.n_lines) load_item(blockIdx.x);
+    if constexpr (PRELU) __syncthreads();                          // the slope-gradient sums are zero before the first segment adds to them
+    int it = 0;
 #pragma unroll 1
-    for (int item0 = blockIdx.x; item0 < g.n_lines; item0 += gridDim.x) {
+    for (int item0 = blockIdx.x; item0 < g.n_lines; item0 += gridDim.x, it ^= 1) {
         int item = item0;
         asm volatile("" : "+s"(item));
         const int chunk = item % g.n_chunks, line = item / g.n_chunks;
@@ -593,9 +597,9 @@ k_conv1_pool_bwd(const T *__restrict__ x, const T *__restrict__ dout, const T *_
         // this wave's dpool tile: 32 positions x (4 x 32) channels
         char *dp = lds + DP_AT + wave * DP_WAVE;
         const int tw = t0 + wave * 32;
-        __syncthreads();                                          // the previous segment's LDS reads are done
+        // (no barrier here: this patch buffer was last read two segments ago, before the previous segment's barrier)
         if constexpr (PRELU) load_item(item);
-        K::patch_store(lds, g, tid, pre_patch);
+        K::patch_store(lds + it * PATCH_SLOT, g, tid, pre_patch);
         unsigned X[3][2][2];                                      // [plane][filter half][word], shifted to this lane's registers
 #pragma unroll
         for (int fi = 0; fi < 3; ++fi)
@@ -688,7 +692,7 @@ k_conv1_pool_bwd(const T *__restrict__ x, const T *__restrict__ dout, const T *_
             uint4 XT[4];
             {
                 uint2 v[8];
-                const char *xb = lds + (wave * 32 + my_pos0) * 8 + fi * my_fi_pitch + my_tap_off;
+                const char *xb = lds + it * my_buf_pitch + (wave * 32 + my_pos0) * 8 + fi * my_fi_pitch + my_tap_off;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const uint2 *>(xb + ((i & 3) + 8 * (i >> 2)) * 8);
                 K::split4(v, XT);
