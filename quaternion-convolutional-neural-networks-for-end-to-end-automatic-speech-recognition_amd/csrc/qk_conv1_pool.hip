@@ -3,19 +3,22 @@
 //     QuaternionConv2D(F, (3,5), 'same', relu) on ONE quaternion input channel  ->  MaxPooling2D((1,3), 'same')
 //                                                                                   (pools the frequency axis)
 //
-// The layer is HBM-bound (K = 4 x 15, 58 FLOP per byte of its 537 MB output), and as separate launches it moves
+// The layer moves bytes, not flops (K = 4 x 15, 58 FLOP per byte of its 537 MB output), and as separate launches it moves
 // 2.4 GB forward (tap-folded copy of x, y, pooled y) and 1.6 GB backward for 17 MB of input and 184 MB of pooled
-// output.  Here the forward reads x and writes ONLY the pooled tensor plus 2 bits per pooled element (which of the
-// window's rows held the maximum; 3 = the relu killed it: 23 MB); the backward reads x, the pooled gradient and those
-// bits, rebuilds dy in registers and accumulates the kernel / bias gradient there -- y never exists in memory.
+// output.  Here the forward reads x and writes ONLY the pooled tensor plus three one-hot bit planes per pooled element
+// (window row 0 / 1 / 2 held the maximum and relu let it through; none set = nothing flows back: 38 MB); the backward
+// reads x, the pooled gradient and those planes, rebuilds dy in registers and accumulates the kernel / bias gradient
+// there -- y never exists in memory.  Both kernels were bound by VALU issue before they were bound by anything else
+// (DESIGN.md 3.5.2): the bookkeeping per element is what the code below is organised around.
 //
-// Geometry: x (N, H, W, 4) channels_last (r,i,j,k of the one channel), kernel (KH, KW, 1, 4F), taps KH*KW <= 16;
-// pooled (N, ceil(H / PH), W, 4F).  A workgroup of 7 waves owns one pooled line segment (n, ho, 224 positions of
-// W); a wave owns 32 consecutive positions x (4 components x 32 filters).  The x patch (PH + KH - 1 rows x 228
-// positions x 8 B) sits in LDS, zero padded.
-//   forward MFMA   y_b[pos, f] += A_a[pos, tap] * W_{a^b}[tap, f]   v_mfma_f32_32x32x16: K = the 16 (15 + 1 zero) taps
-//   backward MFMA  dW_p[tap, f] += x_a[pos, tap]^T * (+-dy_b)[pos, f]   K = positions, two 16-deep steps per tile;
-//                  dy of row tile fi = dpool where fi is the window's arg-max (first maximum wins) and max + bias > 0.
+// Geometry: x (N, H, W, 4) channels_last (r,i,j,k of the one channel) or (N, 4, H, W) component planes, kernel
+// (KH, KW, 1, 4F), taps KH*KW <= 15; pooled (N, ceil(H / PH), W, 4F).  A persistent workgroup walks over pooled line
+// segments (n, ho, 224 positions of W); a wave owns 32 consecutive positions x (4 components x 32 filters) of a segment.
+// The x patch (PH + KH - 1 rows x 232 positions x 8 B) sits in LDS, zero padded, the next segment's patch on its way.
+//   forward   7 computing waves + a loader wave.  y_b[pos, f] += A_a[pos, tap] * W_{a^b}[tap, f], v_mfma_f32_32x32x16:
+//             K = the 16 (15 + 1 zero) taps; lane = filter, registers = positions
+//   backward  7 waves.  dW_p[tap, f] += x_a[pos, tap]^T * (+-dy_b)[pos, f], v_mfma_f32_16x16x32: rows = 15 taps + a row of
+//             ones (the bias gradient), K = the wave's 32 positions; dy of window row fi = dpool where plane fi is set
 // Fragments are assembled from 8-byte LDS reads (all four components of one position) with v_perm_b32.
 #include "qk_common.h"
 #include <type_traits>
