@@ -7,6 +7,7 @@
 //   kind 1  + fragments re-read from LDS every 16-deep step, 8 ds_read_b128 per 16 MFMAs        (today's wave tile: 32 rows x 128 columns)
 //   kind 2  + staging: global loads (L2-resident, 4/5 from a shared 512 KB image) and ds_write_b128 at the band kernel's rate
 //           (5 + 5 per 32 MFMAs with 64-row workgroup tiles; 6 + 6 per 64 MFMAs with 128-row tiles)
+//   kind 3  staging by LDS-DMA instead (global_load_lds_dwordx4: global -> LDS, no VGPR round trip, no ds_write): same units, same rate
 //   RB = 2  64-row wave tiles (one wave per SIMD, 14 accumulator tiles, 12 reads per 32 MFMAs): the "512-register" form
 // Geometry: WPS waves per SIMD (2: two 4-wave workgroups per CU as today, or 1: one 4-wave workgroup per CU).
 // tools/probe/energy_probe.py launches each variant back to back for a few seconds and samples socket power and shader clock.
@@ -28,7 +29,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB == 
 k_probe(const uint4 *__restrict__ src, float *__restrict__ out, int iters, unsigned src_units)
 {
     constexpr int A_U = 4096, B_U = 2048;                  // 64 KB + 32 KB of 16-byte units (an A band pair + B tiles)
-    __shared__ __attribute__((aligned(16))) uint4 lds[RB == 2 ? A_U + B_U + 512 : (A_U + B_U) / 2 + 768];
+    // (kind 3: the staging slots live in dma_win below, the same LDS footprint in total)
+    __shared__ __attribute__((aligned(16))) uint4 lds[KIND == 3 ? (RB * 4 + 4) * 256 + (RB == 2 ? 1024 : 512) : RB == 2 ? A_U + B_U + 512 : (A_U + B_U) / 2 + 768];
+    __shared__ __attribute__((aligned(16))) uint4 dma_win[KIND == 3 ? (RB == 2 ? 6 : 5) * 256 : 1];      // (its own object: the compiler must not order the fragment reads behind the DMA)
     constexpr int LU = sizeof(lds) / 16;
     constexpr unsigned MK = RB == 2 ? 1023u : 511u;        // the read base cycles through a power-of-two window; fragments sit at immediate offsets
     const int tid = threadIdx.x, lane = tid & 63;
@@ -84,7 +87,16 @@ k_probe(const uint4 *__restrict__ src, float *__restrict__ out, int iters, unsig
                             constexpr int GAP = (32 * RB) / (2 * NLD);
                             if (f % GAP == GAP - 1 && f / GAP < 2 * NLD) {
                                 const int slot = f / GAP, q = slot >> 1;
-                                if (slot & 1) {             // (a unit is stored one iteration after its load was issued, as in the kernel)
+                                if (KIND == 3) {            // LDS-DMA: the unit goes from L2 to its LDS slot (wave base + lane x 16 bytes) by itself;
+                                    if (slot < NLD) {       // all NLD issued in the first half of the iteration: the barrier's vmcnt(0) finds them done
+                                        typedef __attribute__((address_space(3))) void lds_void;
+                                        typedef const void __attribute__((address_space(1))) glb_void;
+                                        const int qq = slot;
+                                        const unsigned gi = qq == NLD - 1 ? gown : gsh;
+                                        __builtin_amdgcn_global_load_lds((glb_void *)(src + gi), (lds_void *)(dma_win + qq * 256 + (tid & ~63)), 16, 0, 0);
+                                        if (qq == NLD - 1) gown = own0 + ((gown + 256u) & 8191u); else gsh = (gsh + 256u) & 32767u;
+                                    }
+                                } else if (slot & 1) {      // (a unit is stored one iteration after its load was issued, as in the kernel)
                                     if (q == NLD - 1) { st[q] = src[gown]; gown = own0 + ((gown + 256u) & 8191u); }
                                     else { st[q] = src[gsh]; gsh = (gsh + 256u) & 32767u; }
                                 } else lds[rd + (RB * 4 + 4 + q) * 256] = st[q];
@@ -113,15 +125,15 @@ __global__ void __launch_bounds__(256) k_idle(float *out, int iters)
 }
 
 extern "C" {
-// rb: 1 | 2, kind: 0..2 (kind 3 = idle), wgs_per_cu: workgroups of 4 waves per CU.  Returns the MFMA count of the launch (0 for idle).
+// rb: 1 | 2, kind: 0..3 (kind 9 = idle), wgs_per_cu: workgroups of 4 waves per CU.  Returns the MFMA count of the launch (0 for idle).
 double probe_launch(int rb, int kind, int wgs_per_cu, int iters, const void *src, unsigned src_units, float *out, void *stream)
 {
     const int grid = 256 * wgs_per_cu;
     hipStream_t s = (hipStream_t)stream;
-    if (kind == 3) { hipLaunchKernelGGL(k_idle, dim3(grid), dim3(256), 0, s, out, iters); return 0.0; }
+    if (kind == 9) { hipLaunchKernelGGL(k_idle, dim3(grid), dim3(256), 0, s, out, iters); return 0.0; }
 #define GO(R, K) hipLaunchKernelGGL((k_probe<R, K>), dim3(grid), dim3(256), 0, s, (const uint4 *)src, out, iters, src_units)
-    if (rb == 1) { if (kind == 0) GO(1, 0); else if (kind == 1) GO(1, 1); else GO(1, 2); }
-    else { if (kind == 0) GO(2, 0); else if (kind == 1) GO(2, 1); else GO(2, 2); }
+    if (rb == 1) { if (kind == 0) GO(1, 0); else if (kind == 1) GO(1, 1); else if (kind == 2) GO(1, 2); else GO(1, 3); }
+    else { if (kind == 0) GO(2, 0); else if (kind == 1) GO(2, 1); else if (kind == 2) GO(2, 2); else GO(2, 3); }
 #undef GO
     return (double)grid * 4.0 * iters * 32.0 * rb;
 }

@@ -41,21 +41,23 @@ def main():
     print('# sensor: %s (%s); idle sample (W, MHz): %r' % (smp.src, smp.card, idle))
     print('# %-58s %-22s %9s %9s %8s %8s %8s %8s %6s' % ('variant', 'operands', 'us/launch', 'TFLOP/s', 'W', 'MHz', 'pJ/FLOP', 'W/GHz', 'busy'))
     variants = [
-        ('idle: resident waves in s_sleep', 1, 3, 2),
+        ('idle: resident waves in s_sleep', 1, 9, 2),
         ('A  MFMA only, 32-row tiles, 2 waves/SIMD (2 WG x 4 waves)', 1, 0, 2),
         ('A1 MFMA only, 32-row tiles, 1 wave/SIMD', 1, 0, 1),
         ('B  + LDS fragment reads (0.50 b128/MFMA), 2 waves/SIMD', 1, 1, 2),
         ('C  + staging (global loads + LDS stores), 2 waves/SIMD', 1, 2, 2),
+        ('D  + staging by LDS-DMA (global_load_lds_dwordx4), 2 waves/SIMD', 1, 3, 2),
         ('A2 MFMA only, 64-row tiles, 1 wave/SIMD', 2, 0, 1),
         ('B2 + LDS fragment reads (0.375 b128/MFMA), 1 wave/SIMD', 2, 1, 1),
         ('C2 + staging, 64-row tiles, 1 wave/SIMD', 2, 2, 1),
+        ('D2 + staging by LDS-DMA, 64-row tiles, 1 wave/SIMD', 2, 3, 1),
     ]
     stream = torch.cuda.current_stream().cuda_stream
     for name, rb, kind, wgs in variants:
         for dname, src in (('zeros', zero), ('relu+dropout (65 % zeros)', relu), ('dense normal', rnd)):
-            if kind == 3 and dname != 'zeros':
+            if kind == 9 and dname != 'zeros':
                 continue
-            it = args.iters if kind != 3 else 2000
+            it = args.iters if kind != 9 else 2000
             fn = lambda: lib.probe_launch(rb, kind, wgs, it, src.data_ptr(), units, out.data_ptr(), stream)
             for _ in range(10):
                 n_mfma = fn()
