@@ -548,6 +548,11 @@ __device__ __forceinline__ unsigned outer_tap_mask(int q0, int q1, const GemmGeo
 // least one sub-step after its load (so it never waits on it), and at most three passes are in flight
 // (register pressure: five would spill).
 constexpr int kBandOpsMax = 5;
+constexpr int band_op(int R, int K, int ti, int k);
+// row passes LOADED in sub-step ti of a group (op codes 0 .. R - 1), and whether the halo pass (R - 1) is among them: what the
+// wait in front of a sub-step's barrier leaves in flight behind the B tile's LDS-DMA (k_hgemm16_band)
+constexpr int band_loads_in(int R, int K, int ti) { int n = 0; for (int k = 0; k < kBandOpsMax; ++k) { const int q = band_op(R, K, ti, k); if (q >= 0 && q < R) ++n; } return n; }
+constexpr bool band_loads_halo_in(int R, int K, int ti) { for (int k = 0; k < kBandOpsMax; ++k) if (band_op(R, K, ti, k) == R - 1) return true; return false; }
 constexpr int band_op(int R, int K, int ti, int k)
 {
     if (R == 3 && K == 5) { const int t[5][5] = {{0, 1, -1, -1, -1}, {3, 2, -1, -1, -1}, {4, -1, -1, -1, -1}, {5, -1, -1, -1, -1}, {-1, -1, -1, -1, -1}}; return t[ti][k]; }
@@ -584,7 +589,13 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
     constexpr int BAND = TRIM ? BM : BM + KIN - 1;     // rows of the A band
     constexpr int A_U = (TRIM ? BM : BM + 8) * 16;     // 16-byte units of one band buffer
     constexpr int B_U = 16 * BF;
-    __shared__ __attribute__((aligned(16))) uint4 lds[2 * A_U + 2 * B_U];
+    // The B tiles go L2 -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds: no VGPR round trip, no ds_write; round 4, DESIGN 3.11 item 4b:
+    // +2.9 % in the isolated loop at unchanged clock and power, -0.13 ms on the step).  Their two buffers are OBJECTS of their own and
+    // which one a sub-step reads is a compile-time constant (the group loop runs two groups per trip): hipcc orders every later
+    // ds_read of an LDS object behind a pending LDS-DMA into it -- with one `lds[]` the fragment reads waited for vmcnt(0).
+    __shared__ __attribute__((aligned(16))) uint4 lds[2 * A_U];
+    __shared__ __attribute__((aligned(16))) uint4 ldsB0[B_U];
+    __shared__ __attribute__((aligned(16))) uint4 ldsB1[B_U];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -662,7 +673,7 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
     constexpr bool HALO = !TRIM;                    // pass RPTF holds the KIN - 1 halo rows (none when trimmed)
     constexpr int RPTF = HALO ? RPT3 - 1 : RPT3;    // full passes
     static_assert(RPTF * RPP == BM && RPTF <= 4, "band = up to four full passes (+ one halo pass)");
-    uint4 a0l, a0h, a1l, a1h, a2l, a2h, a3l, a3h, ah0, ah1, br0, br1, br2, br3;
+    uint4 a0l, a0h, a1l, a1h, a2l, a2h, a3l, a3h, ah0, ah1;
 
     // group the A loads fetch (outer tap at0/at1 = index aot, channel chunk akc); stops at the last
     int at0 = 0, at1 = 0, aot = 0, akc = 0, a_next = 0, adelta = 0;
@@ -723,14 +734,12 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
             if (++bti == KIN) { bti = 0; if (++bkc == nkc) { bkc = 0; bot = __builtin_ctz(tile_ot & (~1u << bot)); } }
         }
     };
-    auto load_b1 = [&](int k) {                     // one 16-byte unit of the B tile
-        const uint4 v = buf_load16b(rw, b_thr0, bsoff + (unsigned)k * b_kstep);
-        if (k == 0) br0 = v; else if (k == 1) br1 = v; else if (k == 2) br2 = v; else br3 = v;
-    };
-    auto store_b1 = [&](int k, int buf) {
-        uint4 *Bs = lds + 2 * A_U + buf * B_U;
-        Bs[tid + k * NTHR] = k == 0 ? br0 : k == 1 ? br1 : k == 2 ? br2 : br3;
-    };
+    // unit tid + k NTHR of the tile at bsoff -> its slot of a B buffer (lane-linear: wave base + lane x 16 bytes).  Sub-step s issues the DMA of
+    // tile s + 1 FIRST (a whole sub-step to arrive) and waits for it -- vmcnt(the A loads issued behind it) -- in front of its barrier:
+    // every wave's units are in LDS before anybody passes.
+    typedef __attribute__((address_space(3))) void lds_void;
+    const int dma_slot = tid & ~63;
+#define QK_DMA_B1(K, BUFOBJ) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void *)((BUFOBJ) + (K) * NTHR + dma_slot), 16, (int)b_thr0, (int)(bsoff + (unsigned)(K) * b_kstep), 0, 0)
     // The accumulators START at the bias (round 4): a lane's register r of component b holds channel (r & 3) + 8 (r >> 2) + 4 lh of
     // the wave's 32-channel block.  Added in the epilogue instead (LDS table + barrier + 16 ds_read_b128 + 64 adds) the
     // bias was HALF of the forward epilogue: 7.0 k cycles against backward-data's 3.6 k (tools/probe/phase_stamps.py).
@@ -741,12 +750,12 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
         for (int r = 0; r < 16; ++r) { acc[b][r] = 0.f; accn[b][r] = 0.f; }
 
     const int frow = wm * 32 + lr;                  // tile row this lane reads; band row = frow + tap offset
-    const int b_rd0 = 2 * A_U + wn * 32 + lr;
+    const int b_rd0 = wn * 32 + lr;
 
-    // ---- prologue: band 0, B tile 0 in LDS; B tile 1 in registers ---------------------------------
+    // ---- prologue: band 0 in LDS, B tile 0 on its way there (its DMA leads, the band's loads are behind it: their stores wait for both)
     b_prep();                                        // (the B tile needs no row decode: its loads lead)
 #pragma unroll
-    for (int k = 0; k < BU; ++k) load_b1(k);
+    for (int k = 0; k < BU; ++k) QK_DMA_B1(k, ldsB0);
     a_prep();
 #pragma unroll
     for (int r = 0; r < RPT3; ++r) { decode_row(r); load_a(r); }
@@ -761,14 +770,9 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
     for (int r = 0; r < RPT3; ++r) store_a(r, 0);
     QK_STAMP(6);
     a_advance_if_more();
-#pragma unroll
-    for (int k = 0; k < BU; ++k) store_b1(k, 0);
-    b_advance_if_more();
-    b_prep();
-#pragma unroll
-    for (int k = 0; k < BU; ++k) load_b1(k);
-    b_advance_if_more();
+    b_advance_if_more();                             // sub-step s fetches tile s + 1 straight into the other buffer
     if (g.has_bias && tid < 4 * BF) reinterpret_cast<float *>(lds + A_U)[tid] = bias_v;
+    __builtin_amdgcn_s_waitcnt((7 << 4) | (15 << 8));                  // vmcnt(0): B tile 0 is in LDS (the band's stores above waited for younger loads already)
     __syncthreads();
     if (g.has_bias) {
         const float4 *br = reinterpret_cast<const float4 *>(lds + A_U) + wn * 8 + (lane >> 5);
@@ -786,7 +790,13 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
     static_assert(kBandOpsMax + 2 * BU <= 16, "one staging slot after every second MFMA");
 
     int s = 0;                                      // global sub-step
-    for (int gi = (g.ablate & 4) ? groups : 0; gi < groups; ++gi) {      // (ablate 4: profiling, no K loop)
+    static_assert(KIN % 2 == 1, "parity of a group's first sub-step = parity of the group");
+    for (int gi2 = (g.ablate & 4) ? groups : 0; gi2 < groups; gi2 += 2)
+#pragma unroll
+    for (int gh = 0; gh < 2; ++gh) {                 // two groups per trip: the B buffer a sub-step reads is then a compile-time OBJECT
+        int gi = gi2 + gh;
+        if (gi >= groups) break;
+        asm volatile("" : "+s"(gi));                 // (its parity is known here; kept from the A band's addresses: hoisted for both groups they spilled 28 registers)
         const uint4 *band = lds + (gi & 1) * A_U;
         const int nband = (gi + 1) & 1;
         a_prep();
@@ -796,8 +806,8 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
             const int arow = frow + toff;
             const uint4 *a_rd = band + arow * 16;
             const int fsw = arow & 15;
-            const uint4 *b_rd = lds + b_rd0 + (s & 1) * B_U;
-            const int nb = (s + 1) & 1;
+            const int rdpar = (gh + ti) & 1;                       // (a constant once both loops are unrolled)
+            const uint4 *b_rd = (rdpar ? ldsB1 : ldsB0) + b_rd0;
             b_prep();
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
@@ -820,18 +830,25 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
                         else acc[b] = mfma16(T(), B[a ^ b], A[a], acc[b]);
                         const int f = ks * 16 + a * 4 + b;
                         if (f % 2 == 1) {
-                            const int op = f / 2;                        // staging slot of this sub-step
+                            const int op = f / 2 - BU;                   // the B tile's DMA leads: a whole sub-step to arrive
+                            if (op < 0) { if (rdpar) QK_DMA_B1(f / 2, ldsB0); else QK_DMA_B1(f / 2, ldsB1); }
+                            else
                             if (op < kBandOpsMax) {
                                 const int q = band_op(RPT3, KIN, ti, op);
                                 if (q >= RPT3) store_a(q - RPT3, nband);
                                 else if (q >= 0) load_a(q);
-                            } else if (op < kBandOpsMax + BU) store_b1(op - kBandOpsMax, nb);
-                            else if (op < kBandOpsMax + 2 * BU) load_b1(op - kBandOpsMax - BU);
+                            }
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
             }
             b_advance_if_more();
+            // every wave's DMA units of the next tile are IN LDS before anybody passes the barrier: all but the A loads issued behind
+            // them (two per row pass loaded in this sub-step; the halo pass, wave 0 only, not counted: wave 0 then waits for two more)
+#define QK_DMA_WAIT(TI) case TI: { constexpr int n_ld = band_loads_in(RPT3, KIN, TI < KIN ? TI : 0) - ((!TRIM && band_loads_halo_in(RPT3, KIN, TI < KIN ? TI : 0)) ? 1 : 0); \
+                __builtin_amdgcn_s_waitcnt(((2 * n_ld) & 15) | (7 << 4) | (15 << 8) | (((2 * n_ld) >> 4) << 14)); } break;
+            switch (ti) { QK_DMA_WAIT(0) QK_DMA_WAIT(1) QK_DMA_WAIT(2) QK_DMA_WAIT(3) QK_DMA_WAIT(4) default: __builtin_amdgcn_s_waitcnt(0); }
+#undef QK_DMA_WAIT
             __syncthreads();
         }
         a_advance_if_more();
