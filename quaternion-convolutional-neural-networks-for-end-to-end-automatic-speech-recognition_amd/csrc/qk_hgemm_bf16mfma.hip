@@ -543,10 +543,10 @@ __device__ __forceinline__ unsigned outer_tap_mask(int q0, int q1, const GemmGeo
     return (lo0 >= hi0 || lo1 >= hi1) ? 0u : (m1 * g.b_rep) & r0;
 }
 
-// A-band staging schedule of one group: op code q < R loads row pass q of the NEXT band into its
-// registers, R <= q < 2R stores pass q - R into the other band buffer, -1 = nothing.  A store comes at
-// least one sub-step after its load (so it never waits on it), and at most three passes are in flight
-// (register pressure: five would spill).
+// A-band staging schedule of one group: op code q < R fetches row pass q of the NEXT band (an LDS-DMA into the other band buffer
+// since the end of round 4; through registers before), -1 = nothing.  Codes R <= q < 2R were the register form's LDS stores --
+// at least one sub-step after their loads -- and are no-ops now: the table still says WHEN a pass is asked for, which is what the
+// vmcnt counts in front of the barriers are computed from.
 constexpr int kBandOpsMax = 5;
 constexpr int band_op(int R, int K, int ti, int k);
 // row passes LOADED in sub-step ti of a group (op codes 0 .. R - 1), and whether the halo pass (R - 1) is among them: what the
@@ -589,11 +589,17 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
     constexpr int BAND = TRIM ? BM : BM + KIN - 1;     // rows of the A band
     constexpr int A_U = (TRIM ? BM : BM + 8) * 16;     // 16-byte units of one band buffer
     constexpr int B_U = 16 * BF;
-    // The B tiles go L2 -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds: no VGPR round trip, no ds_write; round 4, DESIGN 3.11 item 4b:
-    // +2.9 % in the isolated loop at unchanged clock and power, -0.13 ms on the step).  Their two buffers are OBJECTS of their own and
-    // which one a sub-step reads is a compile-time constant (the group loop runs two groups per trip): hipcc orders every later
-    // ds_read of an LDS object behind a pending LDS-DMA into it -- with one `lds[]` the fragment reads waited for vmcnt(0).
-    __shared__ __attribute__((aligned(16))) uint4 lds[2 * A_U];
+    // EVERYTHING the kernel stages goes L2 / HBM -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds: no VGPR round trip, no ds_write; round 4,
+    // +2.9 % in the isolated loop at unchanged clock and power; -0.13 ms on the step for the B tiles, -0.20 ms
+    // more for the A band).  The two B buffers and the two band buffers are OBJECTS of their own and which ones a sub-step reads is a
+    // compile-time constant (the group loop runs two groups per trip): hipcc orders every later ds_read of an LDS object behind a
+    // pending LDS-DMA into it -- with one `lds[]` the fragment reads waited for vmcnt(0).
+    // Band buffer: two PLANES [row][8 units of 16 bytes] (components 0, 1 | 2, 3): the 8 DMA lanes of a row fill its 128 bytes of a plane,
+    // slot s of row r holding unit s ^ ((r >> 1) & 7) -- the swizzle sits on the SOURCE side (a DMA lane's slot is fixed) and keeps the
+    // 16 rows of a fragment read on 16 different bank groups.  Rows outside the tensor: out-of-range offsets, the DMA writes zeros.
+    __shared__ __attribute__((aligned(16))) uint4 ldsA0[A_U];
+    __shared__ __attribute__((aligned(16))) uint4 ldsA1[A_U];
+    constexpr int PL = A_U / 2;                        // one PLANE of a band buffer: [row][8 units] (components 0, 1 | 2, 3)
     __shared__ __attribute__((aligned(16))) uint4 ldsB0[B_U];
     __shared__ __attribute__((aligned(16))) uint4 ldsB1[B_U];
 
@@ -621,7 +627,7 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
     QK_STAMP(0);
 
     // ---- band rows of this thread (decoded once) ------------------------------------------------
-    // register staging: 8 threads per row, NTHR / 8 rows per pass
+    // staging: 8 threads (DMA lanes) per row, NTHR / 8 rows per pass
     constexpr int RPP = NTHR / 8;                   // rows per staging pass
     constexpr int RPT3 = (BAND + RPP - 1) / RPP;
     const int s_row = tid >> 3, s8 = tid & 7;
@@ -661,19 +667,20 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
     };
     const int groups = __builtin_popcount(tile_ot) * nkc;
     const int substeps = groups * KIN;
-    const int cmp_lo = s8 >> 2, sub = (s8 & 3) * 8;
+    // LDS-DMA: lane (row, slot s8) fills slot s8 of its row; that slot HOLDS unit s8 ^ ((row >> 1) & 7) (the fragment reads' bank swizzle,
+    // applied on the source side; 32 or 64 rows per pass: a constant of the thread)
+    static_assert((NTHR / 8) % 16 == 0, "rows per pass");
+    const int u_src = s8 ^ ((s_row >> 1) & 7);
+    const int cmp_lo = u_src >> 2, sub = (u_src & 3) * 8;
     const __amdgpu_buffer_rsrc_t rin = make_rsrc16(in, g.b_in_bytes), rw = make_rsrc16(wq, g.b_w_bytes);
     const unsigned a_thr = (unsigned)(cmp_lo * g.Q + sub) * 2u;         // this thread's (component, 8 channels) of a row
     const unsigned a_hi = (unsigned)g.Q * 4u;                            // two components further (wave-uniform)
     // B unit u = tid + k * NTHR lies (NTHR / BF) (slot, part) segments further per k: a wave-uniform offset
     const unsigned b_thr0 = (unsigned)((tid / BF) * g.J + j0 + tid % BF) * 16u;
     const unsigned b_kstep = (unsigned)((NTHR / BF) * g.J) * 16u;
-    // (named registers, not an array: hipcc leaves a 128-byte by-reference-captured array in scratch
-    // here -- every staged unit then takes a scratch round trip)
     constexpr bool HALO = !TRIM;                    // pass RPTF holds the KIN - 1 halo rows (none when trimmed)
     constexpr int RPTF = HALO ? RPT3 - 1 : RPT3;    // full passes
     static_assert(RPTF * RPP == BM && RPTF <= 4, "band = up to four full passes (+ one halo pass)");
-    uint4 a0l, a0h, a1l, a1h, a2l, a2h, a3l, a3h, ah0, ah1;
 
     // group the A loads fetch (outer tap at0/at1 = index aot, channel chunk akc); stops at the last
     int at0 = 0, at1 = 0, aot = 0, akc = 0, a_next = 0, adelta = 0;
@@ -696,30 +703,16 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
             if (++akc == nkc) { akc = 0; a_set_outer((unsigned)__builtin_ctz(tile_ot & (~1u << aot))); }
         }
     };
-    auto load_a = [&](int r) {
-        const bool ok = (omask[r] >> aot) & 1u;
-        const unsigned voff = ok ? (unsigned)(base_off[r] + adelta) * 2u + a_thr : kOutOfRange16;
-        if (r < RPTF || wave == 0) {                // the halo pass holds KIN - 1 <= 8 rows: wave 0 only
-            const uint4 vl = buf_load16b(rin, voff, 0);
-            const uint4 vh = buf_load16b(rin, voff, a_hi);
-            if (HALO && r == RPTF) { ah0 = vl; ah1 = vh; }
-            else if (r == 0) { a0l = vl; a0h = vh; }
-            else if (r == 1) { a1l = vl; a1h = vh; }
-            else if (r == 2) { a2l = vl; a2h = vh; }
-            else { a3l = vl; a3h = vh; }
-        }
-    };
-    auto store_a = [&](int r, int buf) {
-        const int row = s_row + r * RPP;
-        uint4 *As = lds + buf * A_U;
-        if (r < RPTF || (wave == 0 && row < BAND)) {
-            const bool halo = HALO && r == RPTF;
-            const uint4 vl = halo ? ah0 : r == 0 ? a0l : r == 1 ? a1l : r == 2 ? a2l : a3l;
-            const uint4 vh = halo ? ah1 : r == 0 ? a0h : r == 1 ? a1h : r == 2 ? a2h : a3h;
-            As[row * 16 + (s8 ^ (row & 15))] = vl;
-            As[row * 16 + ((s8 + 8) ^ (row & 15))] = vh;
-        }
-    };
+    typedef __attribute__((address_space(3))) void lds_void;
+    const int dma_slot = tid & ~63;
+    // row pass r of the band -> band buffer object BUFOBJ: two DMAs (planes 0 and 1), lane = (row s_row + r RPP, slot s8)
+#define QK_DMA_A(R, BUFOBJ) do { \
+        const bool ok_ = (omask[R] >> aot) & 1u; \
+        const unsigned voff_ = ok_ ? (unsigned)(base_off[R] + adelta) * 2u + a_thr : kOutOfRange16; \
+        if ((R) < RPTF || wave == 0) {               /* the halo pass holds KIN - 1 <= 8 rows: wave 0 only */ \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_void *)((BUFOBJ) + (R) * RPP * 8 + dma_slot), 16, (int)voff_, 0, 0, 0); \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_void *)((BUFOBJ) + PL + (R) * RPP * 8 + dma_slot), 16, (int)voff_, (int)a_hi, 0, 0); \
+        } } while (0)
     // sub-step the B loads fetch: (outer tap bot, chunk bkc, inner step bti); stops at the last
     int bot = 0, bkc = 0, bti = 0, b_next = 0;
     unsigned bsoff = 0;
@@ -737,8 +730,6 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
     // unit tid + k NTHR of the tile at bsoff -> its slot of a B buffer (lane-linear: wave base + lane x 16 bytes).  Sub-step s issues the DMA of
     // tile s + 1 FIRST (a whole sub-step to arrive) and waits for it -- vmcnt(the A loads issued behind it) -- in front of its barrier:
     // every wave's units are in LDS before anybody passes.
-    typedef __attribute__((address_space(3))) void lds_void;
-    const int dma_slot = tid & ~63;
 #define QK_DMA_B1(K, BUFOBJ) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void *)((BUFOBJ) + (K) * NTHR + dma_slot), 16, (int)b_thr0, (int)(bsoff + (unsigned)(K) * b_kstep), 0, 0)
     // The accumulators START at the bias (round 4): a lane's register r of component b holds channel (r & 3) + 8 (r >> 2) + 4 lh of
     // the wave's 32-channel block.  Added in the epilogue instead (LDS table + barrier + 16 ds_read_b128 + 64 adds) the
@@ -758,24 +749,24 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
     for (int k = 0; k < BU; ++k) QK_DMA_B1(k, ldsB0);
     a_prep();
 #pragma unroll
-    for (int r = 0; r < RPT3; ++r) { decode_row(r); load_a(r); }
+    for (int r = 0; r < RPT3; ++r) { decode_row(r); QK_DMA_A(r, ldsA0); }
     QK_STAMP(5);
-    // Bias -> accumulators, through LDS: one value per thread fetched behind the band's loads, parked at the start of band
-    // buffer 1 (first written by the staging of inner tap 1, i.e. behind the NEXT barrier) and read back as 16 broadcast
+    // Bias -> accumulators, through LDS: one value per thread fetched behind the band's loads, parked in the last rows of band
+    // buffer 1 (first written by a DMA issued in sub-step 1 or later, i.e. behind the NEXT barrier) and read back as 16 broadcast
     // ds_read_b128 per lane right behind the prologue's barrier.  (16 vector float4 loads per lane moved 64 KB per workgroup into
     // registers and cost 1.4 k cycles; wave-uniform scalar loads + a move and a select per register 1.2 k.)
     float bias_v = 0.f;
     if (g.has_bias && tid < 4 * BF) bias_v = bias[(tid / BF) * g.J + j0 + tid % BF];
-#pragma unroll
-    for (int r = 0; r < RPT3; ++r) store_a(r, 0);
     QK_STAMP(6);
     a_advance_if_more();
     b_advance_if_more();                             // sub-step s fetches tile s + 1 straight into the other buffer
-    if (g.has_bias && tid < 4 * BF) reinterpret_cast<float *>(lds + A_U)[tid] = bias_v;
+    // (parked in the LAST rows of band buffer 1: their DMA is issued in sub-step 1 or later, behind a barrier every wave passes after reading this)
+    static_assert(4 * BF * 4 <= 8 * 8 * 16, "the bias fits the rows of the band's last pass");
+    if (g.has_bias && tid < 4 * BF) (reinterpret_cast<float *>(ldsA1 + A_U) - 4 * BF)[tid] = bias_v;
     __builtin_amdgcn_s_waitcnt((7 << 4) | (15 << 8));                  // vmcnt(0): B tile 0 is in LDS (the band's stores above waited for younger loads already)
     __syncthreads();
     if (g.has_bias) {
-        const float4 *br = reinterpret_cast<const float4 *>(lds + A_U) + wn * 8 + (lane >> 5);
+        const float4 *br = reinterpret_cast<const float4 *>(reinterpret_cast<float *>(ldsA1 + A_U) - 4 * BF) + wn * 8 + (lane >> 5);
 #pragma unroll
         for (int b = 0; b < 4; ++b)
 #pragma unroll
@@ -796,16 +787,14 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
     for (int gh = 0; gh < 2; ++gh) {                 // two groups per trip: the B buffer a sub-step reads is then a compile-time OBJECT
         int gi = gi2 + gh;
         if (gi >= groups) break;
-        asm volatile("" : "+s"(gi));                 // (its parity is known here; kept from the A band's addresses: hoisted for both groups they spilled 28 registers)
-        const uint4 *band = lds + (gi & 1) * A_U;
-        const int nband = (gi + 1) & 1;
+        const uint4 *band = gh ? ldsA1 : ldsA0;          // (gi2 is even: the parity of a group is gh, and both band OBJECTS are compile-time constants)
         a_prep();
 #pragma unroll
         for (int ti = 0; ti < KIN; ++ti, ++s) {
             const int toff = g.b_rev ? KIN - 1 - ti : ti;
             const int arow = frow + toff;
-            const uint4 *a_rd = band + arow * 16;
-            const int fsw = arow & 15;
+            const uint4 *a_rd = band + arow * 8;
+            const int fsw = ((arow >> 1) & 7) ^ lh;
             const int rdpar = (gh + ti) & 1;                       // (a constant once both loops are unrolled)
             const uint4 *b_rd = (rdpar ? ldsB1 : ldsB0) + b_rd0;
             b_prep();
@@ -813,7 +802,7 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
             for (int ks = 0; ks < 2; ++ks) {
                 uint4 A[4], B[4];
 #pragma unroll
-                for (int a = 0; a < 4; ++a) A[a] = a_rd[(a * 4 + ks * 2 + lh) ^ fsw];
+                for (int a = 0; a < 4; ++a) A[a] = a_rd[(a >> 1) * PL + (((a & 1) * 4 + ks * 2) ^ fsw)];
 #pragma unroll
                 for (int p = 0; p < 4; ++p) B[p] = b_rd[((ks * 2 + lh) * 4 + p) * BF];
                 __builtin_amdgcn_sched_barrier(0);
@@ -834,9 +823,8 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
                             if (op < 0) { if (rdpar) QK_DMA_B1(f / 2, ldsB0); else QK_DMA_B1(f / 2, ldsB1); }
                             else
                             if (op < kBandOpsMax) {
-                                const int q = band_op(RPT3, KIN, ti, op);
-                                if (q >= RPT3) store_a(q - RPT3, nband);
-                                else if (q >= 0) load_a(q);
+                                const int q = band_op(RPT3, KIN, ti, op);      // (the schedule's "store" codes are no-ops: a DMA lands by itself)
+                                if (q >= 0 && q < RPT3) { if (gh) QK_DMA_A(q, ldsA0); else QK_DMA_A(q, ldsA1); }
                             }
                         }
                         __builtin_amdgcn_sched_barrier(0);
@@ -846,10 +834,14 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
             // every wave's DMA units of the next tile are IN LDS before anybody passes the barrier: all but the A loads issued behind
             // them (two per row pass loaded in this sub-step; the halo pass, wave 0 only, not counted: wave 0 then waits for two more)
 #define QK_DMA_WAIT(TI) case TI: { constexpr int n_ld = band_loads_in(RPT3, KIN, TI < KIN ? TI : 0) - ((!TRIM && band_loads_halo_in(RPT3, KIN, TI < KIN ? TI : 0)) ? 1 : 0); \
-                __builtin_amdgcn_s_waitcnt(((2 * n_ld) & 15) | (7 << 4) | (15 << 8) | (((2 * n_ld) >> 4) << 14)); } break;
+                __builtin_amdgcn_s_waitcnt(((2 * n_ld) & 15) | (7 << 4) | (0 << 8) | (((2 * n_ld) >> 4) << 14)); } break;       /* vmcnt(2 n_ld) lgkmcnt(0) */
             switch (ti) { QK_DMA_WAIT(0) QK_DMA_WAIT(1) QK_DMA_WAIT(2) QK_DMA_WAIT(3) QK_DMA_WAIT(4) default: __builtin_amdgcn_s_waitcnt(0); }
 #undef QK_DMA_WAIT
-            __syncthreads();
+            // the bare barrier: __syncthreads() is a workgroup FENCE too, and with band DMAs in flight that fence is vmcnt(0) -- the next
+            // band would have to arrive within the sub-step that asked for it.  What the barrier has to order is all here: this wave's
+            // fragment reads have returned (lgkmcnt(0)), its units of the next B tile are in LDS (the vmcnt above); the band in flight is
+            // complete behind the group's LAST wait (no loads in that sub-step: vmcnt(0)), one barrier before anybody reads it.
+            __builtin_amdgcn_s_barrier();
         }
         a_advance_if_more();
     }
@@ -879,7 +871,7 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
         }
     }
     float a_val = 0.f, dal = 0.f;
-    float *aslab = reinterpret_cast<float *>(reinterpret_cast<char *>(lds) + 32768);   // 256 d-alpha sums (backward post-op)
+    float *aslab = reinterpret_cast<float *>(ldsA1);                                   // 256 d-alpha sums (backward post-op)
     if ((EPM || POSTF) && post_on && g.post.alpha) a_val = g.post.alpha[a_key];
     // (the K loop's last barrier is behind every wave: the tile buffers are free)
     if (EPM && post_on && g.dalpha && tid < 256) aslab[tid] = 0.f;
