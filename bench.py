@@ -46,6 +46,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_TFLOPS = {'fp32': 157.3, 'bf16': 2500.0, 'fp16': 2500.0}   # MI355X_MICROARCH.md dense MFMA peaks
+NOMINAL_SCLK_MHZ = 2400.0        # the clock those peaks assume (MI355X_MICROARCH.md: max clock)
 TORCH_DT = {'fp32': torch.float32, 'bf16': torch.bfloat16, 'fp16': torch.float16}
 
 WORKLOADS = {
@@ -447,27 +448,99 @@ def _cpu_model_pass_time(cfg, threads, seconds, batch, loss='ctc'):
     return 1e3 * t_total / n, n
 
 
+def _numa_cores():
+    """[(node, [one logical CPU per physical core, ...]), ...] from sysfs, restricted to the CPUs this process may run on."""
+    import glob
+    allowed = os.sched_getaffinity(0) if hasattr(os, 'sched_getaffinity') else set(range(os.cpu_count() or 1))
+
+    def parse(txt):
+        out = []
+        for part in txt.strip().split(','):
+            if not part:
+                continue
+            lo, _, hi = part.partition('-')
+            out.extend(range(int(lo), int(hi or lo) + 1))
+        return out
+    nodes = []
+    for nd in sorted(glob.glob('/sys/devices/system/node/node[0-9]*'), key=lambda p: int(p.rsplit('node', 1)[1])):
+        try:
+            cpus = [c for c in parse(open(os.path.join(nd, 'cpulist')).read()) if c in allowed]
+        except Exception:
+            continue
+        seen, cores = set(), []
+        for c in cpus:
+            try:
+                sib = tuple(parse(open('/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list' % c).read()))
+            except Exception:
+                sib = (c,)
+            if sib[0] in seen:
+                continue
+            seen.add(sib[0])
+            cores.append(c)
+        if cores:
+            nodes.append((int(nd.rsplit('node', 1)[1]), cores))
+    if not nodes:
+        nodes = [(0, sorted(allowed))]
+    return nodes
+
+
+def _cpu_worker_main(spec):
+    """`python bench.py --cpu-worker '<json>'`: one thread count of the CPU baseline in a process of its own -- the OpenMP
+    runtime reads OMP_PROC_BIND / OMP_PLACES and the affinity mask when it starts, so they have to be in place before the
+    first parallel region (the parent set them)."""
+    cfg, th, seconds, loss, batch = spec['cfg'], spec['threads'], spec['seconds'], spec['loss'], spec['batch']
+    if cfg.get('kind') == 'model':
+        ms, n = _cpu_model_pass_time(cfg, th, seconds, batch, loss)
+    else:
+        ms, n = _cpu_layer_pass_time(cfg, th, seconds)
+    print('QK_CPU_WORKER ' + json.dumps({'ms': ms, 'n': n}))
+
+
 def cpu_baseline(cfg, seconds, loss='ctc'):
     """The reference's per-step CPU op sequence (expand kernel by concat -> one real conv / matmul -> bias ->
     activation; autograd backward) on this host's cores, fp32, bounded to ~`seconds` in total, for the SAME workload:
     the single layer (oracle/ref_port.py) or the full TIMIT model's TRAINING STEP -- dropout, loss, backward, l2, Adam --
-    on a batch of 32 (oracle/ref_model.py).  oneDNN does not scale these problems linearly to hundreds of threads, so the
-    thread counts {16, 64, 128, all} are tried in ascending order -- a count is skipped (None) once the previous one was 1.5x
-    slower than the best so far -- and the best is reported (`cores` = the thread count that produced `value`)."""
+    on a batch of 32 (oracle/ref_model.py).
+    Round 5: every thread count runs in a process of its own with its threads PINNED -- one per physical core, filling NUMA
+    node 0 first (`OMP_PROC_BIND=close`, `OMP_PLACES=cores`, affinity mask = exactly those cores).  Unpinned, oneDNN's
+    threads wandered over the 256-CPU host and more threads were SLOWER than fewer (round 4: 4.0 s @16, 5.4 s @64, 9.7 s
+    @128); the thread counts {16, 32, 64, one whole node} are tried, a count is skipped once the curve rises steeply, the
+    best is reported (`cores` = its thread count)."""
+    import subprocess
     ncpu = os.cpu_count() or 1
     is_model = cfg.get('kind') == 'model'
-    tries = sorted({min(ncpu, t) for t in ((16, 64, 128, ncpu) if is_model else (8, 32, 64, ncpu))})
+    nodes = _numa_cores()
+    order = [c for _, cores in nodes for c in cores]           # node 0's cores first, then node 1's, ...
+    node0 = len(nodes[0][1])
+    want = (16, 32, 64, node0) if is_model else (8, 16, 32, 64)
+    tries = sorted({max(1, min(len(order), t)) for t in want})
     sample_b = 32 if is_model else cfg['batch']
-    best, per, rising = None, {}, False
+    best, per, rising, pin = None, {}, False, {}
     for th in tries:
-        if best is not None and is_model and rising:
-            per[str(th)] = None            # the curve is already going up steeply (oneDNN on this model): 256 threads took 88 s per step
+        if best is not None and rising:
+            per[str(th)] = None
             continue
-        if is_model:
-            ms, n = _cpu_model_pass_time(cfg, th, seconds / len(tries), sample_b, loss)
-        else:
-            ms, n = _cpu_layer_pass_time(cfg, th, seconds / len(tries))
+        cpus = order[:th]
+        env = dict(os.environ, OMP_NUM_THREADS=str(th), MKL_NUM_THREADS=str(th), OMP_PROC_BIND='close', OMP_PLACES='cores',
+                   CUDA_VISIBLE_DEVICES='', HIP_VISIBLE_DEVICES='')
+        spec = json.dumps({'cfg': {k: (list(v) if isinstance(v, tuple) else v) for k, v in cfg.items()}, 'threads': th,
+                           'seconds': seconds / len(tries), 'loss': loss, 'batch': sample_b})
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-worker', spec], env=env, capture_output=True, text=True,
+                               timeout=max(120.0, 20.0 * seconds),
+                               preexec_fn=(lambda c=cpus: os.sched_setaffinity(0, c)) if hasattr(os, 'sched_setaffinity') else None)
+            line = [l for l in r.stdout.splitlines() if l.startswith('QK_CPU_WORKER ')]
+            if not line:
+                raise RuntimeError((r.stderr or r.stdout)[-300:])
+            res = json.loads(line[-1][len('QK_CPU_WORKER '):])
+            ms, n = res['ms'], res['n']
+        except Exception as e:                      # (no subprocess / no sysfs: the in-process, unpinned measurement of round 4)
+            per['%d_error' % th] = repr(e)[:200]
+            ms, n = (_cpu_model_pass_time(cfg, th, seconds / len(tries), sample_b, loss) if is_model
+                     else _cpu_layer_pass_time(cfg, th, seconds / len(tries)))
         per[str(th)] = round(ms, 2)
+        pin[str(th)] = 'cpus %d..%d (%d NUMA node%s)' % (cpus[0], cpus[-1], len({n_ for n_, cs in nodes for c in cs if c in set(cpus)}),
+                                                       '' if th <= node0 else 's')
         if best is None or ms < best[0]:
             best = (ms, n, th)
         rising = ms > 1.5 * best[0]
@@ -475,7 +548,10 @@ def cpu_baseline(cfg, seconds, loss='ctc'):
     what = ('the full TIMIT QCNN (n=%d, sf=%d, %d frames) through oracle/ref_model.py' % (cfg['layers'], cfg['sf'], cfg['frames'])
             if is_model else 'the same layer through oracle/ref_port.py')
     return {'value': sample_b / (ms * 1e-3), 'unit': 'samples/s', 'cores': th, 'kind': 'port',
-            'ms_per_step': ms, 'host_cpus': ncpu, 'threads_tried': tries, 'ms_per_step_by_threads': per, 'sample_batch': sample_b,
+            'ms_per_step': ms, 'host_cpus': ncpu, 'numa_nodes': len(nodes), 'physical_cores_node0': node0,
+            'threads_tried': tries, 'ms_per_step_by_threads': per, 'pinning': pin,
+            'thread_placement': 'one thread per physical core, NUMA node 0 first; OMP_PROC_BIND=close OMP_PLACES=cores; affinity mask = those cores; one process per thread count',
+            'sample_batch': sample_b,
             'sample': '%d timed %s of %s (reference op sequence, torch-CPU/oneDNN, fp32, batch %d%s)'
                       % (n, 'training steps (dropout, %s loss, backward, l2, Adam)' % loss if is_model else 'fwd+bwd passes', what, sample_b,
                          '' if is_model else ', no optimizer step')}
@@ -648,6 +724,8 @@ def dp_proof(job, steps, ms_per_step, per_rank, barrier, world, dev, dist):
 
 
 def main():
+    if len(sys.argv) == 3 and sys.argv[1] == '--cpu-worker':
+        return _cpu_worker_main(json.loads(sys.argv[2]))
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=None, help='timed steps (default: 100 for the QCNN, 300 for a layer)')
@@ -804,6 +882,14 @@ def main():
                                                         '(the calls include the ~5 us kernel re-layout launch that precedes the GEMM kernel)'
                                                         % (', '.join('%d x the %d-deep layer at %.3f ms' % (c['calls_per_step'], c['k'], c['ms']) for c in same),
                                                            total / calls, calls))
+    if rank == 0 and 'roofline' in out and tele_out and tele_out.get('mean_sclk_mhz'):
+        # `frac` is quoted on the nominal peak (2.4 GHz); the chip holds a lower clock under this load (power / current limiter,
+        # DESIGN.md 3.11) -- the same achieved rate against the peak AT THE CLOCK THE TIMED STEPS RAN AT says how much of the
+        # loss is structure and how much is clock
+        r = out['roofline']
+        r['sustained_clock_mhz'] = tele_out['mean_sclk_mhz']
+        r['peak_at_sustained_clock'] = peak * tele_out['mean_sclk_mhz'] / NOMINAL_SCLK_MHZ
+        r['frac_at_sustained_clock'] = r['achieved'] / r['peak_at_sustained_clock']
     if timing and is_model and not args.no_standalone:
         # free the model's activations before the layer-level timing runs
         model_job, job = job, None
@@ -876,6 +962,34 @@ def main():
             out['loss_variants']['note'] = ('BENCH_r01..r03 timed the `sum` loss (a linear stand-in); since round 4 the headline is the CTC cost the reference model '
                                             'outputs (interspeech_model.py:37-39,178).  Like-for-like with earlier rounds: loss_variants.sum.  The CTC step is slower than '
                                             'kernel(0.12 ms) + glue: its gradient distribution makes the backward kernels draw more power (DESIGN.md 3.11).')
+            try:        # BASELINE configs[4], the per-GPU half: the 10-deep 256-filter stack + head, fp16 (round-4 verdict: on the driver's line)
+                c5 = dict(WORKLOADS['cfg5_stack_b32_fp16'], activation='relu')
+                j5 = StackTrainStep(c5, dev, 0, 1)
+                t5 = GpuTelemetry(dev)
+                t5.start()
+                w5 = {}
+                el = timed_steps(j5, 12, 3, 2, barrier, 1, dev, dist, None, w5)
+                tele5 = t5.summary(*w5['window']) if 'window' in w5 else None
+                tf5 = 3 * j5.flops_per_kernel / (el / 12) / 1e12
+                blk = {'workload': 'cfg5_stack_b32_fp16', 'dtype': 'fp16', 'gemm_view': j5.gemm, 'steps': 12, 'warmup': 3, 'pre_warmup_steps': 2,
+                       'ms_per_step': 1e3 * el / 12, 'samples_per_s': c5['batch'] * 12 / el, 'tflops': tf5, 'frac_of_peak': tf5 / PEAK_TFLOPS['fp16'],
+                       'gpu_telemetry': tele5, 'loss': 'sum (linear stand-in: the stack has no softmax / CTC head)'}
+                k5 = in_step_kernel_times(j5, dev, PEAK_TFLOPS['fp16'], steps=2)
+                blk['in_step_kernels'] = k5
+                if k5.get('calls'):
+                    t = k5['calls'][0]
+                    blk['roofline'] = {'bound': 'mfma', 'kernel': '%s of the %d x %d x %d layer, in the step (%d calls per step x %.3f ms: largest share)'
+                                                                   % (t['op'], t['rows'], t['n'], t['k'], t['calls_per_step'], t['ms']),
+                                       'achieved': t['tflops'], 'peak': PEAK_TFLOPS['fp16'], 'unit': 'TFLOP/s', 'frac': t['frac_of_peak'], 'traffic': None,
+                                       'flops_per_launch': 2.0 * t['rows'] * t['n'] * t['k'], 'avg_launch_ms': t['ms']}
+                    if tele5 and tele5.get('mean_sclk_mhz'):
+                        blk['roofline']['sustained_clock_mhz'] = tele5['mean_sclk_mhz']
+                        blk['roofline']['frac_at_sustained_clock'] = t['tflops'] / (PEAK_TFLOPS['fp16'] * tele5['mean_sclk_mhz'] / NOMINAL_SCLK_MHZ)
+                out['cfg5_stack'] = blk
+                del j5
+                torch.cuda.empty_cache()
+            except Exception as e:
+                out['cfg5_stack'] = {'error': repr(e)}
             try:        # BASELINE configs[1]: the single QuaternionConv1D layer, step + kernels
                 c2 = dict(WORKLOADS['cfg2_qconv1d_timit_b64_fp32'], activation='relu')
                 j2 = LayerTrainStep(c2, dev, 0, 1)

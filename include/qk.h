@@ -135,6 +135,7 @@ const char *qk_last_error(void);
                                          * each element of dw / dbias receives exactly one (atomic) addition -- no
                                          * order-dependent float sums.  Several times slower (the reduction over positions is
                                          * no longer spread over the CUs): for debugging and for repeatability tests. */
+#define QK_DBG_WGRAD_BAND_V1 0x20000u /* 16-bit backward-weight band kernel in its round-2..4 form (register staging, two tile buffers; env QK_WGRAD_BAND_V1) -- A/B */
 #define QK_DBG_BAND16_8WAVES 16u   /* 16-bit band kernels: 8-wave workgroups (one per CU) instead of 4-wave (two per CU) */
 unsigned qk_set_debug_flags(unsigned flags);
 /* Profiling only: a device buffer (64 bytes per workgroup, 65536 workgroups) into which the 16-bit band kernels drop shader-clock time stamps of their

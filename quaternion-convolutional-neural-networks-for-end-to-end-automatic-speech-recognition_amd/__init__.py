@@ -11,6 +11,7 @@ from . import complexnn                             # noqa: F401
 from . import layers, data, dp                      # noqa: F401
 from . import models                                # noqa: F401
 from .complexnn import *                            # noqa: F401,F403
+from .functional import invalidate_cached_kernels   # noqa: F401  (after raw `.data` writes to layer weights)
 
 __version__ = '0.1.0'
 

@@ -30,6 +30,7 @@ unsigned env_flags()
     if (getenv("QK_NO_POINT16")) f |= kDbgNoPoint16;
     if (getenv("QK_CTC_TWO_SWEEPS")) f |= kDbgCtcTwoSweeps;
     if (getenv("QK_DETERMINISTIC")) f |= kDbgDeterministic;
+    if (getenv("QK_WGRAD_BAND_V1")) f |= kDbgWgradBandV1;
     if (const char *ab = getenv("QK_ABLATE")) f |= ((unsigned)atoi(ab) << kDbgAblateShift) & kDbgAblateMask;
     return f;
 }

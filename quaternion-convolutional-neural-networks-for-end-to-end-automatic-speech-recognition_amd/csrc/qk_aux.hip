@@ -464,7 +464,9 @@ int launch_softmax_rows(int dtype, bool backward, const void *a, const void *b, 
                         hipStream_t stream)
 {
     long long blocks = (rows + 15) / 16;              // four rows per wave at least
-    const long long cap = backward ? 512 : 2048;      // (backward: one atomic per class and workgroup)
+    // (backward: one atomic per class and workgroup; QK_DBG_DETERMINISTIC: ONE workgroup -- each bias column receives a single
+    //  addition, its four wave partials summed in a fixed order)
+    const long long cap = backward ? (((debug_flags() & kDbgDeterministic) && dbias) ? 1 : 512) : 2048;
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
 #define QK_SM(T) do { if (backward) hipLaunchKernelGGL((k_softmax_rows_bwd<T>), dim3((unsigned)blocks), dim3(256), 0, stream, (const T *)a, (const T *)b, (T *)out, dbias, rows, cols); \
@@ -478,6 +480,7 @@ int launch_weighted_sum(int dtype, const void *a, const float *w, float *out, lo
 {
     long long blocks = (n / 4 + 255) / 256;
     if (blocks > 512) blocks = 512;                   // one atomic per workgroup on ONE address: keep them few
+    if (debug_flags() & kDbgDeterministic) blocks = 1;                  // ... and exactly one when the sum has to be bit-repeatable
     if (blocks < 1) blocks = 1;
     if (dtype == QK_F32) hipLaunchKernelGGL((k_weighted_sum<float>), dim3((unsigned)blocks), dim3(256), 0, stream, (const float *)a, w, out, n);
     else if (dtype == QK_BF16) hipLaunchKernelGGL((k_weighted_sum<bf16>), dim3((unsigned)blocks), dim3(256), 0, stream, (const bf16 *)a, w, out, n);

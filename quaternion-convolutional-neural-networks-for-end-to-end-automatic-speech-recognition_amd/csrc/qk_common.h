@@ -271,7 +271,7 @@ void note_path(int qk_path);          // thread-local record behind qk_last_path
 enum : unsigned {
     kDbgNoMfma16 = QK_DBG_NO_MFMA16, kDbgNoBand16 = QK_DBG_NO_BAND16, kDbgNoBand32 = QK_DBG_NO_BAND32,
     kDbgWgradOneTap = QK_DBG_WGRAD16_ONE_TAP, kDbgBand8Waves = QK_DBG_BAND16_8WAVES, kDbgNoWgradBand = QK_DBG_NO_WGRAD_BAND,
-    kDbgNoPoint16 = QK_DBG_NO_POINT16, kDbgCtcTwoSweeps = QK_DBG_CTC_TWO_SWEEPS, kDbgDeterministic = QK_DBG_DETERMINISTIC, kDbgAblateShift = 8, kDbgAblateMask = 0xffu << 8
+    kDbgNoPoint16 = QK_DBG_NO_POINT16, kDbgCtcTwoSweeps = QK_DBG_CTC_TWO_SWEEPS, kDbgDeterministic = QK_DBG_DETERMINISTIC, kDbgWgradBandV1 = QK_DBG_WGRAD_BAND_V1, kDbgAblateShift = 8, kDbgAblateMask = 0xffu << 8
 };
 unsigned debug_flags();
 unsigned long long *debug_buffer(size_t *bytes);      // qk_set_debug_buffer (qk_api.hip)

@@ -14,6 +14,7 @@
 // LDS (one barrier per frame), alpha of every frame goes to a workspace for the backward sweep, the emission of the NEXT
 // frame is fetched before the barrier of the current one.  Latency-bound by construction (T dependent steps): ~0.1 ms.
 #include "qk_common.h"
+#include <atomic>
 
 namespace qk {
 namespace {
@@ -34,7 +35,7 @@ __device__ __forceinline__ float lse3(float a, float b, float c)
     return m + __logf(__expf(a - m) + __expf(b - m) + __expf(c - m));
 }
 
-struct CtcGeom { int B, T, C, Lmax, Smax; float eps; };
+struct CtcGeom { int B, T, C, Lmax, Smax; float eps; int det; };      // det (QK_DBG_DETERMINISTIC): occupancies summed in a fixed order
 
 // LPS: the whole (T, C) log-probability table of the sample fits in LDS (TIMIT: 200 x 62 floats = 50 KB) and is built once, with
 // coalesced loads -- every emission of the two sweeps and the gradient then comes from LDS; otherwise emissions are gathered from
@@ -45,11 +46,14 @@ k_ctc(const T *__restrict__ pred, const int *__restrict__ labels, const int *__r
       float *__restrict__ cost, T *__restrict__ dpred, float *__restrict__ alpha_ws, const CtcGeom g)
 {
     extern __shared__ float smem[];
-    // LDS: lse[T] | a[2][Smax] | acc[C] | one float (nll)            (labels are read through registers)
+    // LDS: lse[T] | a[2][Smax] | acc[2][C] | qs[2][Smax] | one float (nll)            (labels are read through registers)
+    // (acc and qs alternate with the frame's parity: the threads that turn frame t's occupancies into its gradient do so
+    //  while the others already add frame t - 1's -- with one table that was a race)
     float *lse = smem;
     float *ab0 = lse + g.T;
-    float *acc = ab0 + 2 * g.Smax;
-    float *nll_s = acc + g.C;
+    float *acc2 = ab0 + 2 * g.Smax;
+    float *qs2 = acc2 + 2 * g.C;
+    float *nll_s = qs2 + 2 * g.Smax;
     float *lpt = nll_s + 4;                    // LPS: lp[t][c]
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int Tn = min(max(in_len[b], 0), g.T);
@@ -78,7 +82,7 @@ k_ctc(const T *__restrict__ pred, const int *__restrict__ labels, const int *__r
         for (int c = 0; c < g.C; ++c) sum += __expf((LPS ? lpt[t * g.C + c] : __logf(to_f32(p[t * g.C + c]) + g.eps)) - m);
         lse[t] = m + __logf(sum);
     }
-    if (tid < g.C) acc[tid] = 0.f;
+    if (tid < 2 * g.C) acc2[tid] = 0.f;
     __syncthreads();
     if constexpr (LPS) {
         for (int e = tid; e < Tn * g.C; e += CTC_THREADS) lpt[e] -= lse[e / g.C];
@@ -155,11 +159,16 @@ k_ctc(const T *__restrict__ pred, const int *__restrict__ labels, const int *__r
         float q = 0.f;
         if (live && a_cur > -1e29f && bt > -1e29f) q = __expf(a_cur + bt - e_cur + nll);
         // blanks (even states) are half of the states: reduce them inside the wave first, one LDS atomic per wave
-        float qb = (live && !(s & 1)) ? q : 0.f;
+        float *acc = acc2 + (t & 1) * g.C, *qs = qs2 + (t & 1) * g.Smax;
+        if (g.det) {
+            if (live) qs[s] = q;                      // summed per class in state order below: no float atomics
+        } else {
+            float qb = (live && !(s & 1)) ? q : 0.f;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) qb += __shfl_xor(qb, o);
-        if (lane == 0 && qb != 0.f) atomicAdd(&acc[blank], qb);
-        if (live && (s & 1) && q != 0.f) atomicAdd(&acc[cls], q);
+            for (int o = 32; o > 0; o >>= 1) qb += __shfl_xor(qb, o);
+            if (lane == 0 && qb != 0.f) atomicAdd(&acc[blank], qb);
+            if (live && (s & 1) && q != 0.f) atomicAdd(&acc[cls], q);
+        }
         // next frame's operands, in flight across the barriers
         float e_nx = 0.f, a_nx = kNegInf;
         if (live && t > 0) { e_nx = emit(t - 1); a_nx = aws[(long long)(t - 1) * g.Smax + s]; }
@@ -168,7 +177,15 @@ k_ctc(const T *__restrict__ pred, const int *__restrict__ labels, const int *__r
             float pc, soft;
             if constexpr (LPS) { const float l = lpt[t * g.C + c]; soft = __expf(l); pc = __expf(l + lse[t]); }
             else { pc = to_f32(p[t * g.C + c]) + g.eps; soft = __expf(__logf(pc) - lse[t]); }
-            const float gu = soft - acc[c];
+            float oc = acc[c];
+            if (g.det) {
+                oc = 0.f;
+                for (int st = 0; st < S; ++st) {
+                    const int cl = (st & 1) ? min(max(labels[b * g.Lmax + (st >> 1)], 0), g.C - 1) : blank;
+                    if (cl == c) oc += qs[st];
+                }
+            }
+            const float gu = soft - oc;
             dp[t * g.C + c] = from_f32<T>(gu / pc);
             acc[c] = 0.f;
         }
@@ -283,6 +300,19 @@ k_ctc_fast(const T *__restrict__ pred, const int *__restrict__ labels, const int
     // ---- phase 2: occupancies of every (frame, state) in parallel, then the gradient table -----------------------------------
     const float *al = alpha_ws + (long long)b * g.T * g.Smax, *be = beta_ws + (long long)b * g.T * g.Smax;
     const int Sp = (S + 63) & ~63;                   // a wave = 64 consecutive states of ONE frame
+    if (g.det) {
+        // QK_DBG_DETERMINISTIC: one owner per (frame, class) sums its states in order (Tn x C x S work instead of Tn x S)
+        for (int e = tid; e < Tn * g.C; e += CTCF_THREADS) {
+            const int t = e / g.C, c = e - t * g.C;
+            float oc = 0.f;
+            for (int st = 0; st < S; ++st) {
+                if (cls_l[st] != c) continue;
+                const float a = al[(long long)t * g.Smax + st], bt = be[(long long)t * g.Smax + st];
+                if (a > -1e29f && bt > -1e29f) oc += __expf(a + bt - lpt[e] + nll);
+            }
+            occ[e] = oc;
+        }
+    } else
     for (int idx = tid; idx < Tn * Sp; idx += CTCF_THREADS) {
         const int t = idx / Sp, st = idx - t * Sp;
         float q = 0.f;
@@ -315,7 +345,8 @@ int launch_ctc(int dtype, int B, int T, int C, const void *pred, const int *labe
 {
     CtcGeom g;
     g.B = B; g.T = T; g.C = C; g.Lmax = Lmax; g.Smax = 2 * Lmax + 1; g.eps = 1e-7f;
-    const size_t base = (size_t)(T + 2 * g.Smax + C + 4) * sizeof(float);
+    g.det = (debug_flags() & kDbgDeterministic) ? 1 : 0;
+    const size_t base = (size_t)(T + 4 * g.Smax + 2 * C + 4) * sizeof(float);
     const size_t full = base + (size_t)T * C * sizeof(float);
     if (g.Smax > CTC_THREADS || C > CTC_THREADS || base > 64 * 1024) return QK_ERR_UNSUPPORTED;
     // fast form: both tables (log-probabilities, occupancies) of the sample in LDS
@@ -323,9 +354,16 @@ int launch_ctc(int dtype, int B, int T, int C, const void *pred, const int *labe
     if (fast_lds <= 150 * 1024 && !(debug_flags() & kDbgCtcTwoSweeps)) {
         float *beta_ws = ws + (size_t)B * T * g.Smax;
         dim3 grid((unsigned)B), block(CTCF_THREADS);
-        // (more than 64 KB of dynamic LDS must be asked for explicitly; idempotent, a few hundred ns)
-#define QK_CTCF(TT) do { if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ctc_fast<TT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast_lds) != hipSuccess) return QK_ERR_LAUNCH; \
-        hipLaunchKernelGGL((k_ctc_fast<TT>), grid, block, fast_lds, stream, (const TT *)pred, labels, in_len, lab_len, cost, (TT *)dpred, ws, beta_ws, g); } while (0)
+        // More than 64 KB of dynamic LDS must be asked for explicitly.  The largest size granted so far is remembered per element
+        // type (one relaxed atomic, as the debug mask): the attribute call is made only when a call needs more.  A device that
+        // refuses the size (less opt-in LDS than gfx950's 160 KB) is no error: the two-sweep kernel below takes the call.
+        bool fast_ok = true;
+#define QK_CTCF(TT) do { static std::atomic<int> granted{0}; \
+        if ((int)fast_lds > granted.load(std::memory_order_relaxed)) { \
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ctc_fast<TT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast_lds) == hipSuccess) \
+                granted.store((int)fast_lds, std::memory_order_relaxed); \
+            else { (void)hipGetLastError(); fast_ok = false; } } \
+        if (fast_ok) hipLaunchKernelGGL((k_ctc_fast<TT>), grid, block, fast_lds, stream, (const TT *)pred, labels, in_len, lab_len, cost, (TT *)dpred, ws, beta_ws, g); } while (0)
         switch (dtype) {
         case QK_F32: QK_CTCF(float); break;
         case QK_BF16: QK_CTCF(bf16); break;
@@ -333,7 +371,7 @@ int launch_ctc(int dtype, int B, int T, int C, const void *pred, const int *labe
         default: return QK_ERR_INVALID_ARG;
         }
 #undef QK_CTCF
-        return hipGetLastError() == hipSuccess ? 0 : QK_ERR_LAUNCH;
+        if (fast_ok) return hipGetLastError() == hipSuccess ? 0 : QK_ERR_LAUNCH;
     }
     const bool lps = full <= 64 * 1024;
     const size_t lds = lps ? full : base;

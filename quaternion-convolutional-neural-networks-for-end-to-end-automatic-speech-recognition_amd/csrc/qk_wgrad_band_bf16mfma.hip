@@ -380,6 +380,332 @@ k_wgrad16_band(const T *__restrict__ x, const T *__restrict__ dy, const T *__res
     }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Round 5: the LINEAR form (no relu mask to apply: what a chain of layers runs) staged by LDS-DMA, three tile buffers.
+//
+// What bound k_wgrad16_band (65 % MFMA-busy on all-zero operands, 29 % of the wave cycles parked, 3.2 non-MFMA VALU per MFMA):
+//   * one barrier per 64-position K step with nothing in flight across it -- behind the barrier all eight waves issue their
+//     first fragment reads and the matrix pipe idles for an LDS round trip, 544 times per block;
+//   * tiles travelled global -> 24 staging registers -> ds_write_b128; the per-thread row decode ran on the VALU in every wave;
+//     the tap windows were cut out of registers (v_alignbit / moves of misaligned register tuples: 12 VALU per 10 MFMAs).
+// Here:
+//   * X and dY tiles go L2 -> LDS by `buffer_load_dwordx4 ... lds`.  Every tile is a set of PLANES [row][128 bytes] (8 DMA
+//     lanes fill one row of a plane: thread = (row tid >> 3, unit tid & 7) as before), the two 64-byte blocks of a row swapped
+//     for rows with (row >> 1) & 1 on the SOURCE side: the four rows a transposing read touches per 32 lanes then sit on the
+//     four 16-bank groups (pad-free, conflict-free for every tap offset);
+//   * THREE tile buffers (objects of their own; the loop is unrolled by three so that every buffer is a compile-time object --
+//     hipcc orders a ds_read behind every pending LDS-DMA into the same object): tile it + 2 is asked for in the second half of
+//     step it and is waited for in the middle of step it + 1 (a whole K step to arrive), in front of the ONE barrier of a step,
+//     which also says that tile it - 1's buffer is free.  The fragments of a sub-step are read during the sub-step before it
+//     (two fragment sets), across the step boundary too: nothing drains at the barrier;
+//   * the tap windows are LDS addresses (tap t = the same transposing read t rows further down: 2 KIN + 4 reads per sub-step,
+//     immediate offsets, no VALU); rows are decoded from wave-uniform LINE state kept in scalar registers (a K step touches two
+//     padded lines at most) -- per thread one compare and a few selects; the bias gradient comes from v_dot2c on the dY
+//     fragments the MFMAs use anyway (no LDS column reads).
+// ---------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) char lds_char;
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float dot_ones(bf16, unsigned w, float c)
+{
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w), __builtin_bit_cast(bf16x2_t, 0x3F803F80u), c, false);
+}
+__device__ __forceinline__ float dot_ones(f16, unsigned w, float c)
+{
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2_t, w), __builtin_bit_cast(f16x2_t, 0x3C003C00u), c, false);
+}
+__device__ __forceinline__ v8s tr_pair(const lds_char *p)                 // rows r .. r + 3 and r + 4 .. r + 7 of a 128-byte-pitch plane
+{
+    const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s *)(p));
+    const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s *)(p + 512));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+template <typename T, int RTT, int KIN>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_wgrad16_band3(const T *__restrict__ x, const T *__restrict__ dy, float *__restrict__ dw, float *__restrict__ dbias, const WgradGeom g)
+{
+    static_assert(RTT == 2 || RTT == 4, "row tiles per tap");
+    static_assert(KIN == 3 || KIN == 5, "inner taps");
+    constexpr int NTHR = 512, WCG = 8 / RTT, CTW = 2;
+    constexpr int CQB = RTT * 8, BF = WCG * CTW * 8;          // channels / filters per block
+    constexpr int KM = 64, KS = KM / 16, NMF = KIN * CTW;
+    constexpr int NPX = (4 * CQB * 2) / 128, NPD = (4 * BF * 2) / 128;     // 128-byte planes of an X / dY row
+    constexpr int XROWS = KM + 8;                             // + the halo rows (KIN - 1 <= 8: one DMA of wave 0)
+    constexpr int XPL = XROWS * 128, DPL = KM * 128;          // bytes of one plane
+    constexpr int DOFF = NPX * XPL;                           // dY planes behind the X planes
+    constexpr int BUFB = NPX * XPL + NPD * DPL;
+    constexpr int TAPB = CQB * 4 * BF * 4;                    // fold slab of one tap
+    static_assert(2 * TAPB <= BUFB, "two taps of the fold slab per tile buffer");
+    static_assert((KIN + 1) / 2 <= 3, "three tile buffers");
+    __shared__ __attribute__((aligned(1024))) char lds0[BUFB];
+    __shared__ __attribute__((aligned(1024))) char lds1[BUFB];
+    __shared__ __attribute__((aligned(1024))) char lds2[BUFB];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rt = wave / WCG, cg = wave % WCG;
+    // ---- which block (as k_wgrad16_band)
+    const int n_ot = g.ks[0] * g.ks[1];
+    const int ncc = g.Cq / CQB, nfc = g.F / BF;
+    const int n_inner = n_ot * ncc * nfc;
+    const int n_tiles = n_inner * g.n_splits;
+    const int per_xcd = (n_tiles + 7) / 8;
+    const int tile = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+    if (tile >= n_tiles) return;
+    const int split = tile / n_inner;
+    const int inner = tile - split * n_inner;
+    const int ot = inner % n_ot;
+    const int chunk = inner / n_ot;
+    const int cchunk = chunk / nfc, fchunk = chunk - cchunk * nfc;
+    const int c0 = cchunk * CQB, f0 = fchunk * BF;
+    const int t0 = ot / g.ks[1], t1 = ot - t0 * g.ks[1];
+    const int WP = g.b_wp, W = g.osp[2];
+    const int p_begin = split * g.m_per_split;
+    const int p_end = min(g.b_nlines * WP, p_begin + g.m_per_split);
+    const bool share0 = ot * ncc + cchunk == 0;
+    const int n_share = g.deterministic ? (share0 ? 1 : (1 << 30)) : n_ot * ncc;
+    const bool bias_wave = g.want_dbias != 0 && rt == 0;      // the waves of row tile 0 hold every column tile of the block once
+    int turn = g.deterministic ? (share0 ? 0 : (1 << 29)) : ot * ncc + cchunk;      // 0 => this K step's bias sums are ours
+
+    // ---- staging: thread = (row s_row, 16-byte unit s_sub) of a plane; the unit it FETCHES is s_sub with the row's block swap
+    constexpr int UC = CQB / 8, UF = BF / 8;        // units per component block of an X / dY row
+    const int s_row = tid >> 3, s_sub = tid & 7;
+    const int s_src = s_sub ^ (((s_row >> 1) & 1) << 2);
+    const __amdgpu_buffer_rsrc_t rx = rsrc_of(x, g.x_bytes), rdy = rsrc_of(dy, g.dy_bytes);
+    const unsigned x_thr = (unsigned)((s_src / UC) * g.Cq + c0 + (s_src % UC) * 8) * 2u;
+    const unsigned d_thr = (unsigned)((s_src / UF) * g.F + f0 + (s_src % UF) * 8) * 2u;
+    const unsigned x_pstep = (unsigned)((8 / UC) * g.Cq) * 2u, d_pstep = (unsigned)((8 / UF) * g.F) * 2u;     // plane -> plane (wave-uniform)
+    const unsigned xs2 = (unsigned)((int)g.x_ss[2]) * 2u, dys = (unsigned)((int)g.dy_ss) * 2u;               // position -> position
+    // ---- wave-uniform line state: a K step's rows lie on padded line A (the line of its row 0) or on B = A + 1
+    int su0, Pj, lineB, nB, o0B, o1B;
+    unsigned xbA, xbB, dbA, dbB;
+    int xvA, xvB, dvA, dvB;
+    auto line_vals = [&](int line, int n, int o0, int o1, unsigned &xb, int &xv, unsigned &db, int &dv) {
+        const int i0 = o0 * g.pa[0] + t0 * g.pb[0] + g.pc[0], i1 = o1 * g.pa[1] + t1 * g.pb[1] + g.pc[1];
+        dv = line < g.b_nlines;
+        xv = dv && (unsigned)i0 < (unsigned)g.isp[0] && (unsigned)i1 < (unsigned)g.isp[1];
+        xb = (unsigned)(n * (int)g.x_sn + i0 * (int)g.x_ss[0] + i1 * (int)g.x_ss[1] + g.b_cshift * (int)g.x_ss[2]) * 2u;
+        db = (unsigned)(line * W * (int)g.dy_ss) * 2u;
+    };
+    {
+        const int line = p_begin / WP;
+        su0 = p_begin - line * WP; Pj = p_begin;
+        int l = line;
+        const int o1 = l % g.osp[1]; l /= g.osp[1];
+        const int o0 = l % g.osp[0];
+        const int n = l / g.osp[0];
+        line_vals(line, n, o0, o1, xbA, xvA, dbA, dvA);
+        lineB = line; nB = n; o0B = o0; o1B = o1;
+    }
+    auto next_line = [&]() {
+        ++lineB; ++o1B;
+        if (o1B == g.osp[1]) { o1B = 0; ++o0B; if (o0B == g.osp[0]) { o0B = 0; ++nB; } }
+        line_vals(lineB, nB, o0B, o1B, xbB, xvB, dbB, dvB);
+    };
+    next_line();
+    auto advance_tile = [&]() {
+        su0 += KM; Pj += KM;
+        if (su0 >= WP) { su0 -= WP; xbA = xbB; xvA = xvB; dbA = dbB; dvA = dvB; next_line(); }
+    };
+    // byte offsets of the units this thread fetches for the tile the line state points at: its X row, its dY row, and (wave 0)
+    // its halo row KM + s_row
+    unsigned vx = kOOR, vd = kOOR, vh = kOOR;
+    auto decode_x = [&](int r) -> unsigned {
+        const int t = su0 + r;
+        const bool selB = t >= WP;
+        const int u = selB ? t - WP : t;
+        const bool ok = (selB ? xvB : xvA) != 0 && (unsigned)(u + g.b_cshift) < (unsigned)g.isp[2] && Pj + r < p_end + KIN - 1;
+        return ok ? (selB ? xbB : xbA) + (unsigned)u * xs2 + x_thr : kOOR;
+    };
+    auto decode_rows = [&]() {
+        vx = decode_x(s_row);
+        {
+            const int t = su0 + s_row;
+            const bool selB = t >= WP;
+            const int u = selB ? t - WP : t;
+            const bool ok = (selB ? dvB : dvA) != 0 && u < W && Pj + s_row < p_end;
+            vd = ok ? (selB ? dbB : dbA) + (unsigned)u * dys + d_thr : kOOR;
+        }
+        if (wave == 0) vh = decode_x(KM + s_row);
+    };
+    const int dma_w = wave * 1024;                  // this wave's 8 rows of a plane
+#define QK_DMA_X(BUF)  do { _Pragma("unroll") for (int p_ = 0; p_ < NPX; ++p_) \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void_t *)((lds_char *)(BUF) + p_ * XPL + dma_w), 16, (int)vx, (int)(p_ * x_pstep), 0, 0); } while (0)
+#define QK_DMA_H(BUF)  do { if (wave == 0) { _Pragma("unroll") for (int p_ = 0; p_ < NPX; ++p_) \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void_t *)((lds_char *)(BUF) + p_ * XPL + KM * 128), 16, (int)vh, (int)(p_ * x_pstep), 0, 0); } } while (0)
+#define QK_DMA_D1(BUF, P_) __builtin_amdgcn_raw_ptr_buffer_load_lds(rdy, (lds_void_t *)((lds_char *)(BUF) + DOFF + (P_) * DPL + dma_w), 16, (int)vd, (int)((P_) * d_pstep), 0, 0)
+
+    floatx16 acc[KIN][CTW];
+#pragma unroll
+    for (int t = 0; t < KIN; ++t)
+#pragma unroll
+        for (int ct = 0; ct < CTW; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][ct][r] = 0.f;
+    float dbacc[CTW] = {0.f, 0.f};
+
+    // ---- fragment addresses: lane -> (row fr_row of the 16 a transposing read pair covers, 8-byte chunk fr_ch) --------------
+    const int Lg = lane & 15, g16 = (lane >> 4) & 1, kh = lane >> 5;
+    const int fr_row = 8 * kh + (Lg >> 2);
+    const int fr_ch = 16 * g16 + 4 * (Lg & 3);
+    // band row = c + fr_row with c = 16 ks + t known at compile time; the row's block swap is ((c + fr_row) >> 1) & 1
+    //   = ((c >> 1) & 1) ^ (((fr_row + (c & 1)) >> 1) & 1): four per-lane bases (c & 1, (c >> 1) & 1), everything else an immediate
+    int a_base[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const int e = v >> 1, mb = v & 1;
+        const int sw = (((fr_row + e) >> 1) & 1) ^ mb;
+        a_base[v] = (rt >> 1) * XPL + fr_row * 128 + (((rt & 1) ^ sw) * 64) + fr_ch * 2;
+    }
+    int b_base[CTW];
+#pragma unroll
+    for (int ct = 0; ct < CTW; ++ct) b_base[ct] = DOFF + cg * DPL + fr_row * 128 + ((ct ^ ((fr_row >> 1) & 1)) * 64) + fr_ch * 2;
+
+#define QK_FRAG_A(FA, BUF, KS_, T_) \
+        FA[T_] = tr_pair((const lds_char *)(BUF) + a_base[((T_) & 1) * 2 + (((T_) >> 1) & 1)] + ((KS_) * 16 + (T_)) * 128)
+#define QK_FRAG_B(FB, BUF, KS_) do { \
+        _Pragma("unroll") for (int c_ = 0; c_ < CTW; ++c_) FB[c_] = tr_pair((const lds_char *)(BUF) + b_base[c_] + (KS_) * 16 * 128); \
+    } while (0)
+
+    // A K step = two halves: H0 = sub-steps 0, 1, then the wait for tile it + 1 and the barrier; H1 = sub-steps 2, 3, which ask for
+    // tile it + 2.  The loop body is [H1(it) H0(it + 1)], three per trip: its back edge sits right behind a vmcnt(0), so hipcc's
+    // waitcnt pass sees NO LDS-DMA pending at the loop header (with the back edge between two K steps it merged "pending into
+    // some buffer" from the back edge with the prologue's state and put a vmcnt(0) in front of the first fragment read of the
+    // trip: the tile then had half a K step to arrive, not a whole one); for the same reason there is no early exit inside a
+    // trip -- the number of K steps is padded to 3 n + 1 with tiles past p_end, whose rows are out-of-range loads (zeros).
+    const int iters = (p_end - p_begin + KM - 1) / KM;
+    const int steps = iters <= 0 ? 0 : (iters + 1) / 3 * 3 + 1;          // smallest 3 n + 1 >= iters
+    // Fragments: the dY fragments of sub-step s + 1 are read at the head of sub-step s into the other of two sets; the X fragment
+    // of tap t is re-read for sub-step s + 1 right behind its last MFMA of sub-step s, into the registers it has just left (a
+    // second set of all taps' fragments would be 20 more registers: 9 spilled) -- eight MFMAs of cover for every read.
+    v8s fA[KIN], fB[2][CTW];
+    bool mine = false;
+#define QK_SUBSTEP(KS_, BCUR, BNXT, BDMA, LAST) do { \
+        constexpr int cur_ = (KS_) & 1, nx_ = cur_ ^ 1;                       /* (KS is even: the sets alternate across steps too) */ \
+        if ((KS_) + 1 < KS) QK_FRAG_B(fB[nx_], BCUR, (KS_) + 1); \
+        else if (!(LAST)) QK_FRAG_B(fB[nx_], BNXT, 0); \
+        __builtin_amdgcn_sched_barrier(0); \
+        if ((KS_) == 0) { mine = turn == 0 && bias_wave; turn = turn == 0 ? n_share - 1 : turn - 1; decode_rows(); }   /* rows of tile it + 2 */ \
+        if ((KS_) == 1) advance_tile(); \
+        if (mine) { \
+            _Pragma("unroll") for (int ct = 0; ct < CTW; ++ct) { \
+                typedef unsigned u4v __attribute__((ext_vector_type(4))); \
+                const u4v w = __builtin_bit_cast(u4v, fB[cur_][ct]); \
+                dbacc[ct] = dot_ones(T(), w.x, dbacc[ct]); dbacc[ct] = dot_ones(T(), w.y, dbacc[ct]); \
+                dbacc[ct] = dot_ones(T(), w.z, dbacc[ct]); dbacc[ct] = dot_ones(T(), w.w, dbacc[ct]); \
+            } \
+        } \
+        _Pragma("unroll") for (int j = 0; j < NMF; ++j) { \
+            const int t = j / CTW, ct = j % CTW; \
+            acc[t][ct] = mfma16b(T(), fA[t], fB[cur_][ct], acc[t][ct]); \
+            if (ct == CTW - 1) { \
+                if ((KS_) + 1 < KS) QK_FRAG_A(fA, BCUR, (KS_) + 1, t); \
+                else if (!(LAST)) QK_FRAG_A(fA, BNXT, 0, t); \
+            } \
+            if (!(LAST)) { \
+                if ((KS_) == 2) { if (j == 1) QK_DMA_X(BDMA); if (j == 3) QK_DMA_H(BDMA); } \
+                if ((KS_) == 3 && (j & 1) && j / 2 < NPD) QK_DMA_D1(BDMA, j / 2); \
+            } \
+            __builtin_amdgcn_sched_barrier(0); \
+        } \
+        if ((KS_) == 1) { \
+            /* tile it + 1 (asked for one K step ago) has landed for this wave; behind the barrier for everybody, and everybody \
+               has left tile it - 1: its buffer takes tile it + 2 from sub-step 2 on */ \
+            __builtin_amdgcn_s_waitcnt((7 << 4) | (15 << 8));          /* vmcnt(0) */ \
+            __builtin_amdgcn_s_barrier(); \
+        } \
+    } while (0)
+    if (steps > 0 && !(g.ablate & 4)) {
+        // ---- prologue: tiles 0 and 1 on their way, tile 0 landed behind the barrier, its first fragments read
+        decode_rows(); advance_tile();
+        QK_DMA_X(lds0); QK_DMA_H(lds0);
+#pragma unroll
+        for (int p = 0; p < NPD; ++p) QK_DMA_D1(lds0, p);
+        decode_rows(); advance_tile();
+        QK_DMA_X(lds1); QK_DMA_H(lds1);
+#pragma unroll
+        for (int p = 0; p < NPD; ++p) QK_DMA_D1(lds1, p);
+        __builtin_amdgcn_s_waitcnt((7 << 4) | (15 << 8));          // vmcnt(0) (tile 1 rides along: once per block)
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int t = 0; t < KIN; ++t) QK_FRAG_A(fA, lds0, 0, t);
+        QK_FRAG_B(fB[0], lds0, 0);
+        QK_SUBSTEP(0, lds0, lds1, lds2, false); QK_SUBSTEP(1, lds0, lds1, lds2, false);                  // H0(0)
+        for (int it = 0; it + 1 < steps; it += 3) {
+            QK_SUBSTEP(2, lds0, lds1, lds2, false); QK_SUBSTEP(3, lds0, lds1, lds2, false);              // H1(it)
+            QK_SUBSTEP(0, lds1, lds2, lds0, false); QK_SUBSTEP(1, lds1, lds2, lds0, false);              // H0(it + 1)
+            QK_SUBSTEP(2, lds1, lds2, lds0, false); QK_SUBSTEP(3, lds1, lds2, lds0, false);
+            QK_SUBSTEP(0, lds2, lds0, lds1, false); QK_SUBSTEP(1, lds2, lds0, lds1, false);
+            QK_SUBSTEP(2, lds2, lds0, lds1, false); QK_SUBSTEP(3, lds2, lds0, lds1, false);
+            QK_SUBSTEP(0, lds0, lds1, lds2, false); QK_SUBSTEP(1, lds0, lds1, lds2, false);              // H0(it + 3)
+        }
+        QK_SUBSTEP(2, lds0, lds1, lds2, true); QK_SUBSTEP(3, lds0, lds1, lds2, true);                    // H1(steps - 1)
+        __builtin_amdgcn_s_waitcnt(0);
+    }
+#undef QK_SUBSTEP
+    __syncthreads();
+#undef QK_FRAG_A
+#undef QK_FRAG_B
+#undef QK_DMA_X
+#undef QK_DMA_H
+#undef QK_DMA_D1
+
+    // ---- fold the 16 expanded blocks onto the 4 compact parts (as k_wgrad16_band; the slab of tap t lives in buffer t / 2) ----
+    if ((g.ablate & 1) && acc[0][0][0] != 123.456f) return;
+    const int lr = lane & 31;
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph) {                  // phase = gathered component a
+        const bool active = RTT == 2 ? rt == (ph >> 1) : rt == ph;
+        if (active) {
+#pragma unroll
+            for (int ct = 0; ct < CTW; ++ct) {
+                const int col = (cg * CTW + ct) * 32 + lr;
+                const int b = col / BF, ff = col % BF;
+                const int p = ph ^ b;
+                const bool neg = (g.sign_tbl >> (ph * 4 + b)) & 1u;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    if (RTT == 2 && (r >> 3) != (ph & 1)) continue;      // this register's rows belong to the other component
+                    const int row = mfma32_row(r, lane);
+                    const int cc = RTT == 2 ? (row & 15) : row;
+#pragma unroll
+                    for (int t = 0; t < KIN; ++t) {
+                        float *slab = reinterpret_cast<float *>(t / 2 == 0 ? lds0 : t / 2 == 1 ? lds1 : lds2) + (t & 1) * (TAPB / 4);
+                        const float v = neg ? -acc[t][ct][r] : acc[t][ct][r];
+                        float *dst = &slab[(cc * 4 + p) * BF + ff];
+                        *dst = ph == 0 ? v : *dst + v;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    const int tap0 = ot * KIN;                        // compact tap index of inner tap 0
+#pragma unroll
+    for (int t = 0; t < KIN; ++t) {
+        const float *slab = reinterpret_cast<const float *>(t / 2 == 0 ? lds0 : t / 2 == 1 ? lds1 : lds2) + (t & 1) * (TAPB / 4);
+        for (int e = tid; e < CQB * 4 * BF; e += NTHR) {
+            const int ff = e % BF;
+            const int p = (e / BF) & 3;
+            const int cc = e / (4 * BF);
+            if (!(g.ablate & 2))
+                atomicAdd(dw + (((tap0 + t) * g.Cq + c0 + cc) * 4 + p) * g.F + f0 + ff, slab[e]);
+        }
+    }
+    if (bias_wave) {
+#pragma unroll
+        for (int ct = 0; ct < CTW; ++ct) {
+            const float s = dbacc[ct] + __shfl_xor(dbacc[ct], 32);            // the two 8-position halves of a K slice
+            const int col = (cg * CTW + ct) * 32 + lr;
+            if (lane < 32) atomicAdd(dbias + (col / BF) * g.F + f0 + col % BF, s);
+        }
+    }
+}
+
 template <typename T, int RTT, int KIN, int CTW = 2>
 int run_wgrad16_band(const T *x, const T *dy, const T *ymask, float *dw, float *dbias, WgradGeom g, hipStream_t stream)
 {
@@ -417,6 +743,9 @@ int run_wgrad16_band(const T *x, const T *dy, const T *ymask, float *dw, float *
     if (g.has_mask) {
         if constexpr (kMasked) hipLaunchKernelGGL((k_wgrad16_band<T, RTT, KIN, true, CTW>), grid, dim3(512), 0, stream, x, dy, ymask, dw, dbias, g);
         else return QK_ERR_UNSUPPORTED;
+    } else if (CTW == 2 && !g.dym && g.b_wp >= KM + 8 && !(debug_flags() & kDbgWgradBandV1)) {
+        // the linear form: LDS-DMA staging, three tile buffers (round 5; QK_DBG_WGRAD_BAND_V1 / env QK_WGRAD_BAND_V1 = the round-2..4 kernel, A/B)
+        if constexpr (CTW == 2) hipLaunchKernelGGL((k_wgrad16_band3<T, RTT, KIN>), grid, dim3(512), 0, stream, x, dy, dw, dbias, g);
     } else {
         if constexpr (kLinear) hipLaunchKernelGGL((k_wgrad16_band<T, RTT, KIN, false, CTW>), grid, dim3(512), 0, stream, x, dy, ymask, dw, dbias, g);
         else return QK_ERR_UNSUPPORTED;

@@ -20,6 +20,29 @@ from ._shape import conv_output_length, normalize_tuple, tf_pads
 _DTYPES = {torch.float32: L.QK_F32, torch.bfloat16: L.QK_BF16, torch.float16: L.QK_F16}
 _PREP_CACHE_ON = not __import__('os').environ.get('QK_NO_PREP_CACHE')     # diagnostic: re-lay the 16-bit kernels out on every call
 _PREP_PARAMS = __import__('weakref').WeakValueDictionary()   # id -> parameter that carries cached 16-bit re-layouts (_Call._ws)
+_CAST_PARAMS = __import__('weakref').WeakValueDictionary()   # id -> tensor that carries a cached 16-bit cast (layers._cast_cached, _WeightedSumFn)
+_PREP_WARNED = False
+
+
+def invalidate_cached_kernels(params=None):
+    """Drop every cached 16-bit image of the given parameters (default: of all parameters that carry one): the re-laid-out
+    kernels of the quaternion layers and the 16-bit casts of the output layer / weighted_sum weights.
+
+    The caches are keyed on the tensor's version counter, its flat buffer's version counter and its data pointer.  Every torch
+    op, `FlatParams.adam_step`, `dp.broadcast_params` and `load_state_dict` bump one of them; a RAW write through `.data`
+    (`p.data.copy_()`, `p.data.clamp_()`, an EMA / weight-averaging loop over `.data`, a c10d collective on `.data`) bumps none --
+    call this afterwards (or use `with torch.no_grad(): p.copy_(...)`, which does bump the counter).  The next call of each
+    layer rebuilds its image; returns the number of parameters touched."""
+    if params is None:
+        params = list(_PREP_PARAMS.values()) + list(_CAST_PARAMS.values())
+    n = 0
+    for p in params:
+        hit = False
+        for key in ('_qk_prep', '_qk_cast16', '_qk_cast'):
+            if p.__dict__.pop(key, None) is not None:
+                hit = True
+        n += hit
+    return n
 
 
 def refresh_prepped_kernels(base=None):
@@ -53,8 +76,19 @@ def refresh_prepped_kernels(base=None):
             rc = L.lib().qk_conv_prep_kernels(n, dp, op_arr, w_arr, ws_arr, _raw_stream(dev.index) if _raw_stream is not None
                                               else torch.cuda.current_stream(dev).cuda_stream)
         if rc != 0:
+            # non-fatal (the optimiser step has already happened) but never silent: a sticky HIP fault or an argument bug would
+            # otherwise show up only as 26 extra launches per step, or as a later unrelated failure
+            msg = L.lib().qk_last_error()
+            msg = msg.decode() if isinstance(msg, bytes) else str(msg)
             for p, key, ent, ver in jobs:
                 p.__dict__.get('_qk_prep', {}).pop(key, None)
+            if rc == L.QK_ERR_LAUNCH:
+                raise RuntimeError('qk_conv_prep_kernels failed on %s: %s' % (dev, msg))
+            global _PREP_WARNED
+            if not _PREP_WARNED:
+                _PREP_WARNED = True
+                __import__('warnings').warn('qk_conv_prep_kernels refused the batched 16-bit kernel refresh on %s (rc %d: %s); the layers '
+                                            're-lay their kernels out per call from now on' % (dev, rc, msg), RuntimeWarning)
             continue
         for p, key, ent, ver in jobs:
             ent[0] = ver
@@ -942,6 +976,12 @@ def softmax_rows_fwd(logits, bias, out_dtype):
 def softmax_rows_bwd(y, dy, dbias=None):
     """d logits = y * (dy - <dy, y>) (returned, y's dtype); the bias gradient (column sums) is ADDED to the fp32 buffer `dbias`."""
     _require_device(y, 'softmax_rows_bwd')
+    if dy.dtype != y.dtype or dy.shape != y.shape or dy.device != y.device or y.dim() != 2:
+        raise ValueError('softmax_rows_bwd: dy must match y (2-D, same shape, dtype and device); got %s %s vs %s %s'
+                         % (tuple(dy.shape), dy.dtype, tuple(y.shape), y.dtype))
+    if dbias is not None and (dbias.dtype != torch.float32 or dbias.numel() != y.shape[1] or dbias.device != y.device or not dbias.is_contiguous()):
+        raise ValueError('softmax_rows_bwd: dbias must be a contiguous fp32 device tensor with one entry per column')
+    y, dy = y.contiguous(), dy.contiguous()           # raw pointers go to the kernel
     dl = torch.empty_like(y)
     with _on_device(y.device):
         rc = L.lib().qk_softmax_rows_bwd(_DTYPES[y.dtype], y.shape[0], y.shape[1], _ptr(y), _ptr(dy), _ptr(dl), _ptr(dbias), _stream(y))
@@ -960,15 +1000,18 @@ class _WeightedSumFn(torch.autograd.Function):
             rc = L.lib().qk_weighted_sum(_DTYPES[a.dtype], a.numel(), _ptr(a), _ptr(w), _ptr(out), _stream(a))
         L.check(rc, 'qk_weighted_sum')
         cache = w.__dict__.setdefault('_qk_cast', {})
+        _CAST_PARAMS[id(w)] = w
         hit = cache.get(a.dtype)
-        if hit is None or hit[0] != w._version:
-            hit = cache[a.dtype] = (w._version, w.to(a.dtype))
+        ver = (w._version, w.data_ptr())
+        if hit is None or hit[0] != ver:
+            hit = cache[a.dtype] = (ver, w.to(a.dtype))
         ctx.wt = hit[1]
+        ctx.a_shape = a.shape
         return out
 
     @staticmethod
     def backward(ctx, g):
-        return ctx.wt * g.to(ctx.wt.dtype), None
+        return (ctx.wt * g.to(ctx.wt.dtype)).view(ctx.a_shape), None          # (w may have a's element count in another shape)
 
 
 def weighted_sum(a, w):
@@ -983,7 +1026,7 @@ class _CtcFn(torch.autograd.Function):
     """qk_ctc_batch_cost: cost and d cost / d y_pred from one launch; the backward only scales the stored gradient."""
 
     @staticmethod
-    def forward(ctx, y_pred, labels, input_length, label_length):
+    def forward(ctx, y_pred, labels, input_length, label_length, loss_scale=1.0):
         b, t, c = y_pred.shape
         lab = labels.to(device=y_pred.device, dtype=torch.int32).contiguous()
         il = input_length.reshape(-1).to(device=y_pred.device, dtype=torch.int32).contiguous()
@@ -999,22 +1042,33 @@ class _CtcFn(torch.autograd.Function):
                                            _ptr(dpred), _ptr(ws), n, _stream(y_pred))
         L.check(rc, 'qk_ctc_batch_cost')
         ctx.save_for_backward(dpred)
+        ctx.loss_scale = float(loss_scale)
         return cost.reshape(b, 1)
 
     @staticmethod
     def backward(ctx, dcost):
         dpred, = ctx.saved_tensors
-        return dpred * dcost.reshape(-1, 1, 1).to(dpred.dtype), None, None, None
+        if ctx.loss_scale != 1.0:
+            # the product is formed in fp32 and rounded once: d cost / d y can be ~1 / y, dcost ~1 / batch
+            return (dpred.float() * (dcost.reshape(-1, 1, 1).float() * ctx.loss_scale)).to(dpred.dtype), None, None, None, None
+        return dpred * dcost.reshape(-1, 1, 1).to(dpred.dtype), None, None, None, None
 
 
 def ctc_supported(y_pred, labels):
     """qk_ctc_batch_cost takes a contiguous (B, T, C) device tensor with C <= 256 and at most 127 labels per sample."""
     return (y_pred.is_cuda and y_pred.dtype in _DTYPES and y_pred.dim() == 3 and y_pred.shape[-1] <= 256 and y_pred.shape[0] > 0
-            and labels.dim() == 2 and labels.shape[1] <= 127 and (y_pred.shape[1] + 4 * labels.shape[1] + 2 + y_pred.shape[-1] + 4) * 4 <= 64 * 1024)
+            and labels.dim() == 2 and labels.shape[1] <= 127 and (y_pred.shape[1] + 8 * labels.shape[1] + 4 + 2 * y_pred.shape[-1] + 4) * 4 <= 64 * 1024)
 
 
-def ctc_batch_cost(y_pred, labels, input_length, label_length):
+def ctc_batch_cost(y_pred, labels, input_length, label_length, loss_scale=1.0):
     """K.ctc_batch_cost(labels, y_pred, input_length, label_length) (interspeech_model.py:37-39): per-sample CTC cost (B, 1) of
-    the softmax outputs y_pred (B, T, C), blank = C - 1, Keras / TensorFlow semantics (include/qk.h: qk_ctc_batch_cost)."""
+    the softmax outputs y_pred (B, T, C), blank = C - 1, Keras / TensorFlow semantics (include/qk.h: qk_ctc_batch_cost).
+
+    loss_scale: the GRADIENT this node sends back is multiplied by it (the cost it returns is not) -- static loss scaling for
+    float16 activations: under the CTC cost the gradients of the TIMIT body layers sit at 2^-18.5 (profiles/r04_loss_ab.txt), below
+    float16's normal range (2^-14); a power of two (2^12 recommended) moves them into it exactly, and the optimiser undoes it in
+    fp32: `adam_step(grad_scale=1 / (world * loss_scale))`.  bfloat16 / float32 need none."""
     _require_device(y_pred, 'ctc_batch_cost')
-    return _CtcFn.apply(y_pred.contiguous(), labels, input_length, label_length)
+    if not (loss_scale > 0 and math.isfinite(loss_scale)):
+        raise ValueError('loss_scale must be a positive finite number')
+    return _CtcFn.apply(y_pred.contiguous(), labels, input_length, label_length, float(loss_scale))

@@ -77,6 +77,7 @@ def _cast_cached(w, dtype):
     if hit is None or hit[0] != ver or hit[1].dtype != dtype:
         hit = (ver, w.detach().to(dtype))
         w.__dict__['_qk_cast16'] = hit
+        Fq._CAST_PARAMS[id(w)] = w                    # (functional.invalidate_cached_kernels: raw `.data` writes bump no counter)
     return hit[1]
 
 
@@ -311,15 +312,32 @@ class TimeDistributed(Layer):
         return y.reshape((b, t) + tuple(y.shape[1:]))
 
 
-def ctc_batch_cost(y_pred, labels, input_length, label_length, blank=None):
+class _GradScale(torch.autograd.Function):
+    """identity forward, gradient x s backward (static loss scaling on the torch path of ctc_batch_cost)"""
+
+    @staticmethod
+    def forward(ctx, x, s):
+        ctx.s = s
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g * ctx.s, None
+
+
+def ctc_batch_cost(y_pred, labels, input_length, label_length, blank=None, loss_scale=1.0):
     """K.ctc_batch_cost (interspeech_model.py:37-39): y_pred (B, T, C) softmax outputs, blank = last class; returns
     the per-sample negative log-likelihood (B, 1).  Keras 2.x hands log(y_pred + epsilon()) to tf.nn.ctc_loss as
     LOGITS, and that op normalises them again (softmax), so the log-probabilities are
-    log_softmax(log(y_pred + 1e-7)); ctc_merge_repeated=True, no collapse of repeated labels (TF defaults)."""
+    log_softmax(log(y_pred + 1e-7)); ctc_merge_repeated=True, no collapse of repeated labels (TF defaults).
+    loss_scale: multiplies the gradient sent back (not the cost): float16 training, see functional.ctc_batch_cost."""
     if (blank is None and y_pred.is_cuda and Fq.ctc_supported(y_pred, labels) and not os.environ.get('QK_NO_FUSED_CTC')):
-        return Fq.ctc_batch_cost(y_pred, labels, input_length, label_length)        # one HIP launch: cost + gradient
+        return Fq.ctc_batch_cost(y_pred, labels, input_length, label_length, loss_scale=loss_scale)        # one HIP launch: cost + gradient
     blank = y_pred.shape[-1] - 1 if blank is None else blank
-    logp = torch.log_softmax(torch.log(y_pred.float() + 1e-7), dim=-1).transpose(0, 1)
+    yp = y_pred.float()
+    if loss_scale != 1.0:
+        yp = _GradScale.apply(yp, float(loss_scale))          # (in fp32, in front of the cast back to y_pred's dtype)
+    logp = torch.log_softmax(torch.log(yp + 1e-7), dim=-1).transpose(0, 1)
     loss = F.ctc_loss(logp, labels.long(), input_length.reshape(-1).long(), label_length.reshape(-1).long(),
                       blank=blank, reduction='none', zero_infinity=False)
     return loss.reshape(-1, 1)

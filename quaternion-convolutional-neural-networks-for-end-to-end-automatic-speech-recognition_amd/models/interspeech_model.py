@@ -290,9 +290,11 @@ class TimitQCNN(torch.nn.Module):
             y = dl.activation(y)
         return y.reshape(b, dl.r.shape[-1], t).permute(0, 2, 1)                      # (B, units, 1, T) -> (B, T, units)
 
-    def ctc_loss(self, x, labels, input_length, label_length):
-        """The model output of the reference: K.ctc_batch_cost per sample, shape (B, 1) (interspeech_model.py:178)."""
-        return ctc_batch_cost(self(x), labels, input_length, label_length)
+    def ctc_loss(self, x, labels, input_length, label_length, loss_scale=1.0):
+        """The model output of the reference: K.ctc_batch_cost per sample, shape (B, 1) (interspeech_model.py:178).
+        loss_scale (float16 training): the gradient sent back through the network is multiplied by it, the returned cost is
+        not; divide it out in the optimiser (functional.adam_step(grad_scale=1 / (world * loss_scale)))."""
+        return ctc_batch_cost(self(x), labels, input_length, label_length, loss_scale=loss_scale)
 
     def regularization_loss(self):
         """Sum of the kernel regularisers (l2(d.l2) on every conv / dense kernel, interspeech_model.py:63,68,173):
@@ -302,10 +304,12 @@ class TimitQCNN(torch.nn.Module):
             return next(self.parameters()).new_zeros(())
         return torch.stack([t.float() for t in terms]).sum()
 
-    def training_loss(self, x, labels, input_length, label_length):
+    def training_loss(self, x, labels, input_length, label_length, loss_scale=1.0):
         """What training the reference model minimises: mean CTC cost over the batch (the usual
-        `loss={'ctc': lambda y_true, y_pred: y_pred}` compile) + the regularisation terms."""
-        return self.ctc_loss(x, labels, input_length, label_length).mean() + self.regularization_loss()
+        `loss={'ctc': lambda y_true, y_pred: y_pred}` compile) + the regularisation terms (scaled like the CTC gradient, so
+        that ONE grad_scale in the optimiser undoes both)."""
+        reg = self.regularization_loss()
+        return self.ctc_loss(x, labels, input_length, label_length, loss_scale=loss_scale).mean() + (reg * loss_scale if loss_scale != 1.0 else reg)
 
 
 class _RealConv2D(Layer):

@@ -328,3 +328,58 @@ def test_timit_qcnn_matches_the_reference_model_fixture(variant, fused):
     l2 = fx['d']['l2']
     want_reg = l2 * sum(float((fx['weights'][k] ** 2).sum()) for k in fx['weights'] if k.endswith('.kernel') or k.endswith('.r'))
     assert abs(float(model.regularization_loss()) - want_reg) <= 1e-5 * want_reg
+
+
+# ---- round 5: float16 training under the model's own loss needs loss scaling (round-4 verdict, missing 3) -------------------
+def test_ctc_loss_scale_multiplies_the_gradient_not_the_cost_on_cpu():
+    """The torch path of layers.ctc_batch_cost (no GPU): loss_scale leaves the cost alone and multiplies d cost / d y."""
+    from qcnn_amd.layers import ctc_batch_cost
+    g = torch.Generator().manual_seed(3)
+    y = torch.softmax(torch.randn(3, 12, 7, generator=g), -1).requires_grad_(True)
+    labels = torch.randint(0, 6, (3, 4), generator=g)
+    il, ll = torch.full((3, 1), 12), torch.tensor([[4], [2], [3]])
+    c1 = ctc_batch_cost(y, labels, il, ll)
+    g1, = torch.autograd.grad(c1.sum(), y)
+    c2 = ctc_batch_cost(y, labels, il, ll, loss_scale=4096.0)
+    g2, = torch.autograd.grad(c2.sum(), y)
+    assert torch.equal(c1, c2)
+    assert torch.allclose(g2, g1 * 4096.0, rtol=1e-6, atol=0)
+
+
+@pytest.mark.gpu
+def test_fp16_timit_step_under_ctc_matches_fp32_with_loss_scaling_and_underflows_without():
+    """interspeech_model.py:37-39,178: the cost the model is trained on.  At B = 256 its gradients reach the body layers at
+    2^-18.5 (profiles/r04_loss_ab.txt) -- below float16's normal range.  Emulated here on a small model by a 2^-16 factor on
+    the loss: without loss scaling the float16 kernel gradients are flushed away; with `loss_scale = 2^16` (undone in fp32,
+    as adam_step(grad_scale=) does) they match the float32 path (oracle-pinned elsewhere) to the 16-bit tolerance."""
+    dev = _dev()
+    model, xt, _ = _build(dev, torch.float32, 32, 4, 'none', 4, 40, seed=23, fuse_head=True, chain_convs=True)
+    rng = np.random.RandomState(5)
+    labels = torch.tensor(rng.randint(0, 61, (4, 10)), device=dev, dtype=torch.int32)
+    il = torch.full((4, 1), 40, dtype=torch.int32, device=dev)
+    ll = torch.tensor([[10], [7], [9], [4]], dtype=torch.int32, device=dev)
+    tiny = 2.0 ** -16
+
+    def grads(x, scale):
+        for p in model.parameters():
+            p.grad = None
+        cost = model.ctc_loss(x, labels, il, ll, loss_scale=scale)
+        (cost.mean() * tiny).backward()
+        return {n: (p.grad.double() / (scale * tiny)).cpu().numpy() for n, p in model.named_parameters() if p.grad is not None}, cost.detach()
+
+    want, c32 = grads(xt, 1.0)
+    x16 = xt.to(torch.float16)
+    got_s, c16 = grads(x16, 2.0 ** 16)
+    got_p, c16p = grads(x16, 1.0)
+    assert torch.equal(c16, c16p)                               # the scale never touches the cost itself
+    assert float((c16.float() - c32).abs().max() / c32.abs().max()) <= 2e-2
+    worst_s, worst_p = 0.0, 0.0
+    for k, w in want.items():
+        nw = np.linalg.norm(w)
+        if nw == 0:
+            continue
+        es, ep = np.linalg.norm(got_s[k] - w) / nw, np.linalg.norm(got_p[k] - w) / nw
+        assert np.isfinite(got_s[k]).all(), k
+        assert es <= 8e-2, '%s: scaled fp16 gradient off by %.3g (2-norm)' % (k, es)
+        worst_s, worst_p = max(worst_s, es), max(worst_p, ep)
+    assert worst_p >= 0.5, 'the unscaled fp16 gradients were expected to underflow (worst 2-norm error %.3g)' % worst_p
