@@ -73,6 +73,9 @@ WORKLOADS = {
     #   ... as the reference builds it (aact='none'): relu, Dropout(0.3) behind every body conv / dense, l2 regulariser
     'cfg3_qcnn_relu_dropout_b256_bf16': dict(kind='model', batch=256, frames=200, sf=32, layers=10, dtype='bf16',
                                              dropout=0.3, l2=1e-5),
+    #   ... the same graph at start_filter = 16 (a free hyperparameter of the reference model, :46-50): 16 -> 16 and 16 -> 32 body layers,
+    #   which run the zero-padded PAD forms of the 16-bit band kernels since round 5 (fp32-MFMA kernels before)
+    'cfg3_qcnn_sf16_b256_bf16': dict(kind='model', batch=256, frames=200, sf=16, layers=10, dtype='bf16', dropout=0.3, l2=1e-5),
     #   ... without dropout and l2 (the round-1/2 headline; kept for comparison)
     'cfg3_qcnn_timit_b256_bf16': dict(kind='model', batch=256, frames=200, sf=32, layers=10, dtype='bf16'),
     'cfg3_qcnn_timit_b64_fp32': dict(kind='model', batch=64, frames=200, sf=32, layers=10, dtype='fp32'),
@@ -142,12 +145,19 @@ class ModelTrainStep(object):
             self.labels = torch.randint(0, 61, (B, 50), generator=cg).to(dev, torch.int32)
             self.input_length = torch.full((B, 1), T, dtype=torch.int32, device=dev)
         self.t = 0
+        self.graph, self.step_dev = None, None
         self.flops_per_kernel = qcnn_flops(cfg['sf'], cfg['layers'], B, T)      # forward; step = 3x
         self.gemm = dict(layers='conv 1->%d, %dx conv, 3x TD-dense' % (cfg['sf'], cfg['layers']),
                          parameters=int(sum(p.numel() for p in params)), allreduce_buckets=len(self.reducer.buckets))
         self.y = self.x
 
     def step(self):
+        if self.graph is not None:
+            self.graph.replay()                         # the whole step below as ONE submission (capture())
+            return
+        self._step_body()
+
+    def _step_body(self):
         self.t += 1
         if self.loss == 'ctc':
             loss = self.model.ctc_loss(self.x, self.labels, self.input_length, self.label_length).mean()
@@ -156,11 +166,34 @@ class ModelTrainStep(object):
             loss = self.F.weighted_sum(pred, self.target)            # sum(pred * target): one launch each way
         loss.backward()                                 # gradients accumulate into the zeroed flat buffer; the
         self.reducer.finish()                           # buckets go out while the backward is still running
-        self.F.adam_step(self.flat.param, self.flat.grad, self.m, self.v, self.t, lr=5e-4,
-                         grad_scale=1.0 / self.world, zero_grad=True, decay=self.decay)
+        # the step number is a DEVICE counter once capture() has run (qk_adam_step_dev): no launch argument of the step
+        # depends on it -- the dropout seeds read the same counter (model.drop_step_dev)
+        self.F.adam_step(self.flat.param, self.flat.grad, self.m, self.v, self.step_dev if self.step_dev is not None else self.t,
+                         lr=5e-4, grad_scale=1.0 / self.world, zero_grad=True, decay=self.decay)
 
     def capture(self):
-        raise RuntimeError('model workloads run eagerly (launch overhead is negligible at this size)')
+        """The whole training step -- forward, loss, backward (autograd's thread launches onto the capturing stream), fused Adam,
+        the batched kernel re-layout -- as ONE hipGraph: 66 launches become one submission, the ~0.4 ms of launch gaps of the
+        eager step (profiles/r04_qcnn_step_timeline.txt: span - kernel sum) go.  What made it capturable: the Adam step number and
+        the dropout seeds' per-step part live in a device counter (qk_adam_step_dev, qk_postop_t.drop_seed_dev), so every launch
+        argument is the same from step to step.  One rank only: the bucketed all-reduce of N > 1 stays eager."""
+        if self.world != 1 or torch.distributed.is_initialized():
+            raise RuntimeError('graph capture of the model step is the one-rank path; N > 1 runs eagerly')
+        dev = self.x.device
+        self.step_dev = torch.full((1,), self.t, dtype=torch.int32, device=dev)
+        self.model.drop_step_dev = self.step_dev
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(2):                          # the device-counter forms of the launches, once eagerly (allocator, code objects)
+                self._step_body()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._step_body()
+        torch.cuda.synchronize(dev)
+        self.graph = g
 
 
 class StackTrainStep(object):
@@ -568,11 +601,12 @@ def in_step_kernel_times(job, dev, peak, steps=3):
     C call).  Grouped by (operation, GEMM view); `ms` is the mean per call (kernel re-layout and memsets of the call
     included), sorted by share of the step."""
     from qcnn_amd import _lib
-    job.step()
+    step = getattr(job, '_step_body', job.step)       # (eagerly: the library's events cannot be recorded inside a graph replay)
+    step()
     torch.cuda.synchronize(dev)
     with _lib.profile() as p:
         for _ in range(steps):
-            job.step()
+            step()
         torch.cuda.synchronize(dev)
         recs = p.records()
     groups = {}
@@ -794,7 +828,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    use_graph = args.graph and (world == 1 or args.graph_multi) and not is_model
+    use_graph = args.graph and (world == 1 or args.graph_multi) and not is_stack and not (is_model and (world > 1 or dist.is_initialized()))
     if use_graph:
         try:
             job.step()

@@ -254,6 +254,10 @@ typedef struct {
     const float *alpha;      /* device pointer, float32; NULL: relu (+ dropout), see above                  */
     float drop_rate;         /* in [0, 1)                                                                   */
     uint32_t drop_seed;
+    const uint32_t *drop_seed_dev; /* optional (NULL: off): a DEVICE counter; the kernels hash with drop_seed + 0x9E3779B1 * (*drop_seed_dev).
+                                    * With the training step's number there (qk_adam_step_dev keeps it) every launch argument is the same
+                                    * from step to step -- a captured graph replays and still draws new masks; forward and backward of
+                                    * one step agree because the counter moves only between steps */
 } qk_postop_t;
 
 /* y = post(W (x) x + b): the convolution must be LINEAR (desc->activation); `pre` receives W (x) x + b (same
@@ -402,7 +406,8 @@ int qk_weighted_sum(int32_t dtype, int64_t n, const void *a, const float *w, flo
  * descs[i] and kernel w[i] would write at the start of its workspace -- ONE launch for up to 32 jobs.  Meant to run once
  * behind each optimiser step; the calls of the next training step then pass desc.ws_has_kernel = 1 with those workspaces
  * and launch nothing but their GEMM kernel.  16-bit descriptors only (QK_ERR_INVALID_ARG otherwise); a job whose cq or fq
- * is not a multiple of 32 is SKIPPED, not refused: its calls run the fp32-MFMA kernels, which read the compact kernel in
+ * is not a multiple of 16 is SKIPPED, not refused (multiples of 16 are zero-padded to the kernels' 32-channel granule: the
+ * workspace holds taps x pad32(cq) x 4 x pad32(fq) 16-bit values + 256 bytes): its calls run the fp32-MFMA kernels, which read the compact kernel in
  * place and never look at the workspace, so a model that mixes on-path and off-path layers hands over all of them. */
 int qk_conv_prep_kernels(int32_t n, const qk_conv_desc_t *const *descs, const int32_t *ops, const float *const *w,
                          void *const *workspaces, void *stream);
@@ -416,6 +421,17 @@ int qk_conv_prep_kernels(int32_t n, const qk_conv_desc_t *const *descs, const in
 int qk_adam_step_l2(float *param, float *grad, float *m, float *v, const float *decay, size_t n, float lr,
                     float beta1, float beta2, float eps, int32_t step, float grad_scale, int32_t zero_grad,
                     void *stream);
+
+/* qk_adam_step_l2 with the step number ON THE DEVICE: *step_dev = number of steps applied so far (start it at 0).  The kernel
+ * applies step *step_dev + 1 (Keras' bias-corrected rate is formed in the kernel, in double as on the host) and a one-thread
+ * launch behind it increments the counter.  No launch argument depends on the step, so a training step captured as ONE graph
+ * (forward, loss, backward, this call, qk_conv_prep_kernels) replays correctly; hand the same counter to the post-ops
+ * (qk_postop_t.drop_seed_dev) and the dropout masks change from replay to replay as well.  Replaces the Keras optimizer's
+ * host-side `iterations` variable (the reference trains through Model.fit: /root/reference/models/interspeech_model.py:106,184).
+ * decay may be NULL. */
+int qk_adam_step_dev(float *param, float *grad, float *m, float *v, const float *decay, size_t n, float lr,
+                     float beta1, float beta2, float eps, int32_t *step_dev, float grad_scale, int32_t zero_grad,
+                     void *stream);
 
 #ifdef __cplusplus
 }

@@ -55,7 +55,7 @@ _PD = ctypes.POINTER(PoolDesc)
 class PostOp(ctypes.Structure):
     """qk_postop_t (include/qk.h): PReLU (+ Dropout) behind a layer."""
     _fields_ = [('alpha_axis', ctypes.c_int32), ('alpha_len', ctypes.c_int32), ('alpha', ctypes.c_void_p),
-                ('drop_rate', ctypes.c_float), ('drop_seed', ctypes.c_uint32)]
+                ('drop_rate', ctypes.c_float), ('drop_seed', ctypes.c_uint32), ('drop_seed_dev', ctypes.c_void_p)]
 
 
 _PO = ctypes.POINTER(PostOp)
@@ -108,6 +108,8 @@ SYMBOLS = {
                                             ctypes.POINTER(ctypes.c_void_p), _VP]),
     'qk_adam_step_l2': (ctypes.c_int, [_FP, _FP, _FP, _FP, _FP, _SZ, ctypes.c_float, ctypes.c_float,
                                        ctypes.c_float, ctypes.c_float, I32, ctypes.c_float, I32, _VP]),
+    'qk_adam_step_dev': (ctypes.c_int, [_FP, _FP, _FP, _FP, _FP, _SZ, ctypes.c_float, ctypes.c_float,
+                                        ctypes.c_float, ctypes.c_float, _VP, ctypes.c_float, I32, _VP]),
     'qk_softmax_rows_fwd': (ctypes.c_int, [I32, ctypes.c_int64, I32, _VP, _VP, _VP, _VP]),
     'qk_softmax_rows_bwd': (ctypes.c_int, [I32, ctypes.c_int64, I32, _VP, _VP, _VP, _VP, _VP]),
     'qk_weighted_sum': (ctypes.c_int, [I32, ctypes.c_int64, _VP, _VP, _VP, _VP]),

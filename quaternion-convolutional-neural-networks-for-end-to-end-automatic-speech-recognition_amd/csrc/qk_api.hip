@@ -244,6 +244,7 @@ int to_postop(const qk_postop_t *q, int rank, const int32_t *sp, PostOp *p)
     p->drop_thr = thr > 255u ? 255u : thr;
     p->drop_scale = p->drop_thr ? 256.f / (256.f - (float)p->drop_thr) : 1.f;   // the scale of the rate actually applied
     p->drop_seed = q->drop_seed;
+    p->seed_dev = q->drop_seed_dev;
     return 0;
 }
 
@@ -322,7 +323,12 @@ size_t ws_bytes_impl(const qk_conv_desc_t *d, int op)
     // fused backward additionally: the relu-masked copy of dy that bwd-weight writes for bwd-data
     size_t n = 0;
     const bool bwd_data = op == QK_OP_BWD_DATA || op == QK_OP_BWD;
-    if (d->dtype != QK_F32 && (op == QK_OP_FWD || bwd_data)) n += w_floats(d) * 2 + 256;
+    if (d->dtype != QK_F32 && (op == QK_OP_FWD || bwd_data)) {
+        // channel counts that are multiples of 16: zero-padded to the kernels' 32-channel granule (other counts never reach the
+        // 16-bit kernels; their figure is what it always was)
+        const bool on16 = d->cq % 16 == 0 && d->fq % 16 == 0;
+        n += (on16 ? (size_t)taps_of(d) * pad32(d->cq) * 4 * pad32(d->fq) : w_floats(d)) * 2 + 256;
+    }
     if (op == QK_OP_BWD && d->activation == QK_ACT_RELU) n = (n + 255) / 256 * 256 + dy_bytes(d);
     return n;
 }
@@ -1043,7 +1049,7 @@ int qk_conv_prep_kernels(int32_t n, const qk_conv_desc_t *const *descs, const in
                 if (d->dtype != dt) continue;
                 if (ops[i] != QK_OP_FWD && ops[i] != QK_OP_BWD_DATA && ops[i] != QK_OP_BWD) { set_error("qk_conv_prep_kernels: job %d: bad op %d", i, ops[i]); return QK_ERR_INVALID_ARG; }
                 if (!aligned(workspaces[i], 16)) { set_error("qk_conv_prep_kernels: job %d: workspace not 16-byte aligned", i); return QK_ERR_INVALID_ARG; }
-                if (d->cq % 32 || d->fq % 32) continue;       // outside the matrix-core path: its calls run the fp32-MFMA kernels, which never read the workspace
+                if (d->cq % 16 || d->fq % 16) continue;       // outside the matrix-core path: its calls run the fp32-MFMA kernels, which never read the workspace
                 const bool bwd = ops[i] != QK_OP_FWD;
                 PrepJob &j = jobs.j[m++];
                 j.w = w[i]; j.wq = workspaces[i]; j.taps = taps_of(d); j.cq = d->cq; j.fq = d->fq;
@@ -1083,6 +1089,13 @@ int qk_adam_step_l2(float *param, float *grad, float *m, float *v, const float *
     if (!param || !grad || !m || !v) { set_error("adam: NULL buffer"); return QK_ERR_INVALID_ARG; }
     if (step < 1) { set_error("adam: step must be >= 1"); return QK_ERR_INVALID_ARG; }
     return check_launch(launch_adam(param, grad, m, v, decay, n, lr, beta1, beta2, eps, step, grad_scale, zero_grad != 0, (hipStream_t)stream), "qk_adam_step_l2");
+}
+
+int qk_adam_step_dev(float *param, float *grad, float *m, float *v, const float *decay, size_t n, float lr, float beta1,
+                     float beta2, float eps, int32_t *step_dev, float grad_scale, int32_t zero_grad, void *stream)
+{
+    if (!param || !grad || !m || !v || !step_dev) { set_error("adam: NULL buffer"); return QK_ERR_INVALID_ARG; }
+    return check_launch(launch_adam(param, grad, m, v, decay, n, lr, beta1, beta2, eps, 1, grad_scale, zero_grad != 0, (hipStream_t)stream, step_dev), "qk_adam_step_dev");
 }
 
 }  // extern "C"

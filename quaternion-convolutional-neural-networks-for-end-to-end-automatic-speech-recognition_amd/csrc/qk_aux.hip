@@ -11,8 +11,20 @@ namespace {
 template <bool ZERO, bool DECAY>
 __global__ void __launch_bounds__(256)
 k_adam(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m,
-       float *__restrict__ v, const float *__restrict__ decay, size_t n, float lr_t, float b1, float b2, float eps, float gscale)
+       float *__restrict__ v, const float *__restrict__ decay, size_t n, float lr_t, float b1, float b2, float eps, float gscale,
+       const int *__restrict__ step_dev, float lr)
 {
+    if (step_dev) {
+        // the step number lives on the device (qk_adam_step_dev): *step_dev steps have been applied, this is step *step_dev + 1;
+        // Keras' bias-corrected rate is formed here, in double as the host form does, so that no launch argument depends on the step
+        __shared__ float lr_s;
+        if (threadIdx.x == 0) {
+            const double t = (double)(*step_dev + 1);
+            lr_s = (float)((double)lr * sqrt(1.0 - pow((double)b2, t)) / (1.0 - pow((double)b1, t)));
+        }
+        __syncthreads();
+        lr_t = lr_s;
+    }
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * 256;
     for (; i < n; i += stride) {
@@ -26,6 +38,7 @@ k_adam(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m,
         if constexpr (ZERO) g[i] = 0.f;
     }
 }
+__global__ void k_bump(int *c) { *c += 1; }          // (behind k_adam on the same stream: every block has read the old value)
 
 // Tap folding: xcol[m, a*cq2 + t*Cq + c] = x[pos(m,t), a*Cq + c]  (zero in the padding and beyond
 // taps*Cq).  One thread per (row, component): the row is decoded once and the folded channels are
@@ -201,7 +214,7 @@ k_postop(const T *__restrict__ pre, const T *__restrict__ dy, T *__restrict__ ou
                 float v[4] = {q.x, q.y, q.z, q.w}, g[4] = {0.f, 0.f, 0.f, 0.f};
                 if constexpr (BWD) { const float4 t = *reinterpret_cast<const float4 *>(dy + e0); g[0] = t.x; g[1] = t.y; g[2] = t.z; g[3] = t.w; }
                 unsigned rb[2] = {0u, 0u};
-                if (p.drop_thr) drop_bits8((unsigned)(e0 >> 3), p.drop_seed, rb[0], rb[1]);
+                if (p.drop_thr) drop_bits8((unsigned)(e0 >> 3), eff_seed(p), rb[0], rb[1]);
                 const unsigned bits = rb[(e0 >> 2) & 1];                   // this thread's 4 elements: half a unit
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
@@ -428,17 +441,18 @@ int launch_fold_taps(int dtype, const void *x, void *xcol, const GemmGeom &g, in
 }
 
 int launch_adam(float *p, float *g, float *m, float *v, const float *decay, size_t n, float lr, float b1,
-                float b2, float eps, int step, float gscale, bool zero_grad, hipStream_t stream)
+                float b2, float eps, int step, float gscale, bool zero_grad, hipStream_t stream, int *step_dev)
 {
     if (n == 0) return 0;
     const double t = (double)step;
-    const float lr_t = (float)((double)lr * sqrt(1.0 - pow((double)b2, t)) / (1.0 - pow((double)b1, t)));
+    const float lr_t = step_dev ? 0.f : (float)((double)lr * sqrt(1.0 - pow((double)b2, t)) / (1.0 - pow((double)b1, t)));
     size_t blocks = (n + 255) / 256;
     if (blocks > 2048) blocks = 2048;
-#define QK_ADAM(Z, D) hipLaunchKernelGGL((k_adam<Z, D>), dim3((unsigned)blocks), dim3(256), 0, stream, p, g, m, v, decay, n, lr_t, b1, b2, eps, gscale)
+#define QK_ADAM(Z, D) hipLaunchKernelGGL((k_adam<Z, D>), dim3((unsigned)blocks), dim3(256), 0, stream, p, g, m, v, decay, n, lr_t, b1, b2, eps, gscale, (const int *)step_dev, lr)
     if (zero_grad) { if (decay) QK_ADAM(true, true); else QK_ADAM(true, false); }
     else { if (decay) QK_ADAM(false, true); else QK_ADAM(false, false); }
 #undef QK_ADAM
+    if (step_dev) hipLaunchKernelGGL(k_bump, dim3(1), dim3(1), 0, stream, step_dev);
     return hipGetLastError() == hipSuccess ? 0 : QK_ERR_LAUNCH;
 }
 

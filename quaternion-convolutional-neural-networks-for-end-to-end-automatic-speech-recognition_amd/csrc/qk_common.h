@@ -43,6 +43,7 @@ struct PostOp {
     float drop_scale;       // 1 / (1 - rate); 1 without dropout
     unsigned drop_thr;      // keep iff the element's 8 random bits >= drop_thr (= round(rate * 256)); 0 = no dropout
     unsigned drop_seed;
+    const unsigned *seed_dev; // optional device counter mixed into drop_seed by the kernels (qk_postop_t.drop_seed_dev: graph replay)
 };
 
 struct GemmGeom {
@@ -52,6 +53,7 @@ struct GemmGeom {
     int isp[3];         // spatial extents of the gathered tensor
     int Q;              // gathered channels per component
     int J;              // produced channels per component
+    int Qp, Jp;         // 16-bit MFMA path: Q / J rounded up to the kernels' 32-channel granule (the re-laid-out kernel is zero-padded to them)
     int ks[3];
     int taps;
     int pa[3], pb[3], pc[3], pd[3];
@@ -123,7 +125,8 @@ inline bool band_geom(const GemmGeom &g, int esize, GemmGeom *o)
     const long long lines = (long long)g.batch * o->osp[0] * o->osp[1];
     if (lines * o->b_wp >= (1ll << 31) - 512) return false;
     o->b_nlines = (int)lines;
-    const long long in_bytes = (long long)g.batch * g.in_sn * esize, w_bytes = (long long)g.taps * g.Q * 4 * g.J * 2 + 256;
+    const long long Qw = g.Qp ? g.Qp : g.Q, Jw = g.Jp ? g.Jp : g.J;             // (padded extents of the re-laid-out kernel, 16-bit path)
+    const long long in_bytes = (long long)g.batch * g.in_sn * esize, w_bytes = (long long)g.taps * Qw * 4 * Jw * 2 + 256;
     if (in_bytes >= 0xF0000000ll || w_bytes >= 0xF0000000ll) return false;   // 32-bit buffer offsets
     o->b_in_bytes = (unsigned)in_bytes;
     o->b_w_bytes = (unsigned)w_bytes;
@@ -132,6 +135,8 @@ inline bool band_geom(const GemmGeom &g, int esize, GemmGeom *o)
     if (o->post.alpha_sel >= 0) o->post.alpha_sel += sh;     // the alpha axis moves with the rotation
     return true;
 }
+
+inline int pad32(int v) { return (v + 31) / 32 * 32; }
 
 // n / d for 0 <= n < 2^31 with (mul, shr) from fastdiv_of(d): umulhi(n, mul) >> shr  (d == 1: mul == 0 marks identity)
 inline void fastdiv_of(unsigned d, unsigned *mul, unsigned *shr)
@@ -259,7 +264,7 @@ int launch_softmax_rows(int dtype, bool backward, const void *a, const void *b, 
                         hipStream_t stream);
 int launch_weighted_sum(int dtype, const void *a, const float *w, float *out, long long n, hipStream_t stream);
 int launch_adam(float *p, float *g, float *m, float *v, const float *decay, size_t n, float lr, float b1,
-                float b2, float eps, int step, float gscale, bool zero_grad, hipStream_t stream);
+                float b2, float eps, int step, float gscale, bool zero_grad, hipStream_t stream, int *step_dev = nullptr);
 
 void set_error(const char *fmt, ...);
 void note_path(int qk_path);          // thread-local record behind qk_last_path()

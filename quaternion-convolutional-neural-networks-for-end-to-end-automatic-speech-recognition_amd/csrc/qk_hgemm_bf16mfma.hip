@@ -80,8 +80,10 @@ template <typename T>
 __global__ void __launch_bounds__(256)
 k_prep_w16(const float *__restrict__ w, T *__restrict__ wq, int taps, int Cq, int F, int transposed, int neg_ijk)
 {
-    const int Q = transposed ? F : Cq;
-    const int J = transposed ? Cq : F;
+    // (Q, J multiples of 16: the layout is written for the 32-channel granule of the kernels, zero beyond the real extents --
+    //  round 5, channel counts that are multiples of 16 only)
+    const int Qr = transposed ? F : Cq, Jr = transposed ? Cq : F;
+    const int Q = (Qr + 31) / 32 * 32, J = (Jr + 31) / 32 * 32;
     const long long total = (long long)taps * Q * 4 * J;
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
         long long r = idx;
@@ -94,7 +96,7 @@ k_prep_w16(const float *__restrict__ w, T *__restrict__ wq, int taps, int Cq, in
         const int k = kc * 32 + slot * 8 + e;
         const int c = transposed ? j : k;
         const int f = transposed ? k : j;
-        const float v = w[((long long)(t * Cq + c) * 4 + p) * F + f];
+        const float v = (k < Qr && j < Jr) ? w[((long long)(t * Cq + c) * 4 + p) * F + f] : 0.f;
         wq[idx] = from_f32<T>(neg_ijk && p ? -v : v);
     }
     if (blockIdx.x == 0 && threadIdx.x < 128) wq[total + threadIdx.x] = from_f32<T>(0.f);   // zero line for padding rows
@@ -111,8 +113,8 @@ k_prep_w16_batch(const PrepJobs jobs)
     const float *__restrict__ w = jb.w;
     T *__restrict__ wq = static_cast<T *>(jb.wq);
     const int Cq = jb.cq, F = jb.fq, transposed = jb.transposed, neg_ijk = jb.neg_ijk;
-    const int Q = transposed ? F : Cq;
-    const int J = transposed ? Cq : F;
+    const int Qr = transposed ? F : Cq, Jr = transposed ? Cq : F;
+    const int Q = (Qr + 31) / 32 * 32, J = (Jr + 31) / 32 * 32;                  // (zero-padded to the 32-channel granule, see k_prep_w16)
     const long long total = (long long)jb.taps * Q * 4 * J;
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
         long long r = idx;
@@ -125,7 +127,7 @@ k_prep_w16_batch(const PrepJobs jobs)
         const int k = kc * 32 + slot * 8 + e;
         const int c = transposed ? j : k;
         const int f = transposed ? k : j;
-        const float v = w[((long long)(t * Cq + c) * 4 + p) * F + f];
+        const float v = (k < Qr && j < Jr) ? w[((long long)(t * Cq + c) * 4 + p) * F + f] : 0.f;
         wq[idx] = from_f32<T>(neg_ijk && p ? -v : v);
     }
     if (blockIdx.x == 0 && threadIdx.x < 128) wq[total + threadIdx.x] = from_f32<T>(0.f);
@@ -573,7 +575,12 @@ constexpr int band_op(int R, int K, int ti, int k)
 //   TRIM (N = 128, 4 x 1 waves): the band buffer holds exactly BM = 128 rows, so a tile yields BM - (KIN - 1)
 //     output rows and the last KIN - 1 rows of the wave tiles are computed and dropped (3 %): 2 x 128 rows x 256 B
 //     + 2 B tiles = 80 KB is what lets two such workgroups share a CU.
-template <typename T, int WM, int WN, int KIN, bool CONJ, bool TRIM, bool EPM, bool POSTF>
+//   PAD (round 5): channel counts that are multiples of 16 but not of 32 (start_filter = 16 models,
+//     /root/reference/models/interspeech_model.py:46-50): the re-laid-out kernel is zero-padded to the 32-channel granule
+//     (g.Qp, g.Jp), band units of channels >= Q are out-of-range DMA lanes (zeros), output pieces of channels >= J are not
+//     stored.  The matrix cores then run 2x (one side padded) to 4x the algorithmic MFMAs -- still several times the fp32-MFMA
+//     path these shapes took before; the unpadded instantiations are untouched.
+template <typename T, int WM, int WN, int KIN, bool CONJ, bool TRIM, bool EPM, bool POSTF, bool PAD = false>
 __global__ void __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *__restrict__ zero_line,
                const float *__restrict__ bias, T *__restrict__ out, const GemmGeom g)
@@ -616,7 +623,8 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
     if (mtile >= n_mt) return;
     const int p0 = mtile * BMU;
     const int j0 = blockIdx.y * BF;
-    const int nkc = g.Q / 32;
+    const int nkc = (PAD ? g.Qp : g.Q) / 32;
+    const int JW = PAD ? g.Jp : g.J;                // filters per part of the re-laid-out kernel
 #ifdef QK_PHASE_STAMPS       // probe builds only (tools/probe/phase_stamps.py): the stamps cost two registers, i.e. spills in the 64-row kernels
     unsigned long long *ts = (g.dbg_ts && blockIdx.x < 65536 && blockIdx.y == 0 && tid == 0) ? g.dbg_ts + 8 * blockIdx.x : nullptr;
     if (ts) ts[4] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | (unsigned)__builtin_amdgcn_s_getreg(63492);   // XCC_ID | HW_ID
@@ -676,8 +684,8 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
     const unsigned a_thr = (unsigned)(cmp_lo * g.Q + sub) * 2u;         // this thread's (component, 8 channels) of a row
     const unsigned a_hi = (unsigned)g.Q * 4u;                            // two components further (wave-uniform)
     // B unit u = tid + k * NTHR lies (NTHR / BF) (slot, part) segments further per k: a wave-uniform offset
-    const unsigned b_thr0 = (unsigned)((tid / BF) * g.J + j0 + tid % BF) * 16u;
-    const unsigned b_kstep = (unsigned)((NTHR / BF) * g.J) * 16u;
+    const unsigned b_thr0 = (unsigned)((tid / BF) * JW + j0 + tid % BF) * 16u;
+    const unsigned b_kstep = (unsigned)((NTHR / BF) * JW) * 16u;
     constexpr bool HALO = !TRIM;                    // pass RPTF holds the KIN - 1 halo rows (none when trimmed)
     constexpr int RPTF = HALO ? RPT3 - 1 : RPT3;    // full passes
     static_assert(RPTF * RPP == BM && RPTF <= 4, "band = up to four full passes (+ one halo pass)");
@@ -707,7 +715,7 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
     const int dma_slot = tid & ~63;
     // row pass r of the band -> band buffer object BUFOBJ: two DMAs (planes 0 and 1), lane = (row s_row + r RPP, slot s8)
 #define QK_DMA_A(R, BUFOBJ) do { \
-        const bool ok_ = (omask[R] >> aot) & 1u; \
+        const bool ok_ = ((omask[R] >> aot) & 1u) && (!PAD || akc * 32 + sub < g.Q); \
         const unsigned voff_ = ok_ ? (unsigned)(base_off[R] + adelta) * 2u + a_thr : kOutOfRange16; \
         if ((R) < RPTF || wave == 0) {               /* the halo pass holds KIN - 1 <= 8 rows: wave 0 only */ \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_void *)((BUFOBJ) + (R) * RPP * 8 + dma_slot), 16, (int)voff_, 0, 0, 0); \
@@ -718,7 +726,7 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
     unsigned bsoff = 0;
     auto b_prep = [&]() {
         const int tap = bot * KIN + bti;           // sub-step ti IS inner tap ti; b_rev only mirrors the band offset
-        bsoff = (unsigned)((tap * nkc + bkc) * 16 * g.J) * 16u;
+        bsoff = (unsigned)((tap * nkc + bkc) * 16 * JW) * 16u;
     };
     if (tile_ot) bot = __builtin_ctz(tile_ot);
     auto b_advance_if_more = [&]() {
@@ -756,7 +764,7 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
     // ds_read_b128 per lane right behind the prologue's barrier.  (16 vector float4 loads per lane moved 64 KB per workgroup into
     // registers and cost 1.4 k cycles; wave-uniform scalar loads + a move and a select per register 1.2 k.)
     float bias_v = 0.f;
-    if (g.has_bias && tid < 4 * BF) bias_v = bias[(tid / BF) * g.J + j0 + tid % BF];
+    if (g.has_bias && tid < 4 * BF && (!PAD || j0 + tid % BF < g.J)) bias_v = bias[(tid / BF) * g.J + j0 + tid % BF];
     QK_STAMP(6);
     a_advance_if_more();
     b_advance_if_more();                             // sub-step s fetches tile s + 1 straight into the other buffer
@@ -882,8 +890,9 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
         for (int b = 0; b < 4; ++b)
 #pragma unroll
             for (int q = 0; q < 2; ++q)
-                em[b][q] = o_ok ? *reinterpret_cast<const uint4 *>(static_cast<const T *>(g.ep_mask) + o_row + b * g.J + q * 16)
-                                : make_uint4(0u, 0u, 0u, 0u);
+                em[b][q] = (o_ok && (!PAD || j0 + wn * 32 + q * 16 + lh * 8 < g.J))
+                               ? *reinterpret_cast<const uint4 *>(static_cast<const T *>(g.ep_mask) + o_row + b * g.J + q * 16)
+                               : make_uint4(0u, 0u, 0u, 0u);
     }
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
@@ -905,7 +914,7 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
             const auto s0 = __builtin_amdgcn_permlane32_swap(pk[2 * q][0], pk[2 * q + 1][0], false, false);
             const auto s1 = __builtin_amdgcn_permlane32_swap(pk[2 * q][1], pk[2 * q + 1][1], false, false);
             uint4 v = make_uint4(s0[0], s1[0], s0[1], s1[1]);
-            if (o_ok) {
+            if (o_ok && (!PAD || j0 + wn * 32 + q * 16 + lh * 8 < g.J)) {       // (PAD: a 16-byte piece lies inside or outside J as a whole)
                 const long long o = o_row + b * g.J + q * 16;
                 if constexpr (EPM) {
                     if (g.ep_mask) {
@@ -1177,16 +1186,16 @@ int run16_point(const T *in, const uint4 *wq, const float *bias, T *out, GemmGeo
     return hipGetLastError() == hipSuccess ? 1 : QK_ERR_LAUNCH;
 }
 
-template <typename T, int WM, int WN, int KIN, bool TRIM>
+template <typename T, int WM, int WN, int KIN, bool TRIM, bool PAD = false>
 int run16_band(const T *in, const uint4 *wq, const T *zero_line, const float *bias, T *out, const GemmGeom &g,
                hipStream_t stream)
 {
     constexpr int BM = WM * 32, BF = WN * 32, BMU = TRIM ? BM - (KIN - 1) : BM, NTHR = WM * WN * 64;
     const int n_mt = (int)(((long long)g.b_nlines * g.b_wp + BMU - 1) / BMU);
-    dim3 grid((n_mt + 7) / 8 * 8, g.J / BF, 1);
+    dim3 grid((n_mt + 7) / 8 * 8, (PAD ? g.Jp : g.J) / BF, 1);
     // EPM (epilogue mask, QK_BWD_MASK_DX) is its own instantiation: its eight prefetched mask pieces cost 32 VGPRs
     // ... and so is POSTF (forward post-op: PReLU / dropout, pre-activation written beside y)
-#define QK_GO(C, E, P) hipLaunchKernelGGL((k_hgemm16_band<T, WM, WN, KIN, C, TRIM, E, P>), grid, dim3(NTHR), 0, stream, in, wq, zero_line, bias, out, g)
+#define QK_GO(C, E, P) hipLaunchKernelGGL((k_hgemm16_band<T, WM, WN, KIN, C, TRIM, E, P, PAD>), grid, dim3(NTHR), 0, stream, in, wq, zero_line, bias, out, g)
     const bool epm = g.ep_mask != nullptr, pf = g.post.kind != 0 && g.post_fwd != 0;
     if (g.sign_tbl != kSignConj) return QK_ERR_LAUNCH;                 // go16 folds the plain table into the kernel
     if (epm) QK_GO(true, true, false); else if (pf) QK_GO(true, false, true); else QK_GO(true, false, false);
@@ -1227,7 +1236,11 @@ int go16(const void *in, const void *mask, const float *w, const float *bias, vo
     for (int i = 0; i < 3; ++i) fastdiv_of((unsigned)g.osp[2 - i], &g.dv_mul[i], &g.dv_shr[i]);
     T *wq = static_cast<T *>(ws);
     const int Cq = transposed ? g.J : g.Q, F = transposed ? g.Q : g.J;
-    const long long total = (long long)g.taps * Cq * 4 * F;
+    g.Qp = pad32(g.Q); g.Jp = pad32(g.J);
+    const bool padded = g.Qp != g.Q || g.Jp != g.J;      // multiples of 16 only: the band kernel's PAD form or nothing (the caller goes on to the fp32-MFMA kernels)
+    GemmGeom bg;
+    if (padded && ((debug_flags() & kDbgNoBand16) || !band_geom(g, 2, &bg))) return 0;
+    const long long total = (long long)g.taps * g.Qp * 4 * g.Jp;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     if (!g.w_prepped) {                              // (the caller vouches for the workspace: qk_conv_desc_t.ws_has_kernel)
@@ -1236,8 +1249,7 @@ int go16(const void *in, const void *mask, const float *w, const float *bias, vo
     }
     const uint4 *wq4 = reinterpret_cast<const uint4 *>(wq);
     const T *zero_line = wq + total;                 // 256 zeroed bytes behind the re-laid-out kernel
-    GemmGeom bg;
-    if (!(debug_flags() & kDbgNoPoint16) && point_geom(g, &bg)) {
+    if (!padded && !(debug_flags() & kDbgNoPoint16) && point_geom(g, &bg)) {
         note_path(QK_PATH_MFMA16_POINT);
         return run16_point<T>((const T *)in, wq4, bias, (T *)out, bg, stream);
     }
@@ -1254,6 +1266,12 @@ int go16(const void *in, const void *mask, const float *w, const float *bias, vo
         // QK_DBG_BAND16_8WAVES forces the 8-wave tilings everywhere (A/B switch).
         const bool w8 = (debug_flags() & kDbgBand8Waves) != 0;
         const bool w8_wide = w8;
+        if (padded) {                                 // (4-wave tiles only: 64 x 256 when the padded width allows, else the trimmed 124 x 128)
+            if (bg.ks[2] == 5) return g.Jp % 64 == 0 ? run16_band<T, 2, 2, 5, false, true>(ip, wq4, zero_line, bias, op, bg, stream)
+                                                      : run16_band<T, 4, 1, 5, true, true>(ip, wq4, zero_line, bias, op, bg, stream);
+            return g.Jp % 64 == 0 ? run16_band<T, 2, 2, 3, false, true>(ip, wq4, zero_line, bias, op, bg, stream)
+                                  : run16_band<T, 4, 1, 3, true, true>(ip, wq4, zero_line, bias, op, bg, stream);
+        }
         if (bg.ks[2] == 5) {
             if (g.J % 64 == 0) return w8_wide ? run16_band<T, 4, 2, 5, false>(ip, wq4, zero_line, bias, op, bg, stream)
                                               : run16_band<T, 2, 2, 5, false>(ip, wq4, zero_line, bias, op, bg, stream);
@@ -1307,9 +1325,9 @@ int try_hgemm_16(int dtype, const void *in, const void *mask, const float *w_f32
     if (g.in_sc != 1 || g.out_sc != 1) return 0;                       // channels_last buffers only
     const long long S = (long long)g.osp[0] * g.osp[1] * g.osp[2];
     if (g.out_sn != S * g.out_ss) return 0;
-    if (g.Q % 32 != 0 || g.J % 32 != 0) return 0;
+    if (g.Q % 16 != 0 || g.J % 16 != 0) return 0;                      // (multiples of 16 but not 32: zero-padded band form, go16)
     if (g.taps > 32 || g.pd[0] != 1 || g.pd[1] != 1 || g.pd[2] != 1) return 0;   // tap bit mask; unit-stride map
-    const size_t need = (size_t)g.taps * g.Q * 4 * g.J * 2 + 256;
+    const size_t need = (size_t)g.taps * pad32(g.Q) * 4 * pad32(g.J) * 2 + 256;
     if (!ws || ws_bytes < need) return 0;
     if ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(ws) | reinterpret_cast<uintptr_t>(mask)) & 15) return 0;
     if (debug_flags() & kDbgNoMfma16) return 0;                        // diagnostic switch

@@ -423,10 +423,13 @@ __device__ __forceinline__ v8s tr_pair(const lds_char *p)                 // row
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-template <typename T, int RTT, int KIN>
+// PAD (RTT = 4 form only): Cq and / or F are multiples of 16 but not of 32 (start_filter = 16 models) -- the units of channels
+// >= Cq / filters >= F are out-of-range DMA lanes (zeros in LDS), gradient entries beyond the real extents are not written.
+template <typename T, int RTT, int KIN, bool PAD = false>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_wgrad16_band3(const T *__restrict__ x, const T *__restrict__ dy, float *__restrict__ dw, float *__restrict__ dbias, const WgradGeom g)
 {
+    static_assert(!PAD || RTT == 4, "padded channel counts run the 32 x 32 block form");
     static_assert(RTT == 2 || RTT == 4, "row tiles per tap");
     static_assert(KIN == 3 || KIN == 5, "inner taps");
     constexpr int NTHR = 512, WCG = 8 / RTT, CTW = 2;
@@ -450,7 +453,7 @@ k_wgrad16_band3(const T *__restrict__ x, const T *__restrict__ dy, float *__rest
     const int rt = wave / WCG, cg = wave % WCG;
     // ---- which block (as k_wgrad16_band)
     const int n_ot = g.ks[0] * g.ks[1];
-    const int ncc = g.Cq / CQB, nfc = g.F / BF;
+    const int ncc = (g.Cq + CQB - 1) / CQB, nfc = (g.F + BF - 1) / BF;       // (PAD: the last chunk may be half real)
     const int n_inner = n_ot * ncc * nfc;
     const int n_tiles = n_inner * g.n_splits;
     const int per_xcd = (n_tiles + 7) / 8;
@@ -479,6 +482,9 @@ k_wgrad16_band3(const T *__restrict__ x, const T *__restrict__ dy, float *__rest
     const unsigned x_thr = (unsigned)((s_src / UC) * g.Cq + c0 + (s_src % UC) * 8) * 2u;
     const unsigned d_thr = (unsigned)((s_src / UF) * g.F + f0 + (s_src % UF) * 8) * 2u;
     const unsigned x_pstep = (unsigned)((8 / UC) * g.Cq) * 2u, d_pstep = (unsigned)((8 / UF) * g.F) * 2u;     // plane -> plane (wave-uniform)
+    // PAD: this thread's 8-channel group of every plane lies inside the real extent, or it fetches nothing (the group index is
+    // the same in every plane: 8 units per plane are a whole number of components)
+    const bool x_grp_ok = !PAD || c0 + (s_src % UC) * 8 < g.Cq, d_grp_ok = !PAD || f0 + (s_src % UF) * 8 < g.F;
     const unsigned xs2 = (unsigned)((int)g.x_ss[2]) * 2u, dys = (unsigned)((int)g.dy_ss) * 2u;               // position -> position
     // ---- wave-uniform line state: a K step's rows lie on padded line A (the line of its row 0) or on B = A + 1
     int su0, Pj, lineB, nB, o0B, o1B;
@@ -518,7 +524,7 @@ k_wgrad16_band3(const T *__restrict__ x, const T *__restrict__ dy, float *__rest
         const int t = su0 + r;
         const bool selB = t >= WP;
         const int u = selB ? t - WP : t;
-        const bool ok = (selB ? xvB : xvA) != 0 && (unsigned)(u + g.b_cshift) < (unsigned)g.isp[2] && Pj + r < p_end + KIN - 1;
+        const bool ok = (selB ? xvB : xvA) != 0 && (unsigned)(u + g.b_cshift) < (unsigned)g.isp[2] && Pj + r < p_end + KIN - 1 && x_grp_ok;
         return ok ? (selB ? xbB : xbA) + (unsigned)u * xs2 + x_thr : kOOR;
     };
     auto decode_rows = [&]() {
@@ -527,7 +533,7 @@ k_wgrad16_band3(const T *__restrict__ x, const T *__restrict__ dy, float *__rest
             const int t = su0 + s_row;
             const bool selB = t >= WP;
             const int u = selB ? t - WP : t;
-            const bool ok = (selB ? dvB : dvA) != 0 && u < W && Pj + s_row < p_end;
+            const bool ok = (selB ? dvB : dvA) != 0 && u < W && Pj + s_row < p_end && d_grp_ok;
             vd = ok ? (selB ? dbB : dbA) + (unsigned)u * dys + d_thr : kOOR;
         }
         if (wave == 0) vh = decode_x(KM + s_row);
@@ -692,7 +698,7 @@ k_wgrad16_band3(const T *__restrict__ x, const T *__restrict__ dy, float *__rest
             const int ff = e % BF;
             const int p = (e / BF) & 3;
             const int cc = e / (4 * BF);
-            if (!(g.ablate & 2))
+            if (!(g.ablate & 2) && (!PAD || (c0 + cc < g.Cq && f0 + ff < g.F)))
                 atomicAdd(dw + (((tap0 + t) * g.Cq + c0 + cc) * 4 + p) * g.F + f0 + ff, slab[e]);
         }
     }
@@ -701,7 +707,7 @@ k_wgrad16_band3(const T *__restrict__ x, const T *__restrict__ dy, float *__rest
         for (int ct = 0; ct < CTW; ++ct) {
             const float s = dbacc[ct] + __shfl_xor(dbacc[ct], 32);            // the two 8-position halves of a K slice
             const int col = (cg * CTW + ct) * 32 + lr;
-            if (lane < 32) atomicAdd(dbias + (col / BF) * g.F + f0 + col % BF, s);
+            if (lane < 32 && (!PAD || f0 + col % BF < g.F)) atomicAdd(dbias + (col / BF) * g.F + f0 + col % BF, s);
         }
     }
 }
@@ -710,7 +716,8 @@ template <typename T, int RTT, int KIN, int CTW = 2>
 int run_wgrad16_band(const T *x, const T *dy, const T *ymask, float *dw, float *dbias, WgradGeom g, hipStream_t stream)
 {
     constexpr int CQB = RTT * 8, BF = (8 / RTT) * CTW * 8, KM = 64;
-    const long long other = (long long)g.ks[0] * g.ks[1] * (g.Cq / CQB) * (g.F / BF);
+    const bool padded = g.Cq % CQB != 0 || g.F % BF != 0;      // multiples of 16 only: the PAD form of the linear kernel (go_wgrad16_band admits nothing else)
+    const long long other = (long long)g.ks[0] * g.ks[1] * ((g.Cq + CQB - 1) / CQB) * ((g.F + BF - 1) / BF);
     const long long total_p = (long long)g.b_nlines * g.b_wp;
     const long long max_splits = (total_p + KM - 1) / KM;
     const int slots = device_cu_count();              // 84 - 100 KB of LDS: one workgroup per CU
@@ -740,7 +747,12 @@ int run_wgrad16_band(const T *x, const T *dy, const T *ymask, float *dw, float *
     dim3 grid((unsigned)((n_tiles + 7) / 8 * 8), 1, 1);
     // (RTT 2 / KIN 5: the masked form exists only with one column tile per wave, the linear form only with two -- go_wgrad16_band)
     constexpr bool kMasked = !(RTT == 2 && KIN == 5 && CTW == 2), kLinear = !(RTT == 2 && KIN == 5 && CTW == 1);
-    if (g.has_mask) {
+    if (padded) {
+        if constexpr (RTT == 4 && CTW == 2) {
+            if (g.has_mask || g.dym || g.b_wp < KM + 8) return 0;          // (the caller goes on: fp32-MFMA kernels)
+            hipLaunchKernelGGL((k_wgrad16_band3<T, RTT, KIN, true>), grid, dim3(512), 0, stream, x, dy, dw, dbias, g);
+        } else return 0;
+    } else if (g.has_mask) {
         if constexpr (kMasked) hipLaunchKernelGGL((k_wgrad16_band<T, RTT, KIN, true, CTW>), grid, dim3(512), 0, stream, x, dy, ymask, dw, dbias, g);
         else return QK_ERR_UNSUPPORTED;
     } else if (CTW == 2 && !g.dym && g.b_wp >= KM + 8 && !(debug_flags() & kDbgWgradBandV1)) {
@@ -788,7 +800,7 @@ int go_wgrad16_band(const void *x, const void *dy, const void *ymask, float *dw,
     const bool k5 = g.ks[2] == 5;
     // F % 64 == 0: 16 channels x 64 filters per block -- except with the relu mask, where the narrower dY tile of the
     // 32 x 32 form halves the mask work per block (B = 256 body layer: 1117 vs 1135 us linear, 1350 vs 1221 us masked)
-    if (g.F % 64 == 0 && !(g.has_mask && g.Cq % 32 == 0)) {
+    if (g.F % 64 == 0 && g.Cq % 16 == 0 && !(g.has_mask && g.Cq % 32 == 0)) {
         // masked, five taps, Cq a multiple of 16 only: the 64-filter block with its eight staged mask / dY units per thread
         // does not fit 256 registers (it spilled); ONE column tile per wave (16 channels x 32 filters per block, five
         // accumulator tiles) does -- a rare shape, never a chain's (their dY arrives pre-masked)
@@ -810,7 +822,8 @@ int try_wgrad_band_16(int dtype, const void *x, const void *dy, const void *ymas
     if (g.x_sc != 1 || g.dy_sc != 1) return 0;                         // channels_last buffers only
     const long long S = (long long)g.osp[0] * g.osp[1] * g.osp[2];
     if (g.dy_sn != S * g.dy_ss) return 0;                              // dy rows are addressed by flat position
-    if (g.F % 32 != 0 || g.Cq % (g.F % 64 == 0 ? 16 : 32) != 0) return 0;
+    if (g.F % 16 != 0 || g.Cq % 16 != 0) return 0;                     // (multiples of 16 but not of 32: the PAD form of the 32 x 32 block kernel, round 5)
+    if (g.has_mask && (g.F % 32 != 0 || g.Cq % (g.F % 64 == 0 ? 16 : 32) != 0)) return 0;
     if ((long long)g.batch * g.x_sn * 2 >= 0xF0000000ll || (long long)g.M * g.dy_ss * 2 >= 0xF0000000ll) return 0;
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(ymask)) & 15) return 0;
     WgradGeom bg;

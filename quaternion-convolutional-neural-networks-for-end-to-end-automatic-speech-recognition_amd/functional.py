@@ -165,9 +165,10 @@ class _Call(object):
         if d.dtype == L.QK_F32 or getattr(d, 'layout', L.QK_CH_LAST) != L.QK_CH_LAST:
             return 0
         cq, fq = (d.in_q, d.q_units) if isinstance(d, L.DenseDesc) else (d.cq, d.fq)
-        if cq % 32 or fq % 32:
+        if cq % 16 or fq % 16:
             return 0            # off the matrix-core path: the fp32-MFMA kernels never read the workspace -- nothing to cache or refresh
-        return int(math.prod(self.w_shape)) * 2 + 256
+        taps = int(math.prod(self.w_shape)) // (cq * 4 * fq)
+        return taps * ((cq + 31) // 32 * 32) * 4 * ((fq + 31) // 32 * 32) * 2 + 256       # (zero-padded to the kernels' 32-channel granule)
 
     def _ws(self, op, like, wparam=None):
         """Workspace of operation `op`.  `wparam`: the PARAMETER the kernel argument is (a long-lived leaf tensor).  When the
@@ -299,20 +300,26 @@ class _Call(object):
 class PostOp(object):
     """PReLU (+ Dropout) behind a quaternion layer (include/qk.h: qk_postop_t).  `alpha`: float32 device tensor, one
     slope (alpha_axis = -1) or one per position along spatial axis `alpha_axis` of the channels_last activation;
-    `rate`: dropout rate (0 = off); `seed`: 32-bit seed of the counter-based mask (a new one every step).
+    `rate`: dropout rate (0 = off); `seed`: 32-bit seed of the counter-based mask (a new one every step);
+    `seed_dev`: optional one-element int32 DEVICE tensor whose current value the kernels mix into the seed -- the step counter of
+    `adam_step(step=<that tensor>)`: the launch arguments are then the same every step (graph replay) and the masks still change.
     alpha=None is the relu form y = dropout(relu(pre)): one output tensor, the backward reads only y.
     The rate the kernels apply is round(rate * 256) / 256 (8 random bits per element): `applied_rate`."""
 
-    def __init__(self, alpha, alpha_axis=-1, rate=0.0, seed=0):
+    def __init__(self, alpha, alpha_axis=-1, rate=0.0, seed=0, seed_dev=None):
         if alpha is not None and (alpha.dtype != torch.float32 or not alpha.is_cuda):
             raise TypeError('PReLU slopes must be float32 device tensors')
+        if seed_dev is not None and (seed_dev.dtype != torch.int32 or not seed_dev.is_cuda or seed_dev.numel() != 1):
+            raise TypeError('seed_dev must be a one-element int32 device tensor (the training step counter of adam_step)')
+        self.seed_dev = seed_dev                      # kept alive: the struct below holds its address
         if not 0.0 <= float(rate) < 1.0:
             raise ValueError('dropout rate must be in [0, 1), got %r' % (rate,))
         self.alpha, self.alpha_axis, self.rate, self.seed = alpha, int(alpha_axis), float(rate), int(seed) & 0xffffffff
         self.applied_rate = min(255, int(self.rate * 256.0 + 0.5)) / 256.0
         self.flat = alpha.detach().reshape(-1).contiguous() if alpha is not None else None
         self.struct = L.PostOp(self.alpha_axis if alpha is not None else -1, self.flat.numel() if alpha is not None else 0,
-                               self.flat.data_ptr() if alpha is not None else None, self.rate, self.seed)
+                               self.flat.data_ptr() if alpha is not None else None, self.rate, self.seed,
+                               seed_dev.data_ptr() if seed_dev is not None else None)
 
 
 def _tensor_desc(t):
@@ -623,6 +630,21 @@ def adam_step(param, grad, m, v, step, lr=0.001, beta1=0.9, beta2=0.999, eps=1e-
         if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
             raise RuntimeError('adam_step needs contiguous float32 device buffers')
     n = param.numel()
+    if isinstance(step, torch.Tensor):
+        # the step number lives on the device (qk_adam_step_dev): `step` holds the number of steps applied so far and is
+        # incremented by the call -- no argument of the launch depends on the step (a captured graph replays correctly)
+        if step.dtype != torch.int32 or not step.is_cuda or step.numel() != 1:
+            raise TypeError('adam_step: a device-side step counter must be a one-element int32 device tensor')
+        if decay is not None and decay.numel() != n:
+            raise ValueError('decay must have one coefficient per parameter element')
+        with _on_device(param.device):
+            rc = L.lib().qk_adam_step_dev(_ptr(param), _ptr(grad), _ptr(m), _ptr(v), _ptr(decay), n, lr, beta1, beta2, eps,
+                                          _ptr(step), grad_scale, int(bool(zero_grad)), _stream(param))
+        L.check(rc, 'qk_adam_step_dev')
+        torch.autograd.graph.increment_version(param)
+        if _PREP_CACHE_ON:
+            refresh_prepped_kernels(param)
+        return
     with _on_device(param.device):
         if decay is not None:
             if decay.numel() != n:
@@ -954,7 +976,7 @@ def quaternion_conv_chain(x, layers):
         calls.append(call)
         ws.append(kernel.contiguous())
         bs.append(bias)
-        posts.append(None if po is None else PostOp(po['alpha'], po.get('alpha_axis', -1), po.get('rate', 0.0), po.get('seed', 0)))
+        posts.append(None if po is None else PostOp(po['alpha'], po.get('alpha_axis', -1), po.get('rate', 0.0), po.get('seed', 0), po.get('seed_dev')))
         alphas.append(None if po is None else po['alpha'])
         shape = tuple(call.y_shape)
     return _ConvChainFn.apply(xp, tuple(calls), tuple(posts), *ws, *bs, *alphas)

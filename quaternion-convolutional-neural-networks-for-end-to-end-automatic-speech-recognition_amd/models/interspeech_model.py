@@ -43,6 +43,10 @@ class TimitQCNN(torch.nn.Module):
         self.prelu = torch.nn.ModuleList([PReLU(shared_axes=[1, 0]) for _ in range(n_act)]) if aact == 'prelu' else None
         self.drop = Dropout(dropout)
         self._drop_base, self._drop_calls, self._dev = 0, 0, None
+        # optional: a one-element int32 device tensor (the step counter of functional.adam_step(step=<tensor>)) mixed into every
+        # dropout seed ON THE DEVICE -- with it the launch arguments of a training step do not change from step to step, which
+        # is what a captured graph needs (bench.ModelTrainStep.capture); fused post-op path only
+        self.drop_step_dev = None
         self.pred = TimeDistributed(Dense(62, activation='softmax', kernel_regularizer=reg, use_bias=True,
                                           bias_initializer='zeros', kernel_initializer='random_uniform'))
 
@@ -70,13 +74,13 @@ class TimitQCNN(torch.nn.Module):
         self._drop_calls += 1
         seed = (self._drop_base + 7919 * self._drop_calls) & 0xffffffff
         if self.prelu is None:
-            return dict(alpha=None, alpha_axis=-1, rate=rate, seed=seed)
+            return dict(alpha=None, alpha_axis=-1, rate=rate, seed=seed, seed_dev=self.drop_step_dev if rate > 0 else None)
         pl = self.prelu[k]
         if not pl.built:
             pl._build_device = self._dev
             pl.build(tuple(out_shape))
         axis = 0 if pl.alpha.numel() > 1 else -1
-        return dict(alpha=pl.alpha, alpha_axis=axis, rate=rate, seed=seed)
+        return dict(alpha=pl.alpha, alpha_axis=axis, rate=rate, seed=seed, seed_dev=self.drop_step_dev if rate > 0 else None)
 
     def forward(self, x):
         self._dev = x.device

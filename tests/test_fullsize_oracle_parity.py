@@ -217,7 +217,9 @@ def _host(t):
 TOL = {torch.bfloat16: (1e-2, 2e-3), torch.float16: (2e-3, 1e-3)}
 
 BODY = [('cfg3_64to64_b256_bf16', torch.bfloat16, 256, 64, 64), ('cfg3_32to64_b256_bf16', torch.bfloat16, 256, 32, 64),
-        ('cfg3_32to32_b256_bf16', torch.bfloat16, 256, 32, 32), ('cfg5_256to256_b32_fp16', torch.float16, 32, 256, 256)]
+        ('cfg3_32to32_b256_bf16', torch.bfloat16, 256, 32, 32), ('cfg5_256to256_b32_fp16', torch.float16, 32, 256, 256),
+        # round 5: the body shapes of the start_filter = 16 model (interspeech_model.py:46-50) on the PAD forms of the band kernels
+        ('sf16_16to16_b256_bf16', torch.bfloat16, 256, 16, 16), ('sf16_16to32_b256_bf16', torch.bfloat16, 256, 16, 32)]
 
 
 def _operands(dev, dtype, xs, ws, seed, relu_dropout_x=None):
@@ -268,7 +270,7 @@ def test_body_layer_in_the_bench_form_matches_sampled_oracle_at_full_size(case):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('case', BODY[:1] + BODY[3:], ids=[c[0] for c in BODY[:1] + BODY[3:]])
+@pytest.mark.parametrize('case', BODY[:1] + BODY[3:4], ids=[c[0] for c in BODY[:1] + BODY[3:4]])
 @pytest.mark.parametrize('form', ['relu_layer', 'chain_flags'])
 def test_body_layer_relu_and_chain_flag_forms_match_sampled_oracle_at_full_size(case, form):
     """The other two forms the bench times at full size: the plain relu layer (qk_conv_fwd + the fused masked qk_conv_bwd:

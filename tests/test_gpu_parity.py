@@ -138,6 +138,14 @@ ORACLE_CASES = [
     # offsets): masked = the one-column-tile-per-wave instantiation that replaced the spilling <2,5,true> (round 4); linear = <2,5,false>
     ('conv2d_cq16_f64_5tap_relu', 2, (2, 5, 70, 64), (3, 5, 16, 256), dict(padding='same', activation='relu')),
     ('conv2d_cq16_f64_5tap_linear', 2, (2, 5, 70, 64), (3, 5, 16, 256), dict(padding='same', activation=None)),
+    # round 5: channel counts that are multiples of 16 but not of 32 (start_filter = 16 models) -- the PAD forms of the 16-bit band
+    # kernels (re-laid-out kernel zero-padded to 32, out-of-range DMA lanes, unstored output pieces): 16 -> 16, 16 -> 32, a
+    # 48-channel layer whose second chunk is half real, a 1-D three-tap layer, and a relu layer (masked backward: fp32-MFMA forms)
+    ('conv2d_16to16_5tap', 2, (2, 6, 80, 64), (3, 5, 16, 64), dict(padding='same', activation=None)),
+    ('conv2d_16to16_5tap_relu', 2, (2, 6, 80, 64), (3, 5, 16, 64), dict(padding='same', activation='relu')),
+    ('conv2d_16to32_3tap', 2, (2, 5, 75, 64), (3, 3, 16, 128), dict(padding='same', activation=None)),
+    ('conv2d_48to16_5tap', 2, (1, 4, 90, 192), (3, 5, 48, 64), dict(padding='same', activation=None)),
+    ('conv1d_16to48_valid', 1, (3, 100, 64), (3, 16, 192), dict(padding='valid', activation=None)),
     # one tap per produced row: the streaming point-form kernel (k_hgemm16_point) in 16 bit
     ('dense_point_64', 0, (333, 256), (64, 256), dict(activation='relu')),
     ('dense_point_32to128', 0, (200, 128), (32, 512), dict(activation=None)),
@@ -176,7 +184,8 @@ HALF_CASES = [c for c in ORACLE_CASES if c[0] in (
     'cfg2_conv1d_b8_f64', 'conv1d_odd_channels', 'conv2d_body_small', 'conv2d_body64_small', 'conv2d_32to64', 'conv1d_64to32_valid',
     'conv2d_chfirst_body_small',
     'conv2d_first_layer', 'dense_timit_head', 'dense_point_64', 'dense_point_32to128', 'conv2d_head_valid_conj', 'conv1d_1x1_64', 'conv3d_32ch', 'conv2d_32ch_outer_stride_dil', 'conv2d_64ch_valid_wide',
-    'conv2d_cq16_f64_5tap_relu', 'conv2d_cq16_f64_5tap_linear')]
+    'conv2d_cq16_f64_5tap_relu', 'conv2d_cq16_f64_5tap_linear',
+    'conv2d_16to16_5tap', 'conv2d_16to16_5tap_relu', 'conv2d_16to32_3tap', 'conv2d_48to16_5tap', 'conv1d_16to48_valid')]
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16], ids=['bf16', 'fp16'])
@@ -191,6 +200,42 @@ def test_half_matches_oracle_on_rounded_inputs(case, dtype):
         err = _rel_err(v, want[k])
         tol = tol16 if k in ('y', 'dx') else tol32
         assert err <= tol, '%s: rel err %.3g > %.1g' % (k, err, tol)
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16], ids=['bf16', 'fp16'])
+def test_sixteen_channel_layers_run_on_the_matrix_cores(dtype):
+    """/root/reference/models/interspeech_model.py:46-50: start_filter is a free hyperparameter; sf = 16 gives 16 -> 16 and 16 -> 32
+    body layers.  Until round 5 every 16-bit call with Cq % 32 or F % 32 ran the fp32-MFMA kernels (1/16 of the bf16 rate); now
+    multiples of 16 take the PAD forms of the band kernels in all three directions (qk_last_path), and the values are those
+    of the exact fp32-MFMA kernels on the same rounded operands."""
+    import qcnn_amd
+    from qcnn_amd import _lib
+    F = qcnn_amd.functional
+    dev = _dev()
+    g = torch.Generator(device=dev).manual_seed(3)
+    for cq, fq in ((16, 16), (16, 32), (32, 16), (48, 48)):
+        xs, ws = (3, 7, 90, 4 * cq), (3, 5, cq, 4 * fq)
+        x = torch.randn(xs, device=dev, generator=g).to(dtype)
+        w = (torch.randn(ws, device=dev, generator=g) / 20).to(dtype).float()
+        b = torch.randn(4 * fq, device=dev, generator=g) / 10
+        call = F.conv_call(xs, ws, dtype, 2, 1, 'same', 'channels_last', 1, None, True, False)
+        y = call.fwd(x, w, b)
+        p_f = _lib.last_path()
+        dy = torch.randn(y.shape, device=dev, generator=g).to(dtype)
+        dx = call.bwd_data(dy, None, w)
+        p_d = _lib.last_path()
+        dw, db = call.bwd_weight(x, dy, None, True)
+        p_w = _lib.last_path()
+        assert (p_f, p_d, p_w) == ('mfma16_band',) * 3, (cq, fq, p_f, p_d, p_w)
+        with _lib.debug_flags(_lib.QK_DBG_NO_MFMA16):
+            y0 = call.fwd(x, w, b)
+            dx0 = call.bwd_data(dy, None, w)
+            dw0, db0 = call.bwd_weight(x, dy, None, True)
+            assert _lib.last_path() == 'fp32_mfma'
+        tol = 1e-2 if dtype == torch.bfloat16 else 2e-3
+        rel = lambda a, r: float((a.float() - r.float()).abs().max() / r.float().abs().max())
+        assert rel(y, y0) <= tol and rel(dx, dx0) <= tol, (cq, fq, rel(y, y0), rel(dx, dx0))
+        assert rel(dw, dw0) <= 1e-4 and rel(db, db0) <= 1e-4, (cq, fq, rel(dw, dw0), rel(db, db0))
 
 
 @pytest.mark.parametrize('dtype,tol', [(torch.float32, 1e-4), (torch.bfloat16, 1e-2)], ids=['fp32', 'bf16'])

@@ -507,7 +507,8 @@ def test_fused_ctc_degenerate_samples():
 
 
 @pytest.mark.gpu
-def test_deterministic_mode_makes_the_training_step_bit_repeatable():
+@pytest.mark.parametrize('shape_loss', [(4, 24, 'sum'), (44, 192, 'ctc')], ids=['small_sumloss', 'fused_softmax_ctc'])
+def test_deterministic_mode_makes_the_training_step_bit_repeatable(shape_loss):
     """QK_DBG_DETERMINISTIC (include/qk.h): every backward-weight kernel runs one split of its reduction per gradient
     tile and one owner per bias column, so no float sum depends on the order in which atomics land (TF's CPU
     Conv2DBackpropFilter, the reference's path, is deterministic too).  Three whole training steps of the headline graph
@@ -518,11 +519,15 @@ def test_deterministic_mode_makes_the_training_step_bit_repeatable():
     import bench
     from qcnn_amd import _lib
     dev = torch.device('cuda:0')
-    cfg = dict(kind='model', batch=4, frames=24, sf=32, layers=4, dtype='bf16', dropout=0.25, l2=1e-4, activation='relu')
+    # second case (round-4 advisor): 44 x 192 = 8448 rows reach the fused Dense(62) + softmax layer (>= 8192 rows: its bias
+    # gradient was a grid of float atomics) and the model's own CTC cost (LDS float atomics in the occupancy sums) -- both
+    # take their fixed-order forms under the flag
+    bsz, frames, loss_kind = shape_loss
+    cfg = dict(kind='model', batch=bsz, frames=frames, sf=32, layers=4, dtype='bf16', dropout=0.25, l2=1e-4, activation='relu')
 
     def run(flags):
         with _lib.debug_flags(flags):
-            job = bench.ModelTrainStep(cfg, dev, 0, 1)
+            job = bench.ModelTrainStep(cfg, dev, 0, 1, loss=loss_kind)
             torch.manual_seed(7)                     # the dropout masks of the three steps
             for _ in range(3):
                 job.step()
@@ -658,3 +663,43 @@ def test_working_example_script_runs_one_epoch_on_the_decoda_fixture(tmp_path, m
     assert len(last) == 1
     loss, acc = float(last[0].split('=')[1].split('|')[0]), float(last[0].split('=')[2])
     assert np.isfinite(loss) and 0.0 < loss < 5.0 and 0.0 <= acc <= 1.0
+
+
+@pytest.mark.gpu
+def test_model_step_replayed_as_one_graph_equals_the_eager_step():
+    """bench.ModelTrainStep.capture(): forward, CTC cost, backward, fused Adam and the kernel re-layout as ONE hipGraph.  The Adam
+    step number and the dropout seeds' per-step part live in a device counter (qk_adam_step_dev, qk_postop_t.drop_seed_dev), so
+    replays are new steps, not repetitions: three replays must leave the parameters and both Adam moments BIT-identical to
+    three eager steps driven by the same device counter (deterministic mode: no order-dependent float sums), the masks of
+    consecutive steps must differ, and the counter must have advanced."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    import bench
+    from qcnn_amd import _lib
+    dev = torch.device('cuda:0')
+    cfg = dict(kind='model', batch=4, frames=40, sf=32, layers=4, dtype='bf16', dropout=0.25, l2=1e-4, activation='relu')
+
+    def run(graph):
+        with _lib.debug_flags(_lib.QK_DBG_DETERMINISTIC):
+            job = bench.ModelTrainStep(cfg, dev, 0, 1, loss='ctc')
+            job.model._new_drop_base = lambda: setattr(job.model, '_drop_calls', 0) or setattr(job.model, '_drop_base', 12345)
+            if graph:
+                job.capture()                        # two eager device-counter steps, then the capture pass (which executes nothing)
+            else:
+                job.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+                job.model.drop_step_dev = job.step_dev
+                for _ in range(2):
+                    job.step()
+            params = [job.flat.param.clone()]
+            for _ in range(3):
+                job.step()
+                params.append(job.flat.param.clone())
+            torch.cuda.synchronize()
+            return params, job.m.clone(), job.v.clone(), int(job.step_dev.item())
+    pe, me, ve, te = run(False)
+    pg, mg, vg, tg = run(True)
+    assert te == tg == 5
+    for i, (a, b) in enumerate(zip(pe, pg)):
+        assert torch.equal(a, b), 'parameters after %d steps differ between eager and graph replay: %g' % (2 + i, float((a - b).abs().max()))
+    assert torch.equal(me, mg) and torch.equal(ve, vg)
+    assert not torch.equal(pg[1] - pg[0], pg[2] - pg[1])           # replays are steps, not repetitions
