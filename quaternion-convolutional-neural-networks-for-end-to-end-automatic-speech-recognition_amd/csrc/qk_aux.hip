@@ -187,8 +187,9 @@ struct PostDims { long long units; int upr; int key_div; int key_mod; };   // un
 template <typename T, bool BWD>
 __global__ void __launch_bounds__(256)
 k_postop(const T *__restrict__ pre, const T *__restrict__ dy, T *__restrict__ out, float *__restrict__ dalpha,
-         const PostOp p, const PostDims d)
+         const PostOp p_in, const PostDims d)
 {
+    const PostOp p = resolve_seed(p_in);
     constexpr int VEC = sizeof(T) == 2 ? 8 : 4;
     __shared__ float slab[256];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -214,7 +215,7 @@ k_postop(const T *__restrict__ pre, const T *__restrict__ dy, T *__restrict__ ou
                 float v[4] = {q.x, q.y, q.z, q.w}, g[4] = {0.f, 0.f, 0.f, 0.f};
                 if constexpr (BWD) { const float4 t = *reinterpret_cast<const float4 *>(dy + e0); g[0] = t.x; g[1] = t.y; g[2] = t.z; g[3] = t.w; }
                 unsigned rb[2] = {0u, 0u};
-                if (p.drop_thr) drop_bits8((unsigned)(e0 >> 3), eff_seed(p), rb[0], rb[1]);
+                if (p.drop_thr) drop_bits8((unsigned)(e0 >> 3), p.drop_seed, rb[0], rb[1]);
                 const unsigned bits = rb[(e0 >> 2) & 1];                   // this thread's 4 elements: half a unit
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {

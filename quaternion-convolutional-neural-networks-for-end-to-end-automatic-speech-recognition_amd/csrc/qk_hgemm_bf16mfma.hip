@@ -414,6 +414,7 @@ k_hgemm16(const T *__restrict__ in, const T *__restrict__ mask, const uint4 *__r
 #pragma unroll
     for (int b = 0; b < 4; ++b) bia4[b] = g.has_bias ? bias[b * g.J + j0 + wn * 32 + lr] : 0.f;
     // post-op (PReLU / dropout, qk_postop.h): forward writes pre and y; backward-data applies the derivative
+    const PostOp psd = resolve_seed(g.post);
     const bool post_on = g.post.kind != 0;
     const bool post_bwd = post_on && g.ep_mask != nullptr, post_fwd = post_on && g.post_fwd != 0;
     float *aslab = reinterpret_cast<float *>(reinterpret_cast<char *>(lds) + 32768);
@@ -466,12 +467,12 @@ k_hgemm16(const T *__restrict__ in, const T *__restrict__ mask, const uint4 *__r
                     uint4 v = val;
                     if (g.ep_mask) {
                         const uint4 mk = *reinterpret_cast<const uint4 *>(static_cast<const T *>(g.ep_mask) + o);
-                        if (post_bwd) v = post_bwd8<T>(v, mk, a_val[pass], (unsigned)o, g.post, dal[pass]);
+                        if (post_bwd) v = post_bwd8<T>(v, mk, a_val[pass], (unsigned)o, psd, dal[pass]);
                         else v = mask8(v, mk);
                     }
                     if (post_fwd) {
                         if (g.pre_out) *reinterpret_cast<uint4 *>(static_cast<T *>(g.pre_out) + o) = v;
-                        v = post_fwd8<T>(v, a_val[pass], (unsigned)o, g.post);
+                        v = post_fwd8<T>(v, a_val[pass], (unsigned)o, psd);
                     }
                     *reinterpret_cast<uint4 *>(out + o) = v;
                 }
@@ -862,6 +863,7 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
     QK_STAMP(2);
     if ((g.ablate & 8) && acc[0][0] != 123.456f) return;              // (ablate 8: profiling, no epilogue)
     const bool post_on = (EPM || POSTF) && g.post.kind != 0;
+    const PostOp psd = (EPM || POSTF) ? resolve_seed(g.post) : g.post;
     const int tr = wm * 32 + lr;                                     // row inside the tile
     bool o_ok;
     long long o_row;                                                 // element offset of the lane's first piece, component 0
@@ -918,14 +920,14 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
                 const long long o = o_row + b * g.J + q * 16;
                 if constexpr (EPM) {
                     if (g.ep_mask) {
-                        if (post_on) v = post_bwd8<T>(v, em[b][q], a_val, (unsigned)o, g.post, dal);
+                        if (post_on) v = post_bwd8<T>(v, em[b][q], a_val, (unsigned)o, psd, dal);
                         else v = mask8(v, em[b][q]);
                     }
                 }
                 if constexpr (POSTF) {
                     if (post_on) {
                         if (g.pre_out) *reinterpret_cast<uint4 *>(static_cast<T *>(g.pre_out) + o) = v;
-                        v = post_fwd8<T>(v, a_val, (unsigned)o, g.post);
+                        v = post_fwd8<T>(v, a_val, (unsigned)o, psd);
                     }
                 }
                 *reinterpret_cast<uint4 *>(out + o) = v;
@@ -1015,6 +1017,7 @@ k_hgemm16_point(const T *__restrict__ in, const uint4 *__restrict__ wq, const fl
     // backward post-op (PReLU / dropout derivative of the tensor whose gradient is produced, see k_hgemm16)
     const bool post_on = EPM && g.post.kind != 0;
     const bool post_fwd_relu = !EPM && g.post.kind == 2 && g.post_fwd != 0;
+    const PostOp psd = resolve_seed(g.post);
     float *aslab = reinterpret_cast<float *>(lds + B_U + BF + 8 * 32 * EP_PITCH / 16);
     if (post_on && g.dalpha && tid < 256) aslab[tid] = 0.f;      // (the first unit's slice load brings the barrier)
     const uint4 *w_rd = lds + wn * 32 + lr;
@@ -1116,10 +1119,10 @@ k_hgemm16_point(const T *__restrict__ in, const uint4 *__restrict__ wq, const fl
             for (int pass = 0; pass < 2; ++pass) {
                 uint4 v = *reinterpret_cast<const uint4 *>(ep + (e_row + 16 * pass) * EP_PITCH + e_chunk * 16);
                 if constexpr (EPM) {
-                    if (post_on) v = post_bwd8<T>(v, em[b][pass], a_val[pass], o_off[pass] / 2u + (unsigned)(b * g.J), g.post, dal[pass]);
+                    if (post_on) v = post_bwd8<T>(v, em[b][pass], a_val[pass], o_off[pass] / 2u + (unsigned)(b * g.J), psd, dal[pass]);
                     else v = mask8(v, em[b][pass]);
                 } else {
-                    if (post_fwd_relu) v = post_fwd8<T>(v, 0.f, o_off[pass] / 2u + (unsigned)(b * g.J), g.post);     // y = dropout(relu(pre))
+                    if (post_fwd_relu) v = post_fwd8<T>(v, 0.f, o_off[pass] / 2u + (unsigned)(b * g.J), psd);     // y = dropout(relu(pre))
                 }
                 buf_store16b(rout, o_off[pass], (unsigned)(b * g.J) * 2u, v);
             }

@@ -34,11 +34,15 @@ __device__ __forceinline__ void drop_bits8(unsigned unit_index, unsigned seed, u
 }
 // The seed the hash runs on: drop_seed, plus -- when the caller gave a device counter (qk_postop_t.drop_seed_dev) -- a multiple of
 // the counter's CURRENT value: a captured graph replays the same launch arguments every step and still draws new masks, the
-// forward and the backward of one step agree because the counter moves only between steps (qk_adam_step_dev).  Wave-uniform:
-// one scalar load per kernel.
-__device__ __forceinline__ unsigned eff_seed(const PostOp &p)
+// forward and the backward of one step agree because the counter moves only between steps (qk_adam_step_dev).  Resolved ONCE at
+// kernel entry into a by-value copy of the post-op (one scalar load; a load at the point of use sat in the epilogues' inner
+// branches as a vector load with a vmcnt(0) behind it).
+__device__ __forceinline__ PostOp resolve_seed(const PostOp &p)
 {
-    return p.seed_dev ? p.drop_seed + *p.seed_dev * 0x9E3779B1u : p.drop_seed;
+    PostOp r = p;
+    if (r.seed_dev) r.drop_seed += __builtin_amdgcn_readfirstlane(*r.seed_dev) * 0x9E3779B1u;
+    r.seed_dev = nullptr;
+    return r;
 }
 // scale factor of element e (0..3) of the half-unit whose bits are `bits`: 0 when dropped
 __device__ __forceinline__ float drop_factor(unsigned bits, int e, const PostOp &p)
@@ -87,7 +91,7 @@ template <typename T>
 __device__ __forceinline__ uint4 post_fwd8(const uint4 &pre, float alpha, unsigned idx, const PostOp &p)
 {
     unsigned in[4] = {pre.x, pre.y, pre.z, pre.w}, out[4], rb[2] = {0u, 0u};
-    if (p.drop_thr) drop_bits8(idx >> 3, eff_seed(p), rb[0], rb[1]);
+    if (p.drop_thr) drop_bits8(idx >> 3, p.drop_seed, rb[0], rb[1]);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         float a, b;
@@ -119,7 +123,7 @@ __device__ __forceinline__ uint4 post_bwd8(const uint4 &dy, const uint4 &pre, fl
 {
     if (p.kind == 2) return post_bwd8_relu<T>(dy, pre, p.drop_scale);
     unsigned g[4] = {dy.x, dy.y, dy.z, dy.w}, q[4] = {pre.x, pre.y, pre.z, pre.w}, out[4], rb[2] = {0u, 0u};
-    if (p.drop_thr) drop_bits8(idx >> 3, eff_seed(p), rb[0], rb[1]);
+    if (p.drop_thr) drop_bits8(idx >> 3, p.drop_seed, rb[0], rb[1]);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         float ga, gb, pa, pb;

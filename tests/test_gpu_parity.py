@@ -1039,14 +1039,15 @@ def test_cfg5_stack_full_size_16bit_kernels_agree_with_exact_fp32_kernels():
 
 
 # ---- post-ops: PReLU + Dropout fused into the kernels (interspeech_model.py:99-101,117-121) ----------------------------
-def _np_drop_factor(shape, seed, rate):
+def _np_drop_factor(shape, seed, rate, idx=None):
     """The counter-based dropout mask of csrc/qk_postop.h restated in numpy: one 32-bit hash (+ one extra mixing round)
     per 16-byte unit of 8 elements of the flat channels_last tensor, 8 bits per element, keep iff bits >= round(rate * 256);
-    kept elements are scaled by 256 / (256 - thr)."""
+    kept elements are scaled by 256 / (256 - thr).  idx: the flat element indices to evaluate (an array of `shape`;
+    default: all of a tensor of that shape) -- a window of a larger tensor keeps that tensor's indices."""
     if rate == 0:
         return np.ones(shape)
     n = int(np.prod(shape))
-    idx = np.arange(n, dtype=np.uint64)
+    idx = np.arange(n, dtype=np.uint64) if idx is None else np.asarray(idx, dtype=np.uint64).reshape(-1)
     M = np.uint64(0xffffffff)
     h = ((idx >> np.uint64(3)) ^ np.uint64(seed)) * np.uint64(0x9E3779B1) & M
     h ^= h >> np.uint64(15); h = h * np.uint64(0x85EBCA77) & M
