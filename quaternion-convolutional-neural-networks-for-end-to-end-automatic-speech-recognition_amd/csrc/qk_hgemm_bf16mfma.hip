@@ -790,6 +790,11 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
     static_assert(kBandOpsMax + 2 * BU <= 16, "one staging slot after every second MFMA");
 
     int s = 0;                                      // global sub-step
+    // PAD, Q = 16 (mod 32): the upper 16 channels of the last chunk are padding -- its second 16-deep step multiplies zeros and is
+    // skipped (where the staging schedule fits the first step's slots: the 4 x 1 tile form the 16-wide layers take)
+    constexpr bool KSKIP = PAD && (BU + kBandOpsMax <= 8);
+    const bool q_half = KSKIP && g.Qp != g.Q;
+    int ckc = 0;                                    // channel chunk of the group being computed
     static_assert(KIN % 2 == 1, "parity of a group's first sub-step = parity of the group");
     for (int gi2 = (g.ablate & 4) ? groups : 0; gi2 < groups; gi2 += 2)
 #pragma unroll
@@ -797,6 +802,8 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
         int gi = gi2 + gh;
         if (gi >= groups) break;
         const uint4 *band = gh ? ldsA1 : ldsA0;          // (gi2 is even: the parity of a group is gh, and both band OBJECTS are compile-time constants)
+        const bool khalf = KSKIP && q_half && ckc == nkc - 1;
+        if (KSKIP) { if (++ckc == nkc) ckc = 0; }
         a_prep();
 #pragma unroll
         for (int ti = 0; ti < KIN; ++ti, ++s) {
@@ -809,6 +816,7 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
             b_prep();
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
+                if (KSKIP && ks == 1 && khalf) continue;
                 uint4 A[4], B[4];
 #pragma unroll
                 for (int a = 0; a < 4; ++a) A[a] = a_rd[(a >> 1) * PL + (((a & 1) * 4 + ks * 2) ^ fsw)];

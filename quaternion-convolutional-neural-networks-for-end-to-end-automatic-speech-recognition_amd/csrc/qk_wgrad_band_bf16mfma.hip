@@ -425,14 +425,18 @@ __device__ __forceinline__ v8s tr_pair(const lds_char *p)                 // row
 
 // PAD (RTT = 4 form only): Cq and / or F are multiples of 16 but not of 32 (start_filter = 16 models) -- the units of channels
 // >= Cq / filters >= F are out-of-range DMA lanes (zeros in LDS), gradient entries beyond the real extents are not written.
-template <typename T, int RTT, int KIN, bool PAD = false>
+// CTW = 1 (RTT = 2 only): ONE column tile per wave -- 16 channels x 32 filters per block, KIN accumulator tiles per wave -- for
+// Cq = 16 (mod 32) layers whose filter count is not a multiple of 64 (16 -> 16, 16 -> 32): the channel side is exact, the filter
+// side pads to 32 at most (the 32 x 32 form would pad both sides).
+template <typename T, int RTT, int KIN, bool PAD = false, int CTW = 2>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_wgrad16_band3(const T *__restrict__ x, const T *__restrict__ dy, float *__restrict__ dw, float *__restrict__ dbias, const WgradGeom g)
 {
-    static_assert(!PAD || RTT == 4, "padded channel counts run the 32 x 32 block form");
+    static_assert(!PAD || RTT == 4 || CTW == 1, "padded channel counts: the 32 x 32 block form, or 16 x 32 with an exact channel side");
+    static_assert(CTW == 2 || (CTW == 1 && RTT == 2), "column tiles per wave");
     static_assert(RTT == 2 || RTT == 4, "row tiles per tap");
     static_assert(KIN == 3 || KIN == 5, "inner taps");
-    constexpr int NTHR = 512, WCG = 8 / RTT, CTW = 2;
+    constexpr int NTHR = 512, WCG = 8 / RTT;
     constexpr int CQB = RTT * 8, BF = WCG * CTW * 8;          // channels / filters per block
     constexpr int KM = 64, KS = KM / 16, NMF = KIN * CTW;
     constexpr int NPX = (4 * CQB * 2) / 128, NPD = (4 * BF * 2) / 128;     // 128-byte planes of an X / dY row
@@ -552,7 +556,9 @@ k_wgrad16_band3(const T *__restrict__ x, const T *__restrict__ dy, float *__rest
         for (int ct = 0; ct < CTW; ++ct)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][ct][r] = 0.f;
-    float dbacc[CTW] = {0.f, 0.f};
+    float dbacc[CTW];
+#pragma unroll
+    for (int ct = 0; ct < CTW; ++ct) dbacc[ct] = 0.f;
 
     // ---- fragment addresses: lane -> (row fr_row of the 16 a transposing read pair covers, 8-byte chunk fr_ch) --------------
     const int Lg = lane & 15, g16 = (lane >> 4) & 1, kh = lane >> 5;
@@ -569,7 +575,10 @@ k_wgrad16_band3(const T *__restrict__ x, const T *__restrict__ dy, float *__rest
     }
     int b_base[CTW];
 #pragma unroll
-    for (int ct = 0; ct < CTW; ++ct) b_base[ct] = DOFF + cg * DPL + fr_row * 128 + ((ct ^ ((fr_row >> 1) & 1)) * 64) + fr_ch * 2;
+    for (int ct = 0; ct < CTW; ++ct) {               // column tile cg CTW + ct = 64 bytes of the dY row: plane (tile >> 1), block (tile & 1)
+        const int ti = cg * CTW + ct;
+        b_base[ct] = DOFF + (ti >> 1) * DPL + fr_row * 128 + (((ti & 1) ^ ((fr_row >> 1) & 1)) * 64) + fr_ch * 2;
+    }
 
 #define QK_FRAG_A(FA, BUF, KS_, T_) \
         FA[T_] = tr_pair((const lds_char *)(BUF) + a_base[((T_) & 1) * 2 + (((T_) >> 1) & 1)] + ((KS_) * 16 + (T_)) * 128)
@@ -613,8 +622,10 @@ k_wgrad16_band3(const T *__restrict__ x, const T *__restrict__ dy, float *__rest
                 else if (!(LAST)) QK_FRAG_A(fA, BNXT, 0, t); \
             } \
             if (!(LAST)) { \
-                if ((KS_) == 2) { if (j == 1) QK_DMA_X(BDMA); if (j == 3) QK_DMA_H(BDMA); } \
-                if ((KS_) == 3 && (j & 1) && j / 2 < NPD) QK_DMA_D1(BDMA, j / 2); \
+                if ((KS_) == 2) { if (j == (NMF > 1 ? 1 : 0)) QK_DMA_X(BDMA); if (j == (NMF > 3 ? 3 : NMF - 1)) QK_DMA_H(BDMA); } \
+                if ((KS_) == 3) {                                     /* the NPD dY planes spread over the sub-step's NMF slots */ \
+                    _Pragma("unroll") for (int p_ = 0; p_ < NPD; ++p_) if ((p_ * NMF + NMF / 2) / NPD == j) QK_DMA_D1(BDMA, p_); \
+                } \
             } \
             __builtin_amdgcn_sched_barrier(0); \
         } \
@@ -712,7 +723,7 @@ k_wgrad16_band3(const T *__restrict__ x, const T *__restrict__ dy, float *__rest
     }
 }
 
-template <typename T, int RTT, int KIN, int CTW = 2>
+template <typename T, int RTT, int KIN, int CTW = 2, bool LINEAR_NARROW = false>
 int run_wgrad16_band(const T *x, const T *dy, const T *ymask, float *dw, float *dbias, WgradGeom g, hipStream_t stream)
 {
     constexpr int CQB = RTT * 8, BF = (8 / RTT) * CTW * 8, KM = 64;
@@ -746,11 +757,13 @@ int run_wgrad16_band(const T *x, const T *dy, const T *ymask, float *dw, float *
     const long long n_tiles = splits * other;
     dim3 grid((unsigned)((n_tiles + 7) / 8 * 8), 1, 1);
     // (RTT 2 / KIN 5: the masked form exists only with one column tile per wave, the linear form only with two -- go_wgrad16_band)
-    constexpr bool kMasked = !(RTT == 2 && KIN == 5 && CTW == 2), kLinear = !(RTT == 2 && KIN == 5 && CTW == 1);
-    if (padded) {
-        if constexpr (RTT == 4 && CTW == 2) {
+    constexpr bool kMasked = !(RTT == 2 && KIN == 5 && CTW == 2) && !LINEAR_NARROW, kLinear = !(RTT == 2 && KIN == 5 && CTW == 1) && !LINEAR_NARROW;
+    constexpr bool kNarrow = RTT == 2 && CTW == 1 && LINEAR_NARROW;            // the round-5 16 x 32 block form (linear kernel only)
+    if (padded || kNarrow) {
+        if constexpr ((RTT == 4 && CTW == 2) || kNarrow) {
             if (g.has_mask || g.dym || g.b_wp < KM + 8) return 0;          // (the caller goes on: fp32-MFMA kernels)
-            hipLaunchKernelGGL((k_wgrad16_band3<T, RTT, KIN, true>), grid, dim3(512), 0, stream, x, dy, dw, dbias, g);
+            if (padded) hipLaunchKernelGGL((k_wgrad16_band3<T, RTT, KIN, true, CTW>), grid, dim3(512), 0, stream, x, dy, dw, dbias, g);
+            else hipLaunchKernelGGL((k_wgrad16_band3<T, RTT, KIN, false, CTW>), grid, dim3(512), 0, stream, x, dy, dw, dbias, g);
         } else return 0;
     } else if (g.has_mask) {
         if constexpr (kMasked) hipLaunchKernelGGL((k_wgrad16_band<T, RTT, KIN, true, CTW>), grid, dim3(512), 0, stream, x, dy, ymask, dw, dbias, g);
@@ -807,6 +820,10 @@ int go_wgrad16_band(const void *x, const void *dy, const void *ymask, float *dw,
         if (g.has_mask && k5) return run_wgrad16_band<T, 2, 5, 1>(xp, dp, yp, dw, dbias, g, stream);
         return k5 ? run_wgrad16_band<T, 2, 5>(xp, dp, yp, dw, dbias, g, stream) : run_wgrad16_band<T, 2, 3>(xp, dp, yp, dw, dbias, g, stream);
     }
+    // Cq = 16 (mod 32) with a filter count that is not a multiple of 64 (start_filter = 16 models: 16 -> 16, 16 -> 32), no mask:
+    // 16 channels x 32 filters per block -- exact on the channel side, padded to 32 filters at most
+    if (g.Cq % 32 != 0 && !g.has_mask)
+        return k5 ? run_wgrad16_band<T, 2, 5, 1, true>(xp, dp, yp, dw, dbias, g, stream) : run_wgrad16_band<T, 2, 3, 1, true>(xp, dp, yp, dw, dbias, g, stream);
     return k5 ? run_wgrad16_band<T, 4, 5>(xp, dp, yp, dw, dbias, g, stream) : run_wgrad16_band<T, 4, 3>(xp, dp, yp, dw, dbias, g, stream);
 }
 

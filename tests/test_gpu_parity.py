@@ -141,6 +141,10 @@ ORACLE_CASES = [
     # round 5: channel counts that are multiples of 16 but not of 32 (start_filter = 16 models) -- the PAD forms of the 16-bit band
     # kernels (re-laid-out kernel zero-padded to 32, out-of-range DMA lanes, unstored output pieces): 16 -> 16, 16 -> 32, a
     # 48-channel layer whose second chunk is half real, a 1-D three-tap layer, and a relu layer (masked backward: fp32-MFMA forms)
+    # (three inner taps, 64-filter blocks, no mask: four dY planes on six staging slots -- the first schedule of round 5 left the
+    #  fourth plane out and no case saw it)
+    ('conv2d_32to64_3tap_linear', 2, (1, 9, 70, 128), (3, 3, 32, 256), dict(padding='same', activation=None)),
+    ('conv1d_16to64_3tap_linear', 1, (3, 150, 64), (3, 16, 256), dict(padding='same', activation=None)),
     ('conv2d_16to16_5tap', 2, (2, 6, 80, 64), (3, 5, 16, 64), dict(padding='same', activation=None)),
     ('conv2d_16to16_5tap_relu', 2, (2, 6, 80, 64), (3, 5, 16, 64), dict(padding='same', activation='relu')),
     ('conv2d_16to32_3tap', 2, (2, 5, 75, 64), (3, 3, 16, 128), dict(padding='same', activation=None)),
@@ -185,7 +189,7 @@ HALF_CASES = [c for c in ORACLE_CASES if c[0] in (
     'conv2d_chfirst_body_small',
     'conv2d_first_layer', 'dense_timit_head', 'dense_point_64', 'dense_point_32to128', 'conv2d_head_valid_conj', 'conv1d_1x1_64', 'conv3d_32ch', 'conv2d_32ch_outer_stride_dil', 'conv2d_64ch_valid_wide',
     'conv2d_cq16_f64_5tap_relu', 'conv2d_cq16_f64_5tap_linear',
-    'conv2d_16to16_5tap', 'conv2d_16to16_5tap_relu', 'conv2d_16to32_3tap', 'conv2d_48to16_5tap', 'conv1d_16to48_valid')]
+    'conv2d_32to64_3tap_linear', 'conv1d_16to64_3tap_linear', 'conv2d_16to16_5tap', 'conv2d_16to16_5tap_relu', 'conv2d_16to32_3tap', 'conv2d_48to16_5tap', 'conv1d_16to48_valid')]
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16], ids=['bf16', 'fp16'])
