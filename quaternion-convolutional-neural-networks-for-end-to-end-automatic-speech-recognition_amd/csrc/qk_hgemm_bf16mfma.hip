@@ -970,7 +970,8 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
 //     and the registers of a fragment are refilled for the NEXT unit as soon as its last MFMA has issued, so the
 //     loads of unit u + 1 fly under the MFMAs and the epilogue of unit u -- no barrier in steady state, the two
 //     waves of a SIMD drift apart and overlap each other's epilogue;
-//   * epilogue as in k_hgemm16 (per-wave LDS transpose, 16-byte stores), optional bias / relu / epilogue mask.
+//   * epilogue as in k_hgemm16_band (operands swapped: transposed accumulator, v_permlane32_swap, 16-byte stores, no LDS),
+//     optional bias / relu / epilogue mask / post-op.
 // HBM-bound by construction: the head backward-data writes 367 MB for 94 GFLOP.
 // ---------------------------------------------------------------------------------------
 template <typename T, int NKC, bool EPM>
@@ -983,8 +984,7 @@ k_hgemm16_point(const T *__restrict__ in, const uint4 *__restrict__ wq, const fl
     constexpr int NF = 2 * NKC;                      // 16-channel K slices per component
     constexpr int B_U = NKC * 16 * BF;               // 16-byte units of one (tap, column block) kernel slice
     constexpr unsigned TBL = kSignConj;              // go16 folds the plain table into the kernel
-    constexpr int EP_PITCH = 80;
-    __shared__ __attribute__((aligned(16))) uint4 lds[B_U + 4 * BF / 4 + 8 * 32 * EP_PITCH / 16 + 64];   // kernel slice, its bias (4 x BF floats), transpose patches, 256 d-alpha sums
+    __shared__ __attribute__((aligned(16))) uint4 lds[B_U + 4 * BF / 4 + 64];   // kernel slice, its bias (4 x BF floats), 256 d-alpha sums
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1026,12 +1026,10 @@ k_hgemm16_point(const T *__restrict__ in, const uint4 *__restrict__ wq, const fl
     const bool post_on = EPM && g.post.kind != 0;
     const bool post_fwd_relu = !EPM && g.post.kind == 2 && g.post_fwd != 0;
     const PostOp psd = resolve_seed(g.post);
-    float *aslab = reinterpret_cast<float *>(lds + B_U + BF + 8 * 32 * EP_PITCH / 16);
+    float *aslab = reinterpret_cast<float *>(lds + B_U + BF);
     if (post_on && g.dalpha && tid < 256) aslab[tid] = 0.f;      // (the first unit's slice load brings the barrier)
     const uint4 *w_rd = lds + wn * 32 + lr;
-    const float *bias_rd = reinterpret_cast<const float *>(lds + B_U) + wn * 32 + lr;
-    char *ep = reinterpret_cast<char *>(lds + B_U + BF) + wave * (32 * EP_PITCH);
-    const int e_row = lane >> 2, e_chunk = lane & 3;
+    const float *bias_q = reinterpret_cast<const float *>(lds + B_U) + wn * 32 + lh * 4;       // + b BF + 8 g: four channels of this lane
     // Stores and mask loads go through buffer resources, rows past the end get an out-of-range offset: no branch
     // around them.
     const __amdgpu_buffer_rsrc_t rout = make_rsrc16(out, out_bytes);
@@ -1053,20 +1051,24 @@ k_hgemm16_point(const T *__restrict__ in, const uint4 *__restrict__ wq, const fl
             __syncthreads();
             cur_slice = slice;
         }
-        // rows this lane stores (two passes of 16): byte offsets of their component-0 pieces
-        unsigned o_off[2];
-        int a_key[2] = {0, 0};
-        float a_val[2] = {0.f, 0.f}, dal[2] = {0.f, 0.f};
-#pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
-            const int r = tile * BM + wm * 32 + e_row + 16 * pass;
+        // Round 5: the kernel fragment is the MFMA's A operand, the activation fragment its B operand (both hold 8 consecutive K
+        // values of line `lr`: the roles swap for free), as in k_hgemm16_band -- the accumulator comes out TRANSPOSED: lane = output
+        // row lr of the wave tile, register r = channel (r & 3) + 8 (r >> 2) + 4 lh of the wave's 32-channel block.  The epilogue
+        // then needs no trip through LDS (it was 32 two-byte LDS writes + 2 reads + their address VALU per component: the kernel
+        // issued ~2000 instructions per wave and unit around 64 MFMAs and was instruction-issue bound, not HBM-bound), the relu
+        // form's 1 / (1 - rate) is applied to the fp32 values and its mask to packed pairs.
+        unsigned o_off;                                  // byte offset of this lane's row, component 0, channel jb BF + wn 32 + lh 8
+        int a_key = 0;
+        float a_val = 0.f, dal = 0.f;
+        {
+            const int r = tile * BM + wm * 32 + lr;
             const int n = fastdiv(r, g.dv_mul[2], g.dv_shr[2]), sp = r - n * S;
-            const unsigned o = (unsigned)(((n * T_ + tap) * S + sp) * (int)g.out_ss + jb * BF + wn * 32 + e_chunk * 8) * 2u;
-            o_off[pass] = r < R ? o : kOutOfRange16;
+            const unsigned o = (unsigned)(((n * T_ + tap) * S + sp) * (int)g.out_ss + jb * BF + wn * 32 + lh * 8) * 2u;
+            o_off = r < R ? o : kOutOfRange16;
             if (post_on) {
                 const int o1 = fastdiv(sp, g.dv_mul[0], g.dv_shr[0]);
-                a_key[pass] = g.post.alpha_sel < 0 ? 0 : g.post.alpha_sel == 0 ? tap : g.post.alpha_sel == 1 ? o1 : sp - o1 * g.osp[2];
-                a_val[pass] = g.post.alpha ? g.post.alpha[a_key[pass]] : 0.f;
+                a_key = g.post.alpha_sel < 0 ? 0 : g.post.alpha_sel == 0 ? tap : g.post.alpha_sel == 1 ? o1 : sp - o1 * g.osp[2];
+                a_val = g.post.alpha ? g.post.alpha[a_key] : 0.f;
             }
         }
         // next unit's rows (same rows when only the tap changes); past the range: nothing is fetched
@@ -1079,7 +1081,7 @@ k_hgemm16_point(const T *__restrict__ in, const uint4 *__restrict__ wq, const fl
 #pragma unroll
             for (int b = 0; b < 4; ++b)
 #pragma unroll
-                for (int pass = 0; pass < 2; ++pass) em[b][pass] = buf_load16b(rmask, o_off[pass], (unsigned)(b * g.J) * 2u);
+                for (int q = 0; q < 2; ++q) em[b][q] = buf_load16b(rmask, (g.ablate & 16) ? kOutOfRange16 : o_off, (unsigned)(b * g.J + q * 16) * 2u);
         }
         floatx16 acc[4], accn[4];
 #pragma unroll
@@ -1101,44 +1103,55 @@ k_hgemm16_point(const T *__restrict__ in, const uint4 *__restrict__ wq, const fl
                     floatx16 zero;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) zero[r] = 0.f;
-                    if (ng) accn[b] = mfma16(T(), A[a][f], W[a ^ b], first ? zero : accn[b]);
-                    else acc[b] = mfma16(T(), A[a][f], W[a ^ b], first ? zero : acc[b]);
+                    if (g.ablate & 4) { if (first) { if (ng) accn[b] = zero; else acc[b] = zero; } }       // (profiling: no MFMAs)
+                    else if (ng) accn[b] = mfma16(T(), W[a ^ b], A[a][f], first ? zero : accn[b]);
+                    else acc[b] = mfma16(T(), W[a ^ b], A[a][f], first ? zero : acc[b]);
                 }
-                load_frag(vnext, a, f);               // this fragment's registers are free: fetch the next unit's
+                if (!(g.ablate & 32)) load_frag(vnext, a, f);               // this fragment's registers are free: fetch the next unit's
             }
         }
-        // ---- epilogue as in k_hgemm16: per-wave LDS transpose, 16-byte stores -------------------------------
+        // ---- epilogue: a lane owns row lr and, per component, channels 8 g + 4 lh + (0..3), g = 0..3; one v_permlane32_swap per
+        //      packed dword pairs the lh halves into 16-byte pieces (channels 16 q + 8 lh .. + 7), two stores per component
+        const bool relu_bwd = EPM && post_on && g.post.kind == 2;          // d pre = dy / (1 - rate) where y > 0
+        const float pscale = relu_bwd ? g.post.drop_scale : 1.f;
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             constexpr unsigned tbl = TBL;
             constexpr unsigned col_neg = (tbl >> 0 | tbl >> 4 | tbl >> 8 | tbl >> 12) & 0xfu;   // columns with negative entries
-            const float bia = g.has_bias ? bias_rd[b * BF] : 0.f;
+            unsigned pk[4][2];
 #pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                float v0 = acc[b][r] + bia, v1 = acc[b][r + 1] + bia;
-                if ((col_neg >> b) & 1u) { v0 -= accn[b][r]; v1 -= accn[b][r + 1]; }
-                if (g.relu) { v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f; }
-                const unsigned pk = pack2(T(), v0, v1);
-                char *dst = ep + mfma32_row(r, lane) * EP_PITCH + lr * 2;
-                *reinterpret_cast<unsigned short *>(dst) = (unsigned short)pk;
-                *reinterpret_cast<unsigned short *>(dst + EP_PITCH) = (unsigned short)(pk >> 16);
-            }
+            for (int gq = 0; gq < 4; ++gq) {
+                float v[4];
+                float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (g.has_bias) bb = *reinterpret_cast<const float4 *>(bias_q + b * BF + 8 * gq);
+                const float bv[4] = {bb.x, bb.y, bb.z, bb.w};
 #pragma unroll
-            for (int pass = 0; pass < 2; ++pass) {
-                uint4 v = *reinterpret_cast<const uint4 *>(ep + (e_row + 16 * pass) * EP_PITCH + e_chunk * 16);
-                if constexpr (EPM) {
-                    if (post_on) v = post_bwd8<T>(v, em[b][pass], a_val[pass], o_off[pass] / 2u + (unsigned)(b * g.J), psd, dal[pass]);
-                    else v = mask8(v, em[b][pass]);
-                } else {
-                    if (post_fwd_relu) v = post_fwd8<T>(v, 0.f, o_off[pass] / 2u + (unsigned)(b * g.J), psd);     // y = dropout(relu(pre))
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = acc[b][4 * gq + e] + bv[e];
+                    if ((col_neg >> b) & 1u) v[e] -= accn[b][4 * gq + e];
+                    if (g.relu) v[e] = v[e] > 0.f ? v[e] : 0.f;
+                    if (EPM) v[e] *= pscale;
                 }
-                buf_store16b(rout, o_off[pass], (unsigned)(b * g.J) * 2u, v);
+                pk[gq][0] = pack2(T(), v[0], v[1]);
+                pk[gq][1] = pack2(T(), v[2], v[3]);
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const auto s0 = __builtin_amdgcn_permlane32_swap(pk[2 * q][0], pk[2 * q + 1][0], false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(pk[2 * q][1], pk[2 * q + 1][1], false, false);
+                uint4 v = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                const unsigned soff = (unsigned)(b * g.J + q * 16) * 2u;
+                if constexpr (EPM) {
+                    if (relu_bwd) v = mask8(v, em[b][q]);
+                    else if (post_on) v = post_bwd8<T>(v, em[b][q], a_val, (o_off + soff) / 2u, psd, dal);
+                    else v = mask8(v, em[b][q]);
+                } else {
+                    if (post_fwd_relu) v = post_fwd8<T>(v, 0.f, (o_off + soff) / 2u, psd);     // y = dropout(relu(pre))
+                }
+                buf_store16b(rout, (g.ablate & 8) ? kOutOfRange16 : o_off, soff, v);
             }
         }
-        if (post_on && g.dalpha) {
-            wave_add_by_key(dal[0], a_key[0], aslab, lane);
-            wave_add_by_key(dal[1], a_key[1], aslab, lane);
-        }
+        if (post_on && g.dalpha) wave_add_by_key(dal, a_key, aslab, lane);
     }
     if (post_on && g.dalpha) {                            // one global atomic per slope and workgroup
         __syncthreads();

@@ -436,3 +436,35 @@ def test_full_b256_bf16_model_in_the_bench_form_meets_the_oracle_at_sampled_fram
         worst = max(worst, err)
         assert err <= 6e-2, 'sample %d frame %d: posterior off by %.3g of its maximum' % (n, t, err)
     print('full-size model vs windowed oracle composition: worst relative error %.3g' % worst)
+
+
+@pytest.mark.gpu
+def test_start_filter_16_model_runs_on_the_matrix_cores_and_matches_its_fp32_run():
+    """interspeech_model.py:46-50: start_filter = 16 -- a first layer with 16 filters (fused kernels on the kernel zero-padded to
+    32), 16 -> 16 and 16 -> 32 body layers (PAD forms of the band kernels, 16 x 32 backward-weight blocks).  bf16 forward against
+    the float64 composition on 16-bit storage; every gradient against the same model run in float32 (whose kernels meet the
+    oracle to 1e-4 elsewhere) in the 2-norm -- single elements differ by whole terms where a bf16 pre-activation rounds across 0."""
+    from qcnn_amd import _lib
+    dev = _dev()
+    model, xt, dpred = _build(dev, torch.float32, 16, 4, 'none', 2, 24, seed=41, fuse_head=True, chain_convs=True)
+    dp = torch.tensor(dpred, device=dev, dtype=torch.float32)
+
+    def run(x):
+        for p in model.parameters():
+            p.grad = None
+        pred = model(x)
+        (pred.float() * dp).sum().backward()
+        return pred.detach().float().cpu().numpy(), {n: p.grad.double().cpu().numpy() for n, p in model.named_parameters() if p.grad is not None}
+    p32, g32 = run(xt)
+    x16 = xt.to(torch.bfloat16)
+    p16, g16 = run(x16)
+    assert _lib.last_path().startswith('mfma16'), _lib.last_path()
+    rnd = _round_fn(torch.bfloat16)
+    want = TimitRef(model, act='relu', rnd=rnd, rnd_w=rnd).forward(x16.detach().cpu().double().numpy())
+    assert _rel(p16, want) <= 2e-2
+    assert _rel(p16, p32) <= 5e-2
+    for k, w in g32.items():
+        nw = np.linalg.norm(w)
+        if nw > 0:
+            e = np.linalg.norm(g16[k] - w) / nw
+            assert e <= 0.15, '%s: bf16 gradient off by %.3g (2-norm) from the float32 run' % (k, e)
