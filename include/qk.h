@@ -136,6 +136,9 @@ const char *qk_last_error(void);
                                          * order-dependent float sums.  Several times slower (the reduction over positions is
                                          * no longer spread over the CUs): for debugging and for repeatability tests. */
 #define QK_DBG_WGRAD_BAND_V1 0x20000u /* 16-bit backward-weight band kernel in its round-2..4 form (register staging, two tile buffers; env QK_WGRAD_BAND_V1) -- A/B */
+#define QK_DBG_NO_SMALL16 0x40000u /* 16-bit layers with 16 / 32 channels per component on the zero-padded band kernels instead of k_hconv16_small
+                                     * (env QK_NO_SMALL16; A/B).  The two forms cache DIFFERENT 16-bit kernel layouts: toggle it at run time only
+                                     * together with dropping the caches (qcnn_amd.invalidate_cached_kernels()) */
 #define QK_DBG_BAND16_8WAVES 16u   /* 16-bit band kernels: 8-wave workgroups (one per CU) instead of 4-wave (two per CU) */
 unsigned qk_set_debug_flags(unsigned flags);
 /* Profiling only: a device buffer (64 bytes per workgroup, 65536 workgroups) into which the 16-bit band kernels drop shader-clock time stamps of their
@@ -146,7 +149,7 @@ unsigned qk_get_debug_flags(void);
 /* Which kernel family served the most recent qk_* compute call of the calling thread (thread-local, like
  * qk_last_error): lets a caller see when a shape fell off the 16-bit matrix-core fast path. */
 typedef enum { QK_PATH_NONE = 0, QK_PATH_MFMA16 = 1, QK_PATH_MFMA16_BAND = 2, QK_PATH_FP32_MFMA = 3,
-               QK_PATH_MFMA16_POINT = 4 } qk_path_t;
+               QK_PATH_MFMA16_POINT = 4, QK_PATH_MFMA16_SMALL = 5 /* k_hconv16_small: 16 / 32 channels per component */ } qk_path_t;
 int qk_last_path(void);
 
 /* Per-call timing for benchmarks.  While enabled, every forward / backward-data / backward-weight call (including the

@@ -21,8 +21,9 @@ QK_DBG_NO_POINT16 = 64
 QK_DBG_CTC_TWO_SWEEPS = 128
 QK_DBG_DETERMINISTIC = 0x10000
 QK_DBG_WGRAD_BAND_V1 = 0x20000
+QK_DBG_NO_SMALL16 = 0x40000
 QK_ERR_INVALID_ARG, QK_ERR_UNSUPPORTED, QK_ERR_WORKSPACE, QK_ERR_LAUNCH = -1, -2, -3, -4
-QK_PATH_NAMES = {0: 'none', 1: 'mfma16', 2: 'mfma16_band', 3: 'fp32_mfma', 4: 'mfma16_point'}               # qk_last_path
+QK_PATH_NAMES = {0: 'none', 1: 'mfma16', 2: 'mfma16_band', 3: 'fp32_mfma', 4: 'mfma16_point', 5: 'mfma16_small'}               # qk_last_path
 
 I32 = ctypes.c_int32
 

@@ -31,6 +31,7 @@ unsigned env_flags()
     if (getenv("QK_CTC_TWO_SWEEPS")) f |= kDbgCtcTwoSweeps;
     if (getenv("QK_DETERMINISTIC")) f |= kDbgDeterministic;
     if (getenv("QK_WGRAD_BAND_V1")) f |= kDbgWgradBandV1;
+    if (getenv("QK_NO_SMALL16")) f |= kDbgNoSmall16;
     if (const char *ab = getenv("QK_ABLATE")) f |= ((unsigned)atoi(ab) << kDbgAblateShift) & kDbgAblateMask;
     return f;
 }
@@ -331,6 +332,36 @@ size_t ws_bytes_impl(const qk_conv_desc_t *d, int op)
     }
     if (op == QK_OP_BWD && d->activation == QK_ACT_RELU) n = (n + 255) / 256 * 256 + dy_bytes(d);
     return n;
+}
+
+// The geometry fields small16_shape / band_geom look at, filled as conv_fwd_impl / conv_bwd_data_impl fill them (channels_last)
+void prep_geom(const qk_conv_desc_t *d, bool bwd, GemmGeom *gp)
+{
+    GemmGeom &g = *gp;
+    memset(&g, 0, sizeof(g));
+    const Strides xs = act_strides(d->in_spatial, 4 * d->cq, d->layout);
+    const Strides ys = act_strides(d->out_spatial, 4 * d->fq, d->layout);
+    g.batch = d->batch;
+    g.taps = taps_of(d);
+    if (!bwd) {
+        g.M = d->batch * d->out_spatial[0] * d->out_spatial[1] * d->out_spatial[2];
+        g.Q = d->cq; g.J = d->fq;
+        for (int i = 0; i < 3; ++i) {
+            g.osp[i] = d->out_spatial[i]; g.isp[i] = d->in_spatial[i]; g.ks[i] = d->kernel[i];
+            g.pa[i] = d->stride[i]; g.pb[i] = d->dilation[i]; g.pc[i] = -d->pad_lo[i]; g.pd[i] = 1;
+            g.in_ss[i] = xs.ss[i];
+        }
+        g.in_sn = xs.sn; g.in_sc = xs.sc; g.out_sn = ys.sn; g.out_ss = ys.flat_ss; g.out_sc = ys.sc;
+    } else {
+        g.M = d->batch * d->in_spatial[0] * d->in_spatial[1] * d->in_spatial[2];
+        g.Q = d->fq; g.J = d->cq;
+        for (int i = 0; i < 3; ++i) {
+            g.osp[i] = d->in_spatial[i]; g.isp[i] = d->out_spatial[i]; g.ks[i] = d->kernel[i];
+            g.pa[i] = 1; g.pb[i] = -d->dilation[i]; g.pc[i] = d->pad_lo[i]; g.pd[i] = d->stride[i];
+            g.in_ss[i] = ys.ss[i];
+        }
+        g.in_sn = ys.sn; g.in_sc = ys.sc; g.out_sn = xs.sn; g.out_ss = xs.flat_ss; g.out_sc = xs.sc;
+    }
 }
 
 int conv_fwd_impl(const qk_conv_desc_t *d, const void *x, const float *w, const float *bias, void *y,
@@ -1054,6 +1085,13 @@ int qk_conv_prep_kernels(int32_t n, const qk_conv_desc_t *const *descs, const in
                 PrepJob &j = jobs.j[m++];
                 j.w = w[i]; j.wq = workspaces[i]; j.taps = taps_of(d); j.cq = d->cq; j.fq = d->fq;
                 j.transposed = bwd ? 1 : 0;
+                {   // 16 / 32-channel layers: the layout of k_hconv16_small, decided by the shape alone exactly as go16 decides it
+                    GemmGeom sg, sbg;
+                    Small16 sm;
+                    prep_geom(d, bwd, &sg);
+                    j.small = (d->layout == QK_CH_LAST && small16_shape(sg, &sbg, &sm)) ? 1 : 0;
+                    j.kin = j.small ? sm.kin : 0; j.n_ot = j.small ? sm.n_ot : 0;
+                }
                 j.neg_ijk = bwd ? (d->conj ? 1 : 0) : (d->conj ? 0 : 1);       // the sign table go16 folds into the kernel
             }
             if (m == 32 || (i == n && m > 0)) {

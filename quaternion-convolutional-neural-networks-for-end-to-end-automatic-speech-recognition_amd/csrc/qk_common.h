@@ -157,6 +157,25 @@ __device__ __forceinline__ int fastdiv(int n, unsigned mul, unsigned shr)
     return (int)((q & ~id) | ((unsigned)n & id));
 }
 
+// Bit (t0 * ks1 + t1) set iff outer tap (t0, t1) of a row whose tap-0 input coordinates are (q0, q1) falls inside the tensor.
+// With dilation +-1 on both outer axes the valid taps of an axis are a RANGE, so the mask is a product of two bit ranges --
+// no loop, no branch (the loops with their run-time trip counts were ~40 taken branches per wave in the band kernel's prologue,
+// which is instruction-issue bound: tools/probe/phase_stamps.py).  `rep` = sum over t0 of 2^(t0 * ks1) (host: GemmGeom::b_rep).
+__device__ __forceinline__ unsigned outer_tap_mask(int q0, int q1, const GemmGeom &g)
+{
+    // input coordinate q + pb t with pb = +1 (forward) or -1 (backward-data) -- band_geom admits nothing else on the outer axes.
+    // pb = -1 is pb = +1 on the mirrored coordinate isp - 1 - q: ONE multiply-add by wave-uniform values instead of selects on a
+    // uniform condition (which hipcc compiles to scalar branches); taps [lo, hi) are then inside [0, extent).
+    const int m0 = q0 * g.pb[0] + (g.pb[0] > 0 ? 0 : g.isp[0] - 1), m1q = q1 * g.pb[1] + (g.pb[1] > 0 ? 0 : g.isp[1] - 1);
+    const int lo0 = max(0, -m0), hi0 = min(g.ks[0], g.isp[0] - m0);
+    const int lo1 = max(0, -m1q), hi1 = min(g.ks[1], g.isp[1] - m1q);
+    const unsigned m1 = ((hi1 >= 32 ? 0u : (1u << hi1)) - 1u) & ~((1u << lo1) - 1u);
+    const int b0 = lo0 * g.ks[1], e0 = hi0 * g.ks[1];
+    const unsigned r0 = ((e0 >= 32 ? 0u : (1u << e0)) - 1u) & ~((1u << b0) - 1u);
+    return (lo0 >= hi0 || lo1 >= hi1) ? 0u : (m1 * g.b_rep) & r0;
+}
+
+
 struct WgradGeom {
     int M;
     int batch;
@@ -226,6 +245,37 @@ __device__ __forceinline__ void load4(const f16 *p, float (&o)[4])
     o[0] = (float)v[0]; o[1] = (float)v[1]; o[2] = (float)v[2]; o[3] = (float)v[3];
 }
 
+// One element of the k_hconv16_small kernel layout (qk_hconv16_small.hip): [K step kk = outer tap x KSO + i][part p][16-filter block fb]
+// [lane 64][8] -- exactly the A-operand fragments of v_mfma_f32_16x16x32 (lane: filter row lane & 15 of the block, K values
+// 8 (lane >> 4) .. + 7 of the step), so a wave reads a fragment with ONE linear ds_read_b128.  A K step holds 32 gathered channels of
+// ONE inner tap (Q = 32) or 16 channels of TWO inner taps (Q = 16; the odd tap out of 3 / 5 pairs with a zero phantom).
+// Same sign fold / transposition conventions as k_prep_w16.
+template <typename T>
+__device__ __forceinline__ void prep_small16_write(const float *w, T *wq, long long idx, int Cq, int F, int transposed, int neg_ijk,
+                                                   int kin, int q32, int fb_n)
+{
+    const int kso = q32 ? kin : (kin + 1) / 2;
+    long long r = idx;
+    const int e = (int)(r % 8); r /= 8;
+    const int lane = (int)(r % 64); r /= 64;
+    const int fb = (int)(r % fb_n); r /= fb_n;
+    const int p = (int)(r % 4); r /= 4;
+    const int kk = (int)r;
+    const int k = (lane >> 4) * 8 + e;
+    const int ot = kk / kso, ki = kk - ot * kso;
+    const int tap_in = q32 ? ki : 2 * ki + (k >> 4);
+    const int q = q32 ? k : (k & 15);
+    const int j = fb * 16 + (lane & 15);
+    float v = 0.f;
+    if (tap_in < kin) {
+        const int tap = ot * kin + tap_in;
+        const int c = transposed ? j : q, f = transposed ? q : j;
+        v = w[((long long)(tap * Cq + c) * 4 + p) * F + f];
+        if (neg_ijk && p) v = -v;
+    }
+    wq[idx] = from_f32<T>(v);
+}
+
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
@@ -244,9 +294,32 @@ int launch_wgrad(int dtype, const void *x, const void *dy, const void *ymask, fl
 int launch_fold_taps(int dtype, const void *x, void *xcol, const GemmGeom &g, int cq2, hipStream_t stream);
 int launch_mask_gt0(int dtype, void *data, const void *mask, size_t n, hipStream_t stream);   // data *= (mask > 0)
 // batched 16-bit re-layout of compact kernels (qk_conv_prep_kernels): up to 32 jobs per launch, passed by value
-struct PrepJob { const float *w; void *wq; int taps, cq, fq, transposed, neg_ijk; };
+struct PrepJob { const float *w; void *wq; int taps, cq, fq, transposed, neg_ijk;
+                 int small, kin, n_ot; };      // small != 0: the fragment layout of k_hconv16_small (qk_hconv16_small.hip) -- kin inner taps, n_ot outer taps
 struct PrepJobs { PrepJob j[32]; };
 int launch_prep_w16_batch(int dtype, const PrepJobs &jobs, int n, hipStream_t stream);
+// Small-channel 16-bit layers (Q, J in {16, 32}, not both 32: start_filter = 16 models) -- qk_hconv16_small.hip.
+// small16_shape: pure geometry (what decides the LAYOUT of the cached 16-bit kernel: qk_conv_prep_kernels and the call agree by
+// construction); *bg receives the band geometry.
+struct Small16 { int q32, fb, kin, kso, n_ot, nkk; unsigned w_bytes; };
+inline bool small16_shape(const GemmGeom &g_in, GemmGeom *bg, Small16 *s)
+{
+    // (Q, J) = (16, 16) and (32, 16).  (16, 32) -- two 16-filter blocks per wave, one workgroup per CU -- measured SLOWER than the band
+    // kernel's PAD form (16 -> 32 forward at B = 256: 205 vs 171 - 199 us) and stays there; the kernel's FB = 2 instantiations remain
+    // for the day its staging runs deeper
+    if (!((g_in.Q == 16 || g_in.Q == 32) && g_in.J == 16)) return false;
+    GemmGeom g = g_in;
+    g.Qp = pad32(g.Q); g.Jp = pad32(g.J);
+    if (!band_geom(g, 2, bg)) return false;           // 3 / 5 unit-stride inner taps, no relu mask on the gathered tensor, <= 32 outer taps ...
+    s->q32 = g.Q == 32; s->fb = g.J / 16; s->kin = bg->ks[2]; s->n_ot = bg->ks[0] * bg->ks[1];
+    s->kso = s->q32 ? s->kin : (s->kin + 1) / 2;
+    s->nkk = s->n_ot * s->kso;
+    s->w_bytes = (unsigned)(s->nkk * 4 * s->fb * 1024);
+    return s->n_ot <= 3;                               // the whole kernel is resident in LDS (static: three outer taps) beside two band buffers
+}
+int launch_prep_small16(int dtype, const float *w, void *wq, int Cq, int F, int transposed, int neg_ijk, const Small16 &s, hipStream_t stream);
+int launch_hconv16_small(int dtype, const void *in, const void *wq, const float *bias, void *out, const GemmGeom &bg, const Small16 &s, hipStream_t stream);
+
 size_t ctc_workspace_bytes(int B, int T, int Lmax);
 int launch_ctc(int dtype, int B, int T, int C, const void *pred, const int *labels, int Lmax, const int *in_len, const int *lab_len,
                float *cost, void *dpred, float *ws, hipStream_t stream);
@@ -276,7 +349,7 @@ void note_path(int qk_path);          // thread-local record behind qk_last_path
 enum : unsigned {
     kDbgNoMfma16 = QK_DBG_NO_MFMA16, kDbgNoBand16 = QK_DBG_NO_BAND16, kDbgNoBand32 = QK_DBG_NO_BAND32,
     kDbgWgradOneTap = QK_DBG_WGRAD16_ONE_TAP, kDbgBand8Waves = QK_DBG_BAND16_8WAVES, kDbgNoWgradBand = QK_DBG_NO_WGRAD_BAND,
-    kDbgNoPoint16 = QK_DBG_NO_POINT16, kDbgCtcTwoSweeps = QK_DBG_CTC_TWO_SWEEPS, kDbgDeterministic = QK_DBG_DETERMINISTIC, kDbgWgradBandV1 = QK_DBG_WGRAD_BAND_V1, kDbgAblateShift = 8, kDbgAblateMask = 0xffu << 8
+    kDbgNoPoint16 = QK_DBG_NO_POINT16, kDbgCtcTwoSweeps = QK_DBG_CTC_TWO_SWEEPS, kDbgDeterministic = QK_DBG_DETERMINISTIC, kDbgWgradBandV1 = QK_DBG_WGRAD_BAND_V1, kDbgNoSmall16 = QK_DBG_NO_SMALL16, kDbgAblateShift = 8, kDbgAblateMask = 0xffu << 8
 };
 unsigned debug_flags();
 unsigned long long *debug_buffer(size_t *bytes);      // qk_set_debug_buffer (qk_api.hip)

@@ -23,6 +23,7 @@
 // (issue-only loads with clamped addresses; zero fill and the relu mask are applied at LDS-store time).
 #include "qk_common.h"
 #include "qk_postop.h"
+#include <type_traits>
 
 namespace qk {
 namespace {
@@ -113,6 +114,15 @@ k_prep_w16_batch(const PrepJobs jobs)
     const float *__restrict__ w = jb.w;
     T *__restrict__ wq = static_cast<T *>(jb.wq);
     const int Cq = jb.cq, F = jb.fq, transposed = jb.transposed, neg_ijk = jb.neg_ijk;
+    if (jb.small) {                                   // the fragment layout of k_hconv16_small (qk_hconv16_small.hip)
+        const int Qs = transposed ? F : Cq, Js = transposed ? Cq : F;
+        const int q32 = Qs == 32, fb_n = Js / 16, kso = q32 ? jb.kin : (jb.kin + 1) / 2;
+        const long long tot = (long long)jb.n_ot * kso * 4 * fb_n * 512;
+        for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < tot; idx += (long long)gridDim.x * 256)
+            prep_small16_write<T>(w, wq, idx, Cq, F, transposed, neg_ijk, jb.kin, q32, fb_n);
+        if (blockIdx.x == 0 && threadIdx.x < 128) wq[tot + threadIdx.x] = from_f32<T>(0.f);
+        return;
+    }
     const int Qr = transposed ? F : Cq, Jr = transposed ? Cq : F;
     const int Q = (Qr + 31) / 32 * 32, J = (Jr + 31) / 32 * 32;                  // (zero-padded to the 32-channel granule, see k_prep_w16)
     const long long total = (long long)jb.taps * Q * 4 * J;
@@ -528,24 +538,7 @@ __device__ __forceinline__ void buf_store16b(__amdgpu_buffer_rsrc_t r, unsigned 
     __builtin_amdgcn_raw_buffer_store_b128(d, r, (int)(voff + soff), 0, 0);
 }
 
-// Bit (t0 * ks1 + t1) set iff outer tap (t0, t1) of a row whose tap-0 input coordinates are (q0, q1) falls inside the tensor.
-// With dilation +-1 on both outer axes the valid taps of an axis are a RANGE, so the mask is a product of two bit ranges --
-// no loop, no branch (the loops with their run-time trip counts were ~40 taken branches per wave in the band kernel's prologue,
-// which is instruction-issue bound: tools/probe/phase_stamps.py).  `rep` = sum over t0 of 2^(t0 * ks1) (host: GemmGeom::b_rep).
-__device__ __forceinline__ unsigned outer_tap_mask(int q0, int q1, const GemmGeom &g)
-{
-    // input coordinate q + pb t with pb = +1 (forward) or -1 (backward-data) -- band_geom admits nothing else on the outer axes.
-    // pb = -1 is pb = +1 on the mirrored coordinate isp - 1 - q: ONE multiply-add by wave-uniform values instead of selects on a
-    // uniform condition (which hipcc compiles to scalar branches); taps [lo, hi) are then inside [0, extent).
-    const int m0 = q0 * g.pb[0] + (g.pb[0] > 0 ? 0 : g.isp[0] - 1), m1q = q1 * g.pb[1] + (g.pb[1] > 0 ? 0 : g.isp[1] - 1);
-    const int lo0 = max(0, -m0), hi0 = min(g.ks[0], g.isp[0] - m0);
-    const int lo1 = max(0, -m1q), hi1 = min(g.ks[1], g.isp[1] - m1q);
-    const unsigned m1 = ((hi1 >= 32 ? 0u : (1u << hi1)) - 1u) & ~((1u << lo1) - 1u);
-    const int b0 = lo0 * g.ks[1], e0 = hi0 * g.ks[1];
-    const unsigned r0 = ((e0 >= 32 ? 0u : (1u << e0)) - 1u) & ~((1u << b0) - 1u);
-    return (lo0 >= hi0 || lo1 >= hi1) ? 0u : (m1 * g.b_rep) & r0;
-}
-
+// (outer_tap_mask: qk_common.h)
 // A-band staging schedule of one group: op code q < R fetches row pass q of the NEXT band (an LDS-DMA into the other band buffer
 // since the end of round 4; through registers before), -1 = nothing.  Codes R <= q < 2R were the register form's LDS stores --
 // at least one sub-step after their loads -- and are no-ops now: the table still says WHEN a pass is asked for, which is what the
@@ -1263,6 +1256,30 @@ int go16(const void *in, const void *mask, const float *w, const float *bias, vo
     g.Qp = pad32(g.Q); g.Jp = pad32(g.J);
     const bool padded = g.Qp != g.Q || g.Jp != g.J;      // multiples of 16 only: the band kernel's PAD form or nothing (the caller goes on to the fp32-MFMA kernels)
     GemmGeom bg;
+    {
+        // 16 / 32 channels per component (start_filter = 16 models): the streaming small-channel kernel (qk_hconv16_small.hip).  The SHAPE
+        // alone decides the layout of the cached 16-bit kernel (qk_conv_prep_kernels asks the same small16_shape); a call the kernel
+        // does not take although the shape is its own -- PReLU post-ops, the diagnostic switch -- re-lays the kernel out for the band form.
+        Small16 sm;
+        if (small16_shape(g, &bg, &sm)) {
+            const bool post_ok = (g.post.kind == 0 || g.post.kind == 2) && !g.pre_out && !g.dalpha &&
+                                 (g.post.kind == 0 || g.post_fwd || g.ep_mask) && !(reinterpret_cast<uintptr_t>(out) & 7) &&
+                                 !(reinterpret_cast<uintptr_t>(g.ep_mask) & 7) && !(reinterpret_cast<uintptr_t>(bias) & 15);
+            if (post_ok && !(debug_flags() & kDbgNoSmall16)) {
+                fastdiv_of((unsigned)bg.b_wp, &bg.dv_mul[0], &bg.dv_shr[0]);
+                fastdiv_of((unsigned)bg.osp[1], &bg.dv_mul[1], &bg.dv_shr[1]);
+                fastdiv_of((unsigned)bg.osp[0], &bg.dv_mul[2], &bg.dv_shr[2]);
+                bg.sign_tbl = kSignConj;
+                bg.ablate = g.ablate;
+                if (!g.w_prepped) {
+                    if (int rc = launch_prep_small16(sizeof(T) == 2 && std::is_same<T, bf16>::value ? QK_BF16 : QK_F16, w, wq, Cq, F, transposed ? 1 : 0, neg_ijk ? 1 : 0, sm, stream)) return rc;
+                }
+                const int r = launch_hconv16_small(std::is_same<T, bf16>::value ? QK_BF16 : QK_F16, in, wq, bias, out, bg, sm, stream);
+                if (r != 0) { if (r > 0) note_path(QK_PATH_MFMA16_SMALL); return r; }
+            }
+            g.w_prepped = 0;                          // (the cache holds the small-channel layout: the band form below lays its own out)
+        }
+    }
     if (padded && ((debug_flags() & kDbgNoBand16) || !band_geom(g, 2, &bg))) return 0;
     const long long total = (long long)g.taps * g.Qp * 4 * g.Jp;
     int blocks = (int)((total + 255) / 256);

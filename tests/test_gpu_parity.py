@@ -230,7 +230,10 @@ def test_sixteen_channel_layers_run_on_the_matrix_cores(dtype):
         p_d = _lib.last_path()
         dw, db = call.bwd_weight(x, dy, None, True)
         p_w = _lib.last_path()
-        assert (p_f, p_d, p_w) == ('mfma16_band',) * 3, (cq, fq, p_f, p_d, p_w)
+        # forward / backward-data: the streaming small-channel kernel where both widths are 16 or 32 (k_hconv16_small), the PAD form of
+        # the band kernel elsewhere (48 channels); backward-weight: the LDS-DMA band kernel (16 x 32 blocks / PAD)
+        small = lambda q, j: 'mfma16_small' if (q in (16, 32) and j == 16) else 'mfma16_band'       # (gathered, produced) channels per component
+        assert (p_f, p_d, p_w) == (small(cq, fq), small(fq, cq), 'mfma16_band'), (cq, fq, p_f, p_d, p_w)
         with _lib.debug_flags(_lib.QK_DBG_NO_MFMA16):
             y0 = call.fwd(x, w, b)
             dx0 = call.bwd_data(dy, None, w)

@@ -12,6 +12,8 @@ from qcnn_amd import functional as F
 SHAPES = {
     'c64': dict(x=(256, 14, 200, 256), w=(3, 5, 64, 256), pad='same', conj=False),
     'c32': dict(x=(256, 14, 200, 128), w=(3, 5, 32, 128), pad='same', conj=False),
+    'c16': dict(x=(256, 14, 200, 64), w=(3, 5, 16, 64), pad='same', conj=False),
+    'c16to32': dict(x=(256, 14, 200, 64), w=(3, 5, 16, 128), pad='same', conj=False),
     'c32to64': dict(x=(256, 14, 200, 128), w=(3, 5, 32, 256), pad='same', conj=False),
     'head': dict(x=(256, 14, 200, 256), w=(14, 1, 64, 256), pad='valid', conj=True),
     'first': dict(x=(256, 41, 200, 128), w=(1, 1, 32, 128), pad='valid', conj=False),     # folded first layer (1x1, cq2=32)
