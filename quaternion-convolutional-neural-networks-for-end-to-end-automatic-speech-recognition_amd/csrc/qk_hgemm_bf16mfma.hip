@@ -543,6 +543,9 @@ __device__ __forceinline__ void buf_store16b(__amdgpu_buffer_rsrc_t r, unsigned 
 // since the end of round 4; through registers before), -1 = nothing.  Codes R <= q < 2R were the register form's LDS stores --
 // at least one sub-step after their loads -- and are no-ops now: the table still says WHEN a pass is asked for, which is what the
 // vmcnt counts in front of the barriers are computed from.
+#ifndef QK_BAND_PIPE
+#define QK_BAND_PIPE 1
+#endif
 constexpr int kBandOpsMax = 5;
 constexpr int band_op(int R, int K, int ti, int k);
 // row passes LOADED in sub-step ti of a group (op codes 0 .. R - 1), and whether the halo pass (R - 1) is among them: what the
@@ -789,6 +792,89 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
     const bool q_half = KSKIP && g.Qp != g.Q;
     int ckc = 0;                                    // channel chunk of the group being computed
     static_assert(KIN % 2 == 1, "parity of a group's first sub-step = parity of the group");
+    // PIPE (round 5, late): the fragment reads are software-pipelined IN PLACE.  Until now a half step (16 MFMAs) began with its 8
+    // ds_read_b128 and its first MFMA waited for five of them: ~100 - 130 cycles per 512 that only the OTHER workgroup of the CU could
+    // cover -- a workgroup running alone (its neighbour in prologue / epilogue: 31 % of the time by the phase stamps) ran at 62 %.
+    // Now the registers of a fragment are refilled for the NEXT half step right behind the fragment's last MFMA: A[a] behind row a
+    // (row a is its only user), the B fragments behind the MFMAs of row 3 in the order the next half step's row 0 consumes them.
+    // The sub-step's wait + barrier moves in front of row 3 of its second half: behind it the next B tile is in LDS and the B refills
+    // of the next sub-step's first half can be issued under the last four MFMAs (the A refills too where the next sub-step opens a
+    // new group: the other band object is complete behind this barrier, not earlier).  No extra registers, no lgkmcnt(0) drain at
+    // the barrier (everything this wave read from the buffers about to be overwritten has been consumed by MFMAs in front of it).
+    constexpr bool PIPE = (QK_BAND_PIPE != 0) && !PAD;
+    if constexpr (PIPE) {
+        const int tdir = g.b_rev ? -1 : 1;
+        const int arow_first = frow + (g.b_rev ? KIN - 1 : 0);
+        uint4 A[4], B[4];
+#define QK_LD_A(a_, BAND_, AROW_, KS_) A[a_] = (BAND_)[(AROW_) * 8 + ((a_) >> 1) * PL + ((((a_) & 1) * 4 + (KS_) * 2) ^ ((((AROW_) >> 1) & 7) ^ lh))]
+#define QK_LD_B(p_, BOBJ_, KS_) B[p_] = (BOBJ_)[b_rd0 + (((KS_) * 2 + lh) * 4 + (p_)) * BF]
+#pragma unroll
+        for (int a = 0; a < 4; ++a) QK_LD_A(a, ldsA0, arow_first, 0);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) QK_LD_B(p, ldsB0, 0);
+        for (int gi2 = (g.ablate & 4) ? groups : 0; gi2 < groups; gi2 += 2)
+#pragma unroll
+        for (int gh = 0; gh < 2; ++gh) {
+            const int gi = gi2 + gh;
+            if (gi >= groups) break;
+            const uint4 *band = gh ? ldsA1 : ldsA0;
+            const uint4 *nband = gh ? ldsA0 : ldsA1;
+            a_prep();
+#pragma unroll
+            for (int ti = 0; ti < KIN; ++ti, ++s) {
+                const int arow = arow_first + ti * tdir;
+                const int arow_n = arow + tdir;                        // (used where ti + 1 < KIN)
+                const int rdpar = (gh + ti) & 1;
+                b_prep();
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+#pragma unroll
+                        for (int bi = 0; bi < 4; ++bi) {
+                            constexpr unsigned tbl = TBL;
+                            // accumulator order: rows 0..2 run b = 3, 2, 0, 1, row 3 runs b = 0, 1, 3, 2 -- row 3 then frees B[3], B[2], B[0], B[1]
+                            // in the order row 0 of the next half step asks for them, and no accumulator is touched by two neighbours
+                            const int b = a == 3 ? ((bi & 2) ? (bi ^ 1) : bi) : ((bi & 2) ? (bi & 1) : 3 - bi);
+                            if (ks == 1 && a == 3 && bi == 0) {
+                                // every wave's DMA units of the next B tile are IN LDS before anybody passes (all but the A loads issued behind them)
+#define QK_DMA_WAIT(TI) case TI: { constexpr int n_ld = band_loads_in(RPT3, KIN, TI < KIN ? TI : 0) - ((!TRIM && band_loads_halo_in(RPT3, KIN, TI < KIN ? TI : 0)) ? 1 : 0); \
+                __builtin_amdgcn_s_waitcnt(((2 * n_ld) & 15) | (7 << 4) | (15 << 8) | (((2 * n_ld) >> 4) << 14)); } break;       /* vmcnt(2 n_ld) */
+                                switch (ti) { QK_DMA_WAIT(0) QK_DMA_WAIT(1) QK_DMA_WAIT(2) QK_DMA_WAIT(3) QK_DMA_WAIT(4) default: __builtin_amdgcn_s_waitcnt(0); }
+#undef QK_DMA_WAIT
+                                __builtin_amdgcn_s_barrier();
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                            if ((tbl >> (a * 4 + b)) & 1u) accn[b] = mfma16(T(), B[a ^ b], A[a], accn[b]);
+                            else acc[b] = mfma16(T(), B[a ^ b], A[a], acc[b]);
+                            const int f = ks * 16 + a * 4 + bi;
+                            if (f % 2 == 1) {
+                                const int op = f / 2 - BU;                   // the B tile's DMA leads: a whole sub-step to arrive
+                                if (op < 0) { if (rdpar) QK_DMA_B1(f / 2, ldsB0); else QK_DMA_B1(f / 2, ldsB1); }
+                                else
+                                if (op < kBandOpsMax) {
+                                    const int q = band_op(RPT3, KIN, ti, op);
+                                    if (q >= 0 && q < RPT3) { if (gh) QK_DMA_A(q, ldsA0); else QK_DMA_A(q, ldsA1); }
+                                }
+                            }
+                            // ---- refills for the next half step, into the registers this MFMA was the last to read
+                            if (ks == 0) {
+                                if (bi == 3) QK_LD_A(a, band, arow, 1);
+                                if (a == 3) { if (rdpar) QK_LD_B(3 ^ b, ldsB1, 1); else QK_LD_B(3 ^ b, ldsB0, 1); }
+                            } else {
+                                if (ti + 1 < KIN) { if (bi == 3) QK_LD_A(a, band, arow_n, 0); }
+                                else if (a == 3) QK_LD_A(bi, nband, arow_first, 0);           // (behind the barrier: the next group's band)
+                                if (a == 3) { if (rdpar) QK_LD_B(3 ^ b, ldsB0, 0); else QK_LD_B(3 ^ b, ldsB1, 0); }
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                b_advance_if_more();
+            }
+            a_advance_if_more();
+        }
+#undef QK_LD_A
+#undef QK_LD_B
+    } else
     for (int gi2 = (g.ablate & 4) ? groups : 0; gi2 < groups; gi2 += 2)
 #pragma unroll
     for (int gh = 0; gh < 2; ++gh) {                 // two groups per trip: the B buffer a sub-step reads is then a compile-time OBJECT
