@@ -546,6 +546,12 @@ __device__ __forceinline__ void buf_store16b(__amdgpu_buffer_rsrc_t r, unsigned 
 #ifndef QK_BAND_PIPE
 #define QK_BAND_PIPE 1
 #endif
+// probe builds (tools/probe/build_variant.sh probe -DQK_BAND_PROBE): QK_ABLATE 16 = no waits / barriers in the K loop, 32 = no DMA issued in the K loop
+#ifdef QK_BAND_PROBE
+#define QK_PROBE_ON(bit) (!(g.ablate & (bit)))
+#else
+#define QK_PROBE_ON(bit) true
+#endif
 constexpr int kBandOpsMax = 5;
 constexpr int band_op(int R, int K, int ti, int k);
 // row passes LOADED in sub-step ti of a group (op codes 0 .. R - 1), and whether the halo pass (R - 1) is among them: what the
@@ -840,14 +846,18 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
                                 // every wave's DMA units of the next B tile are IN LDS before anybody passes (all but the A loads issued behind them)
 #define QK_DMA_WAIT(TI) case TI: { constexpr int n_ld = band_loads_in(RPT3, KIN, TI < KIN ? TI : 0) - ((!TRIM && band_loads_halo_in(RPT3, KIN, TI < KIN ? TI : 0)) ? 1 : 0); \
                 __builtin_amdgcn_s_waitcnt(((2 * n_ld) & 15) | (7 << 4) | (15 << 8) | (((2 * n_ld) >> 4) << 14)); } break;       /* vmcnt(2 n_ld) */
+                                if (QK_PROBE_ON(16)) {
                                 switch (ti) { QK_DMA_WAIT(0) QK_DMA_WAIT(1) QK_DMA_WAIT(2) QK_DMA_WAIT(3) QK_DMA_WAIT(4) default: __builtin_amdgcn_s_waitcnt(0); }
-#undef QK_DMA_WAIT
                                 __builtin_amdgcn_s_barrier();
+                                }
+#undef QK_DMA_WAIT
                                 __builtin_amdgcn_sched_barrier(0);
                             }
                             if ((tbl >> (a * 4 + b)) & 1u) accn[b] = mfma16(T(), B[a ^ b], A[a], accn[b]);
                             else acc[b] = mfma16(T(), B[a ^ b], A[a], acc[b]);
                             const int f = ks * 16 + a * 4 + bi;
+                            if (!QK_PROBE_ON(32)) { }
+                            else
                             if (f % 2 == 1) {
                                 const int op = f / 2 - BU;                   // the B tile's DMA leads: a whole sub-step to arrive
                                 if (op < 0) { if (rdpar) QK_DMA_B1(f / 2, ldsB0); else QK_DMA_B1(f / 2, ldsB1); }
@@ -1298,7 +1308,7 @@ int run16_band(const T *in, const uint4 *wq, const T *zero_line, const float *bi
     dim3 grid((n_mt + 7) / 8 * 8, (PAD ? g.Jp : g.J) / BF, 1);
     // EPM (epilogue mask, QK_BWD_MASK_DX) is its own instantiation: its eight prefetched mask pieces cost 32 VGPRs
     // ... and so is POSTF (forward post-op: PReLU / dropout, pre-activation written beside y)
-#define QK_GO(C, E, P) hipLaunchKernelGGL((k_hgemm16_band<T, WM, WN, KIN, C, TRIM, E, P, PAD>), grid, dim3(NTHR), 0, stream, in, wq, zero_line, bias, out, g)
+#define QK_GO(C, E, P) hipLaunchKernelGGL((k_hgemm16_band<T, WM, WN, KIN, C, TRIM, E, P, PAD>), grid, dim3(NTHR), (g.ablate & 64) ? 40960 : 0, stream, in, wq, zero_line, bias, out, g)      /* (ablate 64: profiling, ONE workgroup per CU) */
     const bool epm = g.ep_mask != nullptr, pf = g.post.kind != 0 && g.post_fwd != 0;
     if (g.sign_tbl != kSignConj) return QK_ERR_LAUNCH;                 // go16 folds the plain table into the kernel
     if (epm) QK_GO(true, true, false); else if (pf) QK_GO(true, false, true); else QK_GO(true, false, false);
