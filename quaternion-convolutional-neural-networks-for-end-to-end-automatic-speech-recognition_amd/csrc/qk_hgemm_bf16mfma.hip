@@ -828,7 +828,13 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
             a_prep();
 #pragma unroll
             for (int ti = 0; ti < KIN; ++ti, ++s) {
-                const int arow = arow_first + ti * tdir;
+                int arow = arow_first + ti * tdir;
+                // (hipcc hoists the fragment addresses of all KIN sub-steps out of the group loop: ~ 25 VGPRs, 254 - 256 in the 5-tap forms and a
+                //  4-byte spill outside the loop in the masked 32-filter one.  Made opaque here -- QK_BAND_NO_HOIST_ADDR -- they are recomputed
+                //  under the MFMAs: 232 - 236 VGPRs, no spill, but 1.0 - 1.5 % slower on zeros and on data, same box: not the default)
+#ifdef QK_BAND_NO_HOIST_ADDR
+                asm volatile("" : "+v"(arow));
+#endif
                 const int arow_n = arow + tdir;                        // (used where ti + 1 < KIN)
                 const int rdpar = (gh + ti) & 1;
                 b_prep();
