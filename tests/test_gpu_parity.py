@@ -206,6 +206,30 @@ def test_half_matches_oracle_on_rounded_inputs(case, dtype):
         assert err <= tol, '%s: rel err %.3g > %.1g' % (k, err, tol)
 
 
+AB_SWITCH_CASES = [c for c in ORACLE_CASES if c[0] in (
+    'conv2d_body_small', 'conv2d_body64_small', 'conv2d_32to64', 'conv2d_32to64_3tap_linear', 'conv2d_head_valid_conj', 'conv1d_64to32_valid')]
+
+
+@pytest.mark.parametrize('switch', ['QK_DBG_BAND16_8WAVES', 'QK_DBG_WGRAD_BAND_V1', 'QK_DBG_NO_BAND16', 'QK_DBG_WGRAD16_ONE_TAP',
+                                    'QK_DBG_NO_WGRAD_BAND', 'QK_DBG_NO_POINT16'])
+@pytest.mark.parametrize('case', AB_SWITCH_CASES, ids=[c[0] for c in AB_SWITCH_CASES])
+def test_ab_switch_kernels_match_oracle(case, switch):
+    """Every A/B switch of include/qk.h selects kernels the default dispatch no longer reaches (the 8-wave band tilings, the
+    round-2..4 backward-weight band kernel, the general implicit-GEMM forms under the band / point kernels, one-tap backward-weight
+    blocks): they are what the committed A/B profiles were measured against, so they are held to the oracle like the defaults."""
+    import qcnn_amd
+    from qcnn_amd import _lib
+    _, rank, xs, ws, kw = case
+    dtype = torch.bfloat16
+    x, w, b, dy, want = _oracle_case(rank, xs, ws, kw, seed=13, dtype=dtype)
+    with _lib.debug_flags(getattr(_lib, switch)):
+        got = _run_layer(qcnn_amd.functional, x, w, b, dy, rank, kw, dtype)
+    for k, v in got.items():
+        err = _rel_err(v, want[k])
+        tol = 1e-2 if k in ('y', 'dx') else 2e-3
+        assert err <= tol, '%s under %s: rel err %.3g > %.1g' % (k, switch, err, tol)
+
+
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16], ids=['bf16', 'fp16'])
 def test_sixteen_channel_layers_run_on_the_matrix_cores(dtype):
     """/root/reference/models/interspeech_model.py:46-50: start_filter is a free hyperparameter; sf = 16 gives 16 -> 16 and 16 -> 32
