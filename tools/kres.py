@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.realpath(__file__)))
 CSRC = os.path.join(ROOT, 'quaternion-convolutional-neural-networks-for-end-to-end-automatic-speech-recognition_amd', 'csrc')
 src = sys.argv[1]
 flt = sys.argv[2] if len(sys.argv) > 2 else ''
-cmd = ['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-munsafe-fp-atomics', '-fPIC', '-Wno-unused-value',
+cmd = ["hipcc"] + os.environ.get("KRES_FLAGS", "").split() + ['--offload-arch=gfx950', '-O3', '-std=c++17', '-munsafe-fp-atomics', '-fPIC', '-Wno-unused-value',
        '-c', os.path.join(CSRC, src), '-o', '/tmp/kres.o', '-Rpass-analysis=kernel-resource-usage']
 out = subprocess.run(cmd, stderr=subprocess.PIPE, stdout=subprocess.PIPE, text=True).stderr
 cur = None
@@ -29,6 +29,6 @@ for r, n in zip(rows, names):
     n = re.sub(r'\(.*', '', n)
     if flt and flt not in n:
         continue
-    print('%-48s vgpr %3d spill %3d scratch %4d sgpr %3d lds %6d occ %d' % (
-        n[:48], r.get('VGPRs', -1), r.get('VGPRs Spill', -1), r.get('ScratchSize', -1),
+    print('%-72s vgpr %3d spill %3d scratch %4d sgpr %3d lds %6d occ %d' % (
+        n[:72], r.get('VGPRs', -1), r.get('VGPRs Spill', -1), r.get('ScratchSize', -1),
         r.get('TotalSGPRs', -1), r.get('LDS Size', -1), r.get('Occupancy', -1)))
