@@ -145,6 +145,11 @@ ORACLE_CASES = [
     #  fourth plane out and no case saw it)
     ('conv2d_32to64_3tap_linear', 2, (1, 9, 70, 128), (3, 3, 32, 256), dict(padding='same', activation=None)),
     ('conv1d_16to64_3tap_linear', 1, (3, 150, 64), (3, 16, 256), dict(padding='same', activation=None)),
+    # the pipelined band loop's corners: ONE group per tile (1-D, one 32-channel chunk: the second half of the two-group trip never runs),
+    # two outer taps (an even group count with a single chunk), a 'valid' 5-tap 2-D layer whose tiles end inside an image line
+    ('conv1d_32to32_5tap', 1, (3, 150, 128), (5, 32, 128), dict(padding='same', activation='relu')),
+    ('conv2d_2x3_64ch', 2, (1, 6, 70, 256), (2, 3, 64, 256), dict(padding='same', activation=None)),
+    ('conv2d_32to64_valid_5tap', 2, (2, 5, 61, 128), (3, 5, 32, 256), dict(padding='valid', activation='relu')),
     ('conv2d_16to16_5tap', 2, (2, 6, 80, 64), (3, 5, 16, 64), dict(padding='same', activation=None)),
     ('conv2d_16to16_5tap_relu', 2, (2, 6, 80, 64), (3, 5, 16, 64), dict(padding='same', activation='relu')),
     ('conv2d_16to32_3tap', 2, (2, 5, 75, 64), (3, 3, 16, 128), dict(padding='same', activation=None)),
@@ -189,7 +194,8 @@ HALF_CASES = [c for c in ORACLE_CASES if c[0] in (
     'conv2d_chfirst_body_small',
     'conv2d_first_layer', 'dense_timit_head', 'dense_point_64', 'dense_point_32to128', 'conv2d_head_valid_conj', 'conv1d_1x1_64', 'conv3d_32ch', 'conv2d_32ch_outer_stride_dil', 'conv2d_64ch_valid_wide',
     'conv2d_cq16_f64_5tap_relu', 'conv2d_cq16_f64_5tap_linear',
-    'conv2d_32to64_3tap_linear', 'conv1d_16to64_3tap_linear', 'conv2d_16to16_5tap', 'conv2d_16to16_5tap_relu', 'conv2d_16to32_3tap', 'conv2d_48to16_5tap', 'conv1d_16to48_valid')]
+    'conv2d_32to64_3tap_linear', 'conv1d_16to64_3tap_linear', 'conv2d_16to16_5tap', 'conv2d_16to16_5tap_relu', 'conv2d_16to32_3tap', 'conv2d_48to16_5tap', 'conv1d_16to48_valid',
+    'conv1d_32to32_5tap', 'conv2d_2x3_64ch', 'conv2d_32to64_valid_5tap')]
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16], ids=['bf16', 'fp16'])
