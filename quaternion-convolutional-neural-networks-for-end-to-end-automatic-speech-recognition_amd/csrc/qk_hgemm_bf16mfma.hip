@@ -1069,13 +1069,16 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
 //     optional bias / relu / epilogue mask / post-op.
 // HBM-bound by construction: the head backward-data writes 367 MB for 94 GFLOP.
 // ---------------------------------------------------------------------------------------
-template <typename T, int NKC, bool EPM>
+// WN = 1 (round 5, late): 32-channel column blocks, 256-row tiles -- produced widths that are multiples of 32 but not of 64 (the head's
+// backward-data of a start_filter = 16 model: 64 -> 32) ran the general implicit-GEMM kernel at 6 % of peak (0.28 ms for 184 MB).
+template <typename T, int NKC, bool EPM, int WN = 2>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_hgemm16_point(const T *__restrict__ in, const uint4 *__restrict__ wq, const float *__restrict__ bias,
                 T *__restrict__ out, const GemmGeom g, const int n_tiles, const int n_units, const unsigned in_bytes,
                 const unsigned out_bytes)
 {
-    constexpr int WN = 2, BM = 128, BF = 64;
+    static_assert(WN == 1 || WN == 2, "column blocks of 32 or 64 channels");
+    constexpr int BM = (8 / WN) * 32, BF = WN * 32;
     constexpr int NF = 2 * NKC;                      // 16-channel K slices per component
     constexpr int B_U = NKC * 16 * BF;               // 16-byte units of one (tap, column block) kernel slice
     constexpr unsigned TBL = kSignConj;              // go16 folds the plain table into the kernel
@@ -1259,7 +1262,7 @@ k_hgemm16_point(const T *__restrict__ in, const uint4 *__restrict__ wq, const fl
 // spatial axes.
 inline bool point_geom(const GemmGeom &g, GemmGeom *o)
 {
-    if (g.has_mask || (g.Q != 32 && g.Q != 64) || g.J % 64 != 0) return false;
+    if (g.has_mask || (g.Q != 32 && g.Q != 64) || g.J % 32 != 0) return false;
     if (g.post.kind != 0) {
         // the backward form (derivative in the epilogue, pre-activation / y in ep_mask), or -- round 4 -- the forward RELU form
         // y = dropout(relu(pre)) with its single output tensor (the TimeDistributed dense layers of the TIMIT model as chain links)
@@ -1291,16 +1294,23 @@ int run16_point(const T *in, const uint4 *wq, const float *bias, T *out, GemmGeo
     fastdiv_of((unsigned)g.osp[2], &g.dv_mul[0], &g.dv_shr[0]);
     fastdiv_of((unsigned)g.osp[1], &g.dv_mul[1], &g.dv_shr[1]);
     fastdiv_of((unsigned)S, &g.dv_mul[2], &g.dv_shr[2]);
-    const int n_tiles = (R + 127) / 128;
-    const int n_units = g.ks[0] * (g.J / 64) * n_tiles;
+    const bool wide = g.J % 64 == 0;                  // 64-channel column blocks x 128-row tiles, or 32 x 256
+    const int BM = wide ? 128 : 256, BF = wide ? 64 : 32;
+    const int n_tiles = (R + BM - 1) / BM;
+    const int n_units = g.ks[0] * (g.J / BF) * n_tiles;
     int blocks = device_cu_count();                   // 8 waves at a 256-register budget: one workgroup per CU
     if (blocks > n_units) blocks = n_units;
     const unsigned in_bytes = (unsigned)((long long)g.batch * g.in_sn * 2);
     const unsigned out_bytes = (unsigned)((long long)g.M * g.out_ss * 2);
-#define QK_GO(NKC, E) hipLaunchKernelGGL((k_hgemm16_point<T, NKC, E>), dim3(blocks), dim3(512), 0, stream, in, wq, bias, out, g, n_tiles, n_units, in_bytes, out_bytes)
+#define QK_GO(NKC, E, W) hipLaunchKernelGGL((k_hgemm16_point<T, NKC, E, W>), dim3(blocks), dim3(512), 0, stream, in, wq, bias, out, g, n_tiles, n_units, in_bytes, out_bytes)
     const bool epm = g.ep_mask != nullptr;
-    if (g.Q == 64) { if (epm) QK_GO(2, true); else QK_GO(2, false); }
-    else           { if (epm) QK_GO(1, true); else QK_GO(1, false); }
+    if (wide) {
+        if (g.Q == 64) { if (epm) QK_GO(2, true, 2); else QK_GO(2, false, 2); }
+        else           { if (epm) QK_GO(1, true, 2); else QK_GO(1, false, 2); }
+    } else {
+        if (g.Q == 64) { if (epm) QK_GO(2, true, 1); else QK_GO(2, false, 1); }
+        else           { if (epm) QK_GO(1, true, 1); else QK_GO(1, false, 1); }
+    }
 #undef QK_GO
     return hipGetLastError() == hipSuccess ? 1 : QK_ERR_LAUNCH;
 }

@@ -158,6 +158,11 @@ ORACLE_CASES = [
     # one tap per produced row: the streaming point-form kernel (k_hgemm16_point) in 16 bit
     ('dense_point_64', 0, (333, 256), (64, 256), dict(activation='relu')),
     ('dense_point_32to128', 0, (200, 128), (32, 512), dict(activation=None)),
+    # produced widths of 32 channels per component: the point form's 32-channel column blocks (256-row tiles) -- a dense layer, a 1 x 1
+    # convolution and the backward-data of a 32 -> 64 head (start_filter = 16 models)
+    ('dense_point_64to32', 0, (300, 256), (64, 128), dict(activation='relu')),
+    ('conv1d_1x1_32to32', 1, (3, 101, 128), (1, 32, 128), dict(padding='same', activation=None)),
+    ('conv2d_head_valid_conj_32to64', 2, (3, 6, 50, 128), (6, 1, 32, 256), dict(padding='valid', activation=None, conj=True)),
     ('conv2d_head_valid_conj', 2, (3, 6, 50, 256), (6, 1, 64, 256), dict(padding='valid', activation=None, conj=True)),
     ('conv1d_1x1_64', 1, (4, 77, 256), (1, 64, 256), dict(padding='same', activation='relu')),
     ('dense_qdnn0', 0, (32, 1000), (250, 512), dict(activation='relu')),
@@ -195,7 +200,7 @@ HALF_CASES = [c for c in ORACLE_CASES if c[0] in (
     'conv2d_first_layer', 'dense_timit_head', 'dense_point_64', 'dense_point_32to128', 'conv2d_head_valid_conj', 'conv1d_1x1_64', 'conv3d_32ch', 'conv2d_32ch_outer_stride_dil', 'conv2d_64ch_valid_wide',
     'conv2d_cq16_f64_5tap_relu', 'conv2d_cq16_f64_5tap_linear',
     'conv2d_32to64_3tap_linear', 'conv1d_16to64_3tap_linear', 'conv2d_16to16_5tap', 'conv2d_16to16_5tap_relu', 'conv2d_16to32_3tap', 'conv2d_48to16_5tap', 'conv1d_16to48_valid',
-    'conv1d_32to32_5tap', 'conv2d_2x3_64ch', 'conv2d_32to64_valid_5tap')]
+    'conv1d_32to32_5tap', 'conv2d_2x3_64ch', 'conv2d_32to64_valid_5tap', 'dense_point_64to32', 'conv1d_1x1_32to32', 'conv2d_head_valid_conj_32to64')]
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16], ids=['bf16', 'fp16'])
