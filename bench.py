@@ -972,7 +972,9 @@ def main():
                         ('qcnn_ctc_step', DEFAULT_WORKLOAD, 'ctc', 'the default workload with K.ctc_batch_cost (interspeech_model.py:37-39,178), '
                                                                     'mean over the batch, as the loss'),
                         ('qcnn_sumloss_step', DEFAULT_WORKLOAD, 'sum', 'the default workload with the linear stand-in loss <prediction, fixed '
-                                                                       'random tensor> that rounds 1-3 timed as the headline'))
+                                                                       'random tensor> that rounds 1-3 timed as the headline'),
+                        ('qcnn_sf16_step', 'cfg3_qcnn_sf16_b256_bf16', 'ctc', 'the same graph at start_filter = 16 (interspeech_model.py:46-50): 16 -> 16 / 16 -> 32 / '
+                                                                              '32 -> 32 body layers on the 16-bit matrix cores (round 5), CTC cost'))
             for key, wl, loss, note in variants:
                 if wl == args.workload and loss == args.loss:
                     continue
