@@ -63,7 +63,7 @@ struct GemmGeom {
     int relu;           // epilogue activation
     int has_bias;
     int has_mask;       // gathered value is zeroed where mask[same index] <= 0 (relu backward)
-    int ablate;         // profiling only (env QK_ABLATE): 4 = skip the MFMA loop, 8 = skip the epilogue
+    int ablate;         // profiling only (env QK_ABLATE): 4 = skip the MFMA loop, 8 = skip the epilogue, 64 = band kernels with ONE workgroup per CU (probe builds: 16 / 32, qk_hgemm_bf16mfma.hip)
     unsigned b_rep;     // band kernels: sum over outer tap t0 of 2^(t0 * ks[1]) (0: more than 32 outer taps -- loop form)
     unsigned long long *dbg_ts;          // profiling only (qk_set_debug_buffer): per-workgroup phase time stamps of the band kernel
     int w_swapped;      // Wk is the compact kernel itself, read with q/j swapped (backward-data): no transposed copy
