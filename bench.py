@@ -581,6 +581,8 @@ def cpu_baseline(cfg, seconds, loss='ctc'):
     what = ('the full TIMIT QCNN (n=%d, sf=%d, %d frames) through oracle/ref_model.py' % (cfg['layers'], cfg['sf'], cfg['frames'])
             if is_model else 'the same layer through oracle/ref_port.py')
     return {'value': sample_b / (ms * 1e-3), 'unit': 'samples/s', 'cores': th, 'kind': 'port',
+            'value_measured_at': 'batch %d (%d timed steps); the GPU line above is batch %d -- samples/s of a bounded CPU sample, not the same batch'
+                                 % (sample_b, n, cfg['batch']),
             'ms_per_step': ms, 'host_cpus': ncpu, 'numa_nodes': len(nodes), 'physical_cores_node0': node0,
             'threads_tried': tries, 'ms_per_step_by_threads': per, 'pinning': pin,
             'thread_placement': 'one thread per physical core, NUMA node 0 first; OMP_PROC_BIND=close OMP_PLACES=cores; affinity mask = those cores; one process per thread count',
@@ -668,7 +670,9 @@ class GpuTelemetry(object):
             p = self._read('power1_average', 1e6)
             if p is None:
                 p = self._read('power1_input', 1e6)
-            self.rows.append((time.perf_counter(), p, self._read('freq1_input', 1e6)))
+            # (energy1_input: the socket's accumulated-energy counter in microjoules where the driver exposes it; amdgpu's hwmon
+            #  usually does not -- the energy of the window is then the trapezoid integral of the power samples)
+            self.rows.append((time.perf_counter(), p, self._read('freq1_input', 1e6), self._read('energy1_input', 1e6)))
             time.sleep(0.01)
 
     def start(self):
@@ -686,8 +690,22 @@ class GpuTelemetry(object):
         ck = [r[2] for r in rows if r[2] is not None]
         if not pw and not ck:
             return None
+        # energy of the window: the hwmon energy counter's difference where there is one, else the integral of the power samples
+        # (trapezoid over the sample times, the first / last sample held to the window's edges)
+        energy, how = None, None
+        en = [(r[0], r[3]) for r in rows if len(r) > 3 and r[3] is not None]
+        if len(en) >= 2 and en[-1][1] > en[0][1]:
+            energy = (en[-1][1] - en[0][1]) * (t1 - t0) / max(en[-1][0] - en[0][0], 1e-9)
+            how = 'hwmon energy1_input difference, scaled from the sampled span to the window'
+        else:
+            pts = [(r[0], r[1]) for r in rows if r[1] is not None]
+            if pts:
+                pts = [(t0, pts[0][1])] + pts + [(t1, pts[-1][1])]
+                energy = sum(0.5 * (a[1] + b[1]) * (b[0] - a[0]) for a, b in zip(pts, pts[1:]))
+                how = 'integral of the socket-power samples over the window (trapezoid; power1_average is itself a driver-side average)'
         return {'mean_socket_w': sum(pw) / len(pw) if pw else None, 'mean_sclk_mhz': sum(ck) / len(ck) if ck else None,
                 'min_sclk_mhz': min(ck) if ck else None, 'samples': len(rows), 'power_cap_w': self._read('power1_cap', 1e6),
+                'window_s': t1 - t0, 'energy_j': energy, 'energy_method': how,
                 'source': 'amdgpu hwmon of %s, 10 ms period, inside the timed region' % self.card}
 
 
@@ -887,6 +905,13 @@ def main():
                             'flops_per_step': 3 * job.flops_per_kernel,
                             'note': 'algorithmic 2MNK fwd + 4MNK bwd of the quaternion layers / whole-step wall time'}
         out['step_tflops'] = tf
+        if tele_out and tele_out.get('energy_j'):
+            # energy accounting (round-5 verdict, missing 5): every body kernel sits on the socket power limiter, so
+            # "structure vs clock" is tracked round over round in JOULES: per training step and per algorithmic TFLOP of the step
+            out['energy_j_per_step'] = tele_out['energy_j'] / steps
+            out['j_per_tflop'] = out['energy_j_per_step'] / (3 * job.flops_per_kernel / 1e12)
+            out['energy_note'] = ('socket energy of the %d timed steps (rank 0) / steps; j_per_tflop = that / the step\'s algorithmic TFLOP '
+                                  '(%.2f); %s' % (steps, 3 * job.flops_per_kernel / 1e12, tele_out.get('energy_method')))
     if rank == 0 and world == 1 and is_model and not args.no_kernel_timing:
         try:
             out['in_step_kernels'] = in_step_kernel_times(job, dev, peak)
@@ -1010,6 +1035,9 @@ def main():
                 blk = {'workload': 'cfg5_stack_b32_fp16', 'dtype': 'fp16', 'gemm_view': j5.gemm, 'steps': 12, 'warmup': 3, 'pre_warmup_steps': 2,
                        'ms_per_step': 1e3 * el / 12, 'samples_per_s': c5['batch'] * 12 / el, 'tflops': tf5, 'frac_of_peak': tf5 / PEAK_TFLOPS['fp16'],
                        'gpu_telemetry': tele5, 'loss': 'sum (linear stand-in: the stack has no softmax / CTC head)'}
+                if tele5 and tele5.get('energy_j'):
+                    blk['energy_j_per_step'] = tele5['energy_j'] / 12
+                    blk['j_per_tflop'] = blk['energy_j_per_step'] / (3 * j5.flops_per_kernel / 1e12)
                 k5 = in_step_kernel_times(j5, dev, PEAK_TFLOPS['fp16'], steps=2)
                 blk['in_step_kernels'] = k5
                 if k5.get('calls'):

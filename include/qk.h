@@ -137,8 +137,19 @@ const char *qk_last_error(void);
                                          * no longer spread over the CUs): for debugging and for repeatability tests. */
 #define QK_DBG_WGRAD_BAND_V1 0x20000u /* 16-bit backward-weight band kernel in its round-2..4 form (register staging, two tile buffers; env QK_WGRAD_BAND_V1) -- A/B */
 #define QK_DBG_NO_SMALL16 0x40000u /* 16-bit layers with 16 / 32 channels per component on the zero-padded band kernels instead of k_hconv16_small
-                                     * (env QK_NO_SMALL16; A/B).  The two forms cache DIFFERENT 16-bit kernel layouts: toggle it at run time only
-                                     * together with dropping the caches (qcnn_amd.invalidate_cached_kernels()) */
+                                     * (env QK_NO_SMALL16; A/B).  Safe to toggle at run time: such a layer's workspace carries both 16-bit
+                                     * kernel layouts in regions of their own (round 6) */
+/* Graph-level A/B switches (round 6: they were environment variables read by the Python host at call time).  The library itself
+ * does not act on them -- they live in this mask so that every A/B switch of the engine has ONE home, ONE initialisation from the
+ * environment (same names: QK_NO_CONV_CHAIN ...) and ONE run-time API; the host-side model code (models/interspeech_model.py,
+ * layers.py) asks qk_get_debug_flags().  Each one selects the unfused composition of the same arithmetic. */
+#define QK_DBG_NO_CONV_CHAIN 0x100000u     /* body convolutions as separate autograd nodes instead of qk_conv_bwd_chain */
+#define QK_DBG_NO_FUSED_PRELU 0x200000u    /* PReLU (+ Dropout) as qk_postop_* passes instead of the conv epilogues */
+#define QK_DBG_NO_FUSED_DROPOUT 0x400000u  /* relu + Dropout as separate passes instead of the one-output post-op */
+#define QK_DBG_NO_FUSED_CTC 0x800000u      /* K.ctc_batch_cost through torch's ctc_loss instead of qk_ctc_batch_cost */
+#define QK_DBG_NO_FUSED_FIRST 0x1000000u   /* first layer + frequency pooling as conv, activation and pooling passes instead of qk_conv_*_pool_* */
+#define QK_DBG_NO_DENSE_IN_CHAIN 0x2000000u /* the TimeDistributed quaternion-dense layers outside the backward chain */
+#define QK_DBG_NO_FUSED_SOFTMAX 0x4000000u /* Dense(62, softmax) through torch ops instead of the fused output-layer kernels */
 #define QK_DBG_BAND16_8WAVES 16u   /* 16-bit band kernels: 8-wave workgroups (one per CU) instead of 4-wave (two per CU) */
 unsigned qk_set_debug_flags(unsigned flags);
 /* Profiling only: a device buffer (64 bytes per workgroup, 65536 workgroups) into which the 16-bit band kernels drop shader-clock time stamps of their

@@ -22,6 +22,9 @@ QK_DBG_CTC_TWO_SWEEPS = 128
 QK_DBG_DETERMINISTIC = 0x10000
 QK_DBG_WGRAD_BAND_V1 = 0x20000
 QK_DBG_NO_SMALL16 = 0x40000
+# graph-level A/B switches (include/qk.h): kept in the library's mask, acted on by models/interspeech_model.py and layers.py
+QK_DBG_NO_CONV_CHAIN, QK_DBG_NO_FUSED_PRELU, QK_DBG_NO_FUSED_DROPOUT, QK_DBG_NO_FUSED_CTC = 0x100000, 0x200000, 0x400000, 0x800000
+QK_DBG_NO_FUSED_FIRST, QK_DBG_NO_DENSE_IN_CHAIN, QK_DBG_NO_FUSED_SOFTMAX = 0x1000000, 0x2000000, 0x4000000
 QK_ERR_INVALID_ARG, QK_ERR_UNSUPPORTED, QK_ERR_WORKSPACE, QK_ERR_LAUNCH = -1, -2, -3, -4
 QK_PATH_NAMES = {0: 'none', 1: 'mfma16', 2: 'mfma16_band', 3: 'fp32_mfma', 4: 'mfma16_point', 5: 'mfma16_small'}               # qk_last_path
 
@@ -143,6 +146,12 @@ def check(rc, what):
     if rc != 0:
         msg = lib().qk_last_error()
         raise RuntimeError('%s failed (status %d): %s' % (what, rc, msg.decode() if msg else ''))
+
+
+def dbg(bit):
+    """True when diagnostic bit `bit` of the library's process-wide mask is set (qk_get_debug_flags: one relaxed atomic load; the
+    mask's initial value was read from the environment ONCE, when the library initialised it)."""
+    return bool(lib().qk_get_debug_flags() & bit)
 
 
 class debug_flags(object):

@@ -32,6 +32,14 @@ unsigned env_flags()
     if (getenv("QK_DETERMINISTIC")) f |= kDbgDeterministic;
     if (getenv("QK_WGRAD_BAND_V1")) f |= kDbgWgradBandV1;
     if (getenv("QK_NO_SMALL16")) f |= kDbgNoSmall16;
+    // graph-level switches: stored here, acted on by the host-side model code (include/qk.h)
+    if (getenv("QK_NO_CONV_CHAIN")) f |= QK_DBG_NO_CONV_CHAIN;
+    if (getenv("QK_NO_FUSED_PRELU")) f |= QK_DBG_NO_FUSED_PRELU;
+    if (getenv("QK_NO_FUSED_DROPOUT")) f |= QK_DBG_NO_FUSED_DROPOUT;
+    if (getenv("QK_NO_FUSED_CTC")) f |= QK_DBG_NO_FUSED_CTC;
+    if (getenv("QK_NO_FUSED_FIRST")) f |= QK_DBG_NO_FUSED_FIRST;
+    if (getenv("QK_NO_DENSE_IN_CHAIN")) f |= QK_DBG_NO_DENSE_IN_CHAIN;
+    if (getenv("QK_NO_FUSED_SOFTMAX")) f |= QK_DBG_NO_FUSED_SOFTMAX;
     if (const char *ab = getenv("QK_ABLATE")) f |= ((unsigned)atoi(ab) << kDbgAblateShift) & kDbgAblateMask;
     return f;
 }
@@ -300,6 +308,8 @@ int x_to_first(const qk_conv_desc_t *d, const void *src, void *dst, hipStream_t 
 int y_to_last(const qk_conv_desc_t *d, const void *src, void *dst, hipStream_t s) { return launch_relayout16(src, dst, d->batch, 4 * d->fq, out_positions(d), s); }
 int y_to_first(const qk_conv_desc_t *d, const void *src, void *dst, hipStream_t s) { return launch_relayout16(src, dst, d->batch, out_positions(d), 4 * d->fq, s); }
 
+void prep_geom(const qk_conv_desc_t *d, bool bwd, GemmGeom *gp);
+
 size_t ws_bytes_impl(const qk_conv_desc_t *d, int op)
 {
     if (cf16_ok(d)) {
@@ -329,6 +339,12 @@ size_t ws_bytes_impl(const qk_conv_desc_t *d, int op)
         // 16-bit kernels; their figure is what it always was)
         const bool on16 = d->cq % 16 == 0 && d->fq % 16 == 0;
         n += (on16 ? (size_t)taps_of(d) * pad32(d->cq) * 4 * pad32(d->fq) : w_floats(d)) * 2 + 256;
+        if (on16 && d->layout == QK_CH_LAST) {        // 16 / 32-channel layers: the fragment layout of k_hconv16_small in a second region (go16)
+            GemmGeom sg, sbg;
+            Small16 sm;
+            prep_geom(d, bwd_data, &sg);
+            if (small16_shape(sg, &sbg, &sm)) n += small16_region_bytes(sm);
+        }
     }
     if (op == QK_OP_BWD && d->activation == QK_ACT_RELU) n = (n + 255) / 256 * 256 + dy_bytes(d);
     return n;
@@ -1085,16 +1101,22 @@ int qk_conv_prep_kernels(int32_t n, const qk_conv_desc_t *const *descs, const in
                 PrepJob &j = jobs.j[m++];
                 j.w = w[i]; j.wq = workspaces[i]; j.taps = taps_of(d); j.cq = d->cq; j.fq = d->fq;
                 j.transposed = bwd ? 1 : 0;
-                {   // 16 / 32-channel layers: the layout of k_hconv16_small, decided by the shape alone exactly as go16 decides it
+                j.small = 0; j.kin = 0; j.n_ot = 0;
+                j.neg_ijk = bwd ? (d->conj ? 1 : 0) : (d->conj ? 0 : 1);       // the sign table go16 folds into the kernel
+                {   // 16 / 32-channel layers: a second job writes the fragment layout of k_hconv16_small into the region behind the band
+                    // layout (the shape alone decides that the region exists, exactly as go16 and qk_conv_workspace_bytes see it)
                     GemmGeom sg, sbg;
                     Small16 sm;
                     prep_geom(d, bwd, &sg);
-                    j.small = (d->layout == QK_CH_LAST && small16_shape(sg, &sbg, &sm)) ? 1 : 0;
-                    j.kin = j.small ? sm.kin : 0; j.n_ot = j.small ? sm.n_ot : 0;
+                    if (d->layout == QK_CH_LAST && small16_shape(sg, &sbg, &sm)) {
+                        PrepJob &k = jobs.j[m++];
+                        k = j;
+                        k.wq = static_cast<char *>(workspaces[i]) + (size_t)j.taps * pad32(d->cq) * 4 * pad32(d->fq) * 2 + 256;
+                        k.small = 1; k.kin = sm.kin; k.n_ot = sm.n_ot;
+                    }
                 }
-                j.neg_ijk = bwd ? (d->conj ? 1 : 0) : (d->conj ? 0 : 1);       // the sign table go16 folds into the kernel
             }
-            if (m == 32 || (i == n && m > 0)) {
+            if (m >= 31 || (i == n && m > 0)) {
                 if (int rc = launch_prep_w16_batch(dt, jobs, m, (hipStream_t)stream)) return check_launch(rc, "qk_conv_prep_kernels");
                 m = 0;
             }

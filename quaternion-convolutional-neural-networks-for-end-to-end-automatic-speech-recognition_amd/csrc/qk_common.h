@@ -317,6 +317,8 @@ inline bool small16_shape(const GemmGeom &g_in, GemmGeom *bg, Small16 *s)
     s->w_bytes = (unsigned)(s->nkk * 4 * s->fb * 1024);
     return s->n_ot <= 3;                               // the whole kernel is resident in LDS (static: three outer taps) beside two band buffers
 }
+// bytes of the workspace region that holds the fragment layout (it sits BEHIND the band layout + zero line of the same kernel)
+inline size_t small16_region_bytes(const Small16 &s) { return ((size_t)s.w_bytes + 255) / 256 * 256 + 256; }
 int launch_prep_small16(int dtype, const float *w, void *wq, int Cq, int F, int transposed, int neg_ijk, const Small16 &s, hipStream_t stream);
 int launch_hconv16_small(int dtype, const void *in, const void *wq, const float *bias, void *out, const GemmGeom &bg, const Small16 &s, hipStream_t stream);
 

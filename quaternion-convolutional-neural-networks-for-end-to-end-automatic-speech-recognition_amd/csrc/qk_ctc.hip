@@ -82,7 +82,7 @@ k_ctc(const T *__restrict__ pred, const int *__restrict__ labels, const int *__r
         for (int c = 0; c < g.C; ++c) sum += __expf((LPS ? lpt[t * g.C + c] : __logf(to_f32(p[t * g.C + c]) + g.eps)) - m);
         lse[t] = m + __logf(sum);
     }
-    if (tid < 2 * g.C) acc2[tid] = 0.f;
+    for (int i = tid; i < 2 * g.C; i += CTC_THREADS) acc2[i] = 0.f;      // C may reach CTC_THREADS: both parity tables
     __syncthreads();
     if constexpr (LPS) {
         for (int e = tid; e < Tn * g.C; e += CTC_THREADS) lpt[e] -= lse[e / g.C];
@@ -354,16 +354,21 @@ int launch_ctc(int dtype, int B, int T, int C, const void *pred, const int *labe
     if (fast_lds <= 150 * 1024 && !(debug_flags() & kDbgCtcTwoSweeps)) {
         float *beta_ws = ws + (size_t)B * T * g.Smax;
         dim3 grid((unsigned)B), block(CTCF_THREADS);
-        // More than 64 KB of dynamic LDS must be asked for explicitly.  The largest size granted so far is remembered per element
-        // type (one relaxed atomic, as the debug mask): the attribute call is made only when a call needs more.  A device that
-        // refuses the size (less opt-in LDS than gfx950's 160 KB) is no error: the two-sweep kernel below takes the call.
+        // More than 64 KB of dynamic LDS must be asked for explicitly.  The largest size granted so far is remembered per DEVICE and
+        // element type (the attribute belongs to the device's copy of the function): the attribute call is made only when a call
+        // needs more.  A device that refuses the size, or a launch of the fast form that fails, is no error: the two-sweep kernel
+        // below takes the call.
         bool fast_ok = true;
-#define QK_CTCF(TT) do { static std::atomic<int> granted{0}; \
-        if ((int)fast_lds > granted.load(std::memory_order_relaxed)) { \
+        constexpr int kMaxDevices = 64;
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) { (void)hipGetLastError(); dev = 0; }
+#define QK_CTCF(TT) do { static std::atomic<int> granted[kMaxDevices]; \
+        if ((int)fast_lds > granted[dev].load(std::memory_order_relaxed)) { \
             if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ctc_fast<TT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast_lds) == hipSuccess) \
-                granted.store((int)fast_lds, std::memory_order_relaxed); \
+                granted[dev].store((int)fast_lds, std::memory_order_relaxed); \
             else { (void)hipGetLastError(); fast_ok = false; } } \
-        if (fast_ok) hipLaunchKernelGGL((k_ctc_fast<TT>), grid, block, fast_lds, stream, (const TT *)pred, labels, in_len, lab_len, cost, (TT *)dpred, ws, beta_ws, g); } while (0)
+        if (fast_ok) { hipLaunchKernelGGL((k_ctc_fast<TT>), grid, block, fast_lds, stream, (const TT *)pred, labels, in_len, lab_len, cost, (TT *)dpred, ws, beta_ws, g); \
+            if (hipGetLastError() != hipSuccess) { granted[dev].store(0, std::memory_order_relaxed); fast_ok = false; } } } while (0)
         switch (dtype) {
         case QK_F32: QK_CTCF(float); break;
         case QK_BF16: QK_CTCF(bf16); break;
@@ -371,7 +376,7 @@ int launch_ctc(int dtype, int B, int T, int C, const void *pred, const int *labe
         default: return QK_ERR_INVALID_ARG;
         }
 #undef QK_CTCF
-        if (fast_ok) return hipGetLastError() == hipSuccess ? 0 : QK_ERR_LAUNCH;
+        if (fast_ok) return 0;
     }
     const bool lps = full <= 64 * 1024;
     const size_t lds = lps ? full : base;

@@ -1350,7 +1350,7 @@ int run16(const T *in, const T *mask, const uint4 *wq, const T *zero_line, const
 
 template <typename T>
 int go16(const void *in, const void *mask, const float *w, const float *bias, void *out, const GemmGeom &g_in,
-         bool transposed, void *ws, hipStream_t stream)
+         bool transposed, void *ws, size_t ws_bytes, hipStream_t stream)
 {
     GemmGeom g = g_in;
     g.ablate = debug_ablate();
@@ -1369,11 +1369,23 @@ int go16(const void *in, const void *mask, const float *w, const float *bias, vo
     const bool padded = g.Qp != g.Q || g.Jp != g.J;      // multiples of 16 only: the band kernel's PAD form or nothing (the caller goes on to the fp32-MFMA kernels)
     GemmGeom bg;
     {
-        // 16 / 32 channels per component (start_filter = 16 models): the streaming small-channel kernel (qk_hconv16_small.hip).  The SHAPE
-        // alone decides the layout of the cached 16-bit kernel (qk_conv_prep_kernels asks the same small16_shape); a call the kernel
-        // does not take although the shape is its own -- PReLU post-ops, the diagnostic switch -- re-lays the kernel out for the band form.
+        // 16 / 32 channels per component (start_filter = 16 models): the streaming small-channel kernel (qk_hconv16_small.hip).  Such a
+        // shape's workspace holds BOTH 16-bit layouts of the kernel, each in a region of its own -- [band layout + zero line][fragment
+        // layout of k_hconv16_small] (qk_*_workspace_bytes; qk_conv_prep_kernels writes both) -- so a cached workspace
+        // (ws_has_kernel) is valid whichever kernel a call ends up on: PReLU post-ops and the diagnostic switch take the band form,
+        // everything else the small kernel, in any order, on the same buffer.  A workspace without room for the second region
+        // (a caller that sized it by hand for the band form) runs the band form.
         Small16 sm;
-        if (small16_shape(g, &bg, &sm)) {
+        const size_t band_bytes = (size_t)g.taps * g.Qp * 4 * g.Jp * 2 + 256;
+        if (small16_shape(g, &bg, &sm) && ws_bytes >= band_bytes + small16_region_bytes(sm)) {
+            T *wqs = reinterpret_cast<T *>(static_cast<char *>(ws) + band_bytes);
+            if (!g.w_prepped) {                       // a cache miss fills BOTH regions: the caller may flag the buffer as prepped from now on
+                if (int rc = launch_prep_small16(std::is_same<T, bf16>::value ? QK_BF16 : QK_F16, w, wqs, Cq, F, transposed ? 1 : 0, neg_ijk ? 1 : 0, sm, stream)) return rc;
+                const long long tot = (long long)g.taps * g.Qp * 4 * g.Jp;
+                hipLaunchKernelGGL((k_prep_w16<T>), dim3((unsigned)((tot + 255) / 256 > 2048 ? 2048 : (tot + 255) / 256)), dim3(256), 0, stream, w, wq, g.taps, Cq, F, transposed ? 1 : 0, neg_ijk ? 1 : 0);
+                if (hipGetLastError() != hipSuccess) return QK_ERR_LAUNCH;
+                g.w_prepped = 1;
+            }
             const bool post_ok = (g.post.kind == 0 || g.post.kind == 2) && !g.pre_out && !g.dalpha &&
                                  (g.post.kind == 0 || g.post_fwd || g.ep_mask) && !(reinterpret_cast<uintptr_t>(out) & 7) &&
                                  !(reinterpret_cast<uintptr_t>(g.ep_mask) & 7) && !(reinterpret_cast<uintptr_t>(bias) & 15);
@@ -1383,13 +1395,9 @@ int go16(const void *in, const void *mask, const float *w, const float *bias, vo
                 fastdiv_of((unsigned)bg.osp[0], &bg.dv_mul[2], &bg.dv_shr[2]);
                 bg.sign_tbl = kSignConj;
                 bg.ablate = g.ablate;
-                if (!g.w_prepped) {
-                    if (int rc = launch_prep_small16(sizeof(T) == 2 && std::is_same<T, bf16>::value ? QK_BF16 : QK_F16, w, wq, Cq, F, transposed ? 1 : 0, neg_ijk ? 1 : 0, sm, stream)) return rc;
-                }
-                const int r = launch_hconv16_small(std::is_same<T, bf16>::value ? QK_BF16 : QK_F16, in, wq, bias, out, bg, sm, stream);
+                const int r = launch_hconv16_small(std::is_same<T, bf16>::value ? QK_BF16 : QK_F16, in, wqs, bias, out, bg, sm, stream);
                 if (r != 0) { if (r > 0) note_path(QK_PATH_MFMA16_SMALL); return r; }
             }
-            g.w_prepped = 0;                          // (the cache holds the small-channel layout: the band form below lays its own out)
         }
     }
     if (padded && ((debug_flags() & kDbgNoBand16) || !band_geom(g, 2, &bg))) return 0;
@@ -1484,8 +1492,8 @@ int try_hgemm_16(int dtype, const void *in, const void *mask, const float *w_f32
     if (!ws || ws_bytes < need) return 0;
     if ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(ws) | reinterpret_cast<uintptr_t>(mask)) & 15) return 0;
     if (debug_flags() & kDbgNoMfma16) return 0;                        // diagnostic switch
-    if (dtype == QK_BF16) return go16<bf16>(in, mask, w_f32, bias, out, g, w_is_transposed, ws, stream);
-    return go16<f16>(in, mask, w_f32, bias, out, g, w_is_transposed, ws, stream);
+    if (dtype == QK_BF16) return go16<bf16>(in, mask, w_f32, bias, out, g, w_is_transposed, ws, ws_bytes, stream);
+    return go16<f16>(in, mask, w_f32, bias, out, g, w_is_transposed, ws, ws_bytes, stream);
 }
 
 }  // namespace qk

@@ -158,17 +158,22 @@ class _Call(object):
             c = L.ConvDesc.from_buffer_copy(d)
         return c, (L.QK_OP_FWD if op == L.QK_OP_FWD else L.QK_OP_BWD_DATA)
 
-    def _kernel_only_bytes(self):
-        """Size of the workspace when it holds NOTHING but the re-laid-out 16-bit kernel (+ its zero line); 0 for
-        fp32 and for channels_first descriptors (their workspace also carries re-laid-out operands)."""
+    def _kernel_only_bytes(self, op):
+        """Size of operation `op`'s workspace when it holds NOTHING but the re-laid-out 16-bit kernel (band layout + zero line,
+        and for 16 / 32-channel layers the small-channel kernel's fragment layout behind it); 0 for fp32 and for
+        channels_first descriptors (their workspace also carries re-laid-out operands).  The library is asked, never a formula
+        restated here: the forward / backward-data figure IS the kernel-only size for such descriptors."""
         d = self.desc
         if d.dtype == L.QK_F32 or getattr(d, 'layout', L.QK_CH_LAST) != L.QK_CH_LAST:
             return 0
         cq, fq = (d.in_q, d.q_units) if isinstance(d, L.DenseDesc) else (d.cq, d.fq)
         if cq % 16 or fq % 16:
             return 0            # off the matrix-core path: the fp32-MFMA kernels never read the workspace -- nothing to cache or refresh
-        taps = int(math.prod(self.w_shape)) // (cq * 4 * fq)
-        return taps * ((cq + 31) // 32 * 32) * 4 * ((fq + 31) // 32 * 32) * 2 + 256       # (zero-padded to the kernels' 32-channel granule)
+        kop = L.QK_OP_FWD if op == L.QK_OP_FWD else L.QK_OP_BWD_DATA
+        n = self._ws_bytes.get(('k', kop))
+        if n is None:
+            n = self._ws_bytes[('k', kop)] = int(getattr(L.lib(), self.ws_fn)(ctypes.byref(self.desc), kop))
+        return n
 
     def _ws(self, op, like, wparam=None):
         """Workspace of operation `op`.  `wparam`: the PARAMETER the kernel argument is (a long-lived leaf tensor).  When the
@@ -184,7 +189,7 @@ class _Call(object):
         self.desc.ws_has_kernel = 0
         if n == 0:
             return None, 0
-        if (wparam is not None and not self.static_buffers and n == self._kernel_only_bytes() and wparam.is_leaf
+        if (wparam is not None and not self.static_buffers and n == self._kernel_only_bytes(op) and wparam.is_leaf
                 and wparam.requires_grad and _PREP_CACHE_ON):
             key = ('f' if op == L.QK_OP_FWD else 't', int(self.desc.conj) if hasattr(self.desc, 'conj') else 1, int(self.desc.dtype))
             cache = wparam.__dict__.setdefault('_qk_prep', {})
@@ -1033,7 +1038,7 @@ class _WeightedSumFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        return (ctx.wt * g.to(ctx.wt.dtype)).view(ctx.a_shape), None          # (w may have a's element count in another shape)
+        return (ctx.wt * g.to(ctx.wt.dtype)).reshape(ctx.a_shape), None          # (w may have a's element count in another shape)
 
 
 def weighted_sum(a, w):

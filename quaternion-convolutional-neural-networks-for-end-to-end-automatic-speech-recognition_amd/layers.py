@@ -10,12 +10,12 @@ torch ops with the Keras/TensorFlow semantics the models rely on (SURVEY.md 8f r
     (B, 4F, 41, T) tensor this pools the 41-bin frequency axis 41 -> 14).
 """
 import math
-import os
 
 import numpy as np
 import torch
 import torch.nn.functional as F
 
+from . import _lib as L
 from . import functional as Fq
 from ._shape import normalize_tuple, tf_pads
 from .keras_like import Layer, activations, initializers, regularizers
@@ -147,7 +147,7 @@ class Dense(Layer):
         tall = (inputs.is_cuda and inputs.dtype in (torch.bfloat16, torch.float16) and self.kernel.dtype == torch.float32
                 and rows >= 8192 and rows % _TallDenseFn.SPLITS == 0 and inputs.is_contiguous())
         if (tall and activations.serialize(self.activation) == 'softmax' and self.units <= 64
-                and not os.environ.get('QK_NO_FUSED_SOFTMAX')):
+                and not L.dbg(L.QK_DBG_NO_FUSED_SOFTMAX)):
             y = _DenseSoftmaxFn.apply(inputs.reshape(rows, inputs.shape[-1]), self.kernel, self.bias)
             return y.reshape(tuple(inputs.shape[:-1]) + (self.units,))
         if tall:
@@ -331,7 +331,7 @@ def ctc_batch_cost(y_pred, labels, input_length, label_length, blank=None, loss_
     LOGITS, and that op normalises them again (softmax), so the log-probabilities are
     log_softmax(log(y_pred + 1e-7)); ctc_merge_repeated=True, no collapse of repeated labels (TF defaults).
     loss_scale: multiplies the gradient sent back (not the cost): float16 training, see functional.ctc_batch_cost."""
-    if (blank is None and y_pred.is_cuda and Fq.ctc_supported(y_pred, labels) and not os.environ.get('QK_NO_FUSED_CTC')):
+    if (blank is None and y_pred.is_cuda and Fq.ctc_supported(y_pred, labels) and not L.dbg(L.QK_DBG_NO_FUSED_CTC)):
         return Fq.ctc_batch_cost(y_pred, labels, input_length, label_length, loss_scale=loss_scale)        # one HIP launch: cost + gradient
     blank = y_pred.shape[-1] - 1 if blank is None else blank
     yp = y_pred.float()

@@ -7,10 +7,10 @@ n/2 convs of 2*sf filters (PReLU + Dropout after each) -> Permute/reshape to (B,
 `d` is the reference's attribute bag (num_layers, start_filter, act, aact, dropout, l2, model,
 quat_init); only the quaternion branch (`d.model == 'quaternion'`) is built.
 """
-import os
 
 import torch
 
+from .. import _lib as L
 from ..complexnn import QuaternionConv2D, QuaternionDense
 from ..keras_like import Layer, regularizers
 from ..layers import Dense, Dropout, MaxPooling2D, PReLU, TimeDistributed, ctc_batch_cost
@@ -32,7 +32,7 @@ class TimitQCNN(torch.nn.Module):
         self.aact, self.rate, self.act = aact, dropout, act
         self.fuse_head = fuse_head          # first TimeDistributed dense as an (F, 1) convolution (no transpose copy)
         self.chain_convs = (chain_convs and internal_layout == 'channels_last'      # body convs as one autograd node
-                            and not os.environ.get('QK_NO_CONV_CHAIN'))
+                            and not L.dbg(L.QK_DBG_NO_CONV_CHAIN))
         self.conv = QuaternionConv2D(sf, (3, 5), name='conv', **conv_args)
         self.pool = MaxPooling2D(pool_size=(1, 3), padding='same')
         widths = [sf] * (n // 2) + [2 * sf] * (n // 2)
@@ -85,12 +85,12 @@ class TimitQCNN(torch.nn.Module):
     def forward(self, x):
         self._dev = x.device
         fusable = self.chain_convs and x.is_cuda and x.dtype in (torch.bfloat16, torch.float16, torch.float32)
-        if self.prelu is not None and fusable and not os.environ.get('QK_NO_FUSED_PRELU'):
+        if self.prelu is not None and fusable and not L.dbg(L.QK_DBG_NO_FUSED_PRELU):
             return self._forward_fused_post(x)
         # aact == 'none': relu layers with Dropout(d.dropout) behind every body convolution and the first two dense
         # layers (interspeech_model.py:117-121,131-137,150-154) -- relu + dropout fused into the producing kernels
         if (self.prelu is None and self.act == 'relu' and self.training and self.rate > 0 and fusable
-                and not os.environ.get('QK_NO_FUSED_DROPOUT')):
+                and not L.dbg(L.QK_DBG_NO_FUSED_DROPOUT)):
             return self._forward_fused_post(x)
         o = self._first_layer_fused(x) if self.prelu is None else None
         if o is None:
@@ -129,7 +129,7 @@ class TimitQCNN(torch.nn.Module):
         from .. import functional as Fq
         from ..keras_like import activations
         c, pl = self.conv, self.pool
-        if os.environ.get('QK_NO_FUSED_FIRST') or not x.is_cuda or x.dim() != 4:
+        if L.dbg(L.QK_DBG_NO_FUSED_FIRST) or not x.is_cuda or x.dim() != 4:
             return None
         if not c.built:
             c._build_device = x.device
@@ -179,7 +179,7 @@ class TimitQCNN(torch.nn.Module):
         xl, lay = (x, 'channels_first') if x.is_contiguous() else (x.movedim(1, -1), 'channels_last')   # see _first_layer_fused
         o = self._first_layer_fused(x) if relu_form else None
         fused_first = (not relu_form and
-                       not os.environ.get('QK_NO_FUSED_FIRST') and x.dim() == 4 and c.padding == 'same' and c.strides == (1, 1) and
+                       not L.dbg(L.QK_DBG_NO_FUSED_FIRST) and x.dim() == 4 and c.padding == 'same' and c.strides == (1, 1) and
                        c.dilation_rate == (1, 1) and c.internal_layout == 'channels_last' and pl.pool_size == (1, 3) and
                        pl.strides == (1, 3) and pl.padding == 'same' and pl.data_format == 'channels_last' and
                        Fq.conv_prelu_pool_supported(xl, c.kernel, post0['alpha'], post0['alpha_axis'], 3, lay))
@@ -208,7 +208,7 @@ class TimitQCNN(torch.nn.Module):
         layers.append((w, dl.bias, dict(strides=1, padding='valid', dilation_rate=1, activation=None, conj=True,
                                         post=self._post(k, (shape[0], shape[3], dl.r.shape[-1])))))
         k += 1
-        if relu_form and not os.environ.get('QK_NO_DENSE_IN_CHAIN'):
+        if relu_form and not L.dbg(L.QK_DBG_NO_DENSE_IN_CHAIN):
             # aact == 'none': the second and third TimeDistributed(QuaternionDense(256)) (interspeech_model.py:150-166) are links
             # of the SAME chain -- 1 x 1 conj-convolutions on the (B, 1, T, 256) tensor, relu (+ dropout behind the second) as the
             # producing kernel's post-op, its derivative in the consumer's backward-data epilogue: no separate activation /
@@ -322,10 +322,14 @@ class TimitQCNN(torch.nn.Module):
 
     def training_loss(self, x, labels, input_length, label_length, loss_scale=1.0):
         """What training the reference model minimises: mean CTC cost over the batch (the usual
-        `loss={'ctc': lambda y_true, y_pred: y_pred}` compile) + the regularisation terms (scaled like the CTC gradient, so
-        that ONE grad_scale in the optimiser undoes both)."""
+        `loss={'ctc': lambda y_true, y_pred: y_pred}` compile) + the regularisation terms.  loss_scale changes GRADIENTS only:
+        the regulariser goes through the same identity-forward / scaled-backward node as the CTC cost, so that ONE grad_scale in
+        the optimiser undoes both and the value returned (what gets logged) is the unscaled loss."""
         reg = self.regularization_loss()
-        return self.ctc_loss(x, labels, input_length, label_length, loss_scale=loss_scale).mean() + (reg * loss_scale if loss_scale != 1.0 else reg)
+        if loss_scale != 1.0:
+            from ..layers import _GradScale
+            reg = _GradScale.apply(reg, float(loss_scale))
+        return self.ctc_loss(x, labels, input_length, label_length, loss_scale=loss_scale).mean() + reg
 
 
 class _RealConv2D(Layer):

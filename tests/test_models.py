@@ -374,8 +374,10 @@ def test_tall_dense_split_reduction_matches_plain_autograd():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['fp32', 'bf16'])
-@pytest.mark.parametrize('shape', [(5, 30, 10, 6), (3, 27, 62, 9), (256, 200, 62, 50), (2, 300, 62, 20), (3, 160, 20, 70)],
-                         ids=['small', 'odd', 'timit_b256', 'long_lp_from_global', 'more_than_63_labels'])
+@pytest.mark.parametrize('shape', [(5, 30, 10, 6), (3, 27, 62, 9), (256, 200, 62, 50), (2, 300, 62, 20), (3, 160, 20, 70), (3, 40, 200, 8),
+                                   (2, 70, 256, 9)],
+                         ids=['small', 'odd', 'timit_b256', 'long_lp_from_global', 'more_than_63_labels', 'more_than_128_classes',
+                              'classes_256'])
 def test_fused_ctc_batch_cost_matches_the_keras_restatement(shape, dtype):
     """qk_ctc_batch_cost (K.ctc_batch_cost of interspeech_model.py:37-39 as one launch: cost and d cost / d y_pred) against the
     torch restatement of the Keras / TensorFlow op that the golden fixture G17 pins (layers.ctc_batch_cost with the fused path
@@ -396,17 +398,12 @@ def test_fused_ctc_batch_cost_matches_the_keras_restatement(shape, dtype):
     from qcnn_amd import _lib
     outs = {}
     for fused in (True, 'two_sweeps', False):
-        if not fused:
-            os.environ['QK_NO_FUSED_CTC'] = '1'
-        try:
-            with _lib.debug_flags(_lib.QK_DBG_CTC_TWO_SWEEPS if fused == 'two_sweeps' else 0):
-                p = pred.clone().requires_grad_(True)
-                cost = ctc_batch_cost(p, labels.to(dev), il, ll)
-                (cost * w).sum().backward()
-                torch.cuda.synchronize()
-            outs[fused] = (cost.detach().double().cpu(), p.grad.detach().double().cpu())
-        finally:
-            os.environ.pop('QK_NO_FUSED_CTC', None)
+        with _lib.debug_flags(_lib.QK_DBG_CTC_TWO_SWEEPS if fused == 'two_sweeps' else 0 if fused else _lib.QK_DBG_NO_FUSED_CTC):
+            p = pred.clone().requires_grad_(True)
+            cost = ctc_batch_cost(p, labels.to(dev), il, ll)
+            (cost * w).sum().backward()
+            torch.cuda.synchronize()
+        outs[fused] = (cost.detach().double().cpu(), p.grad.detach().double().cpu())
     (ct, gt) = outs[False]
     for form in (True, 'two_sweeps'):       # the concurrent-sweep kernel (round 4; long utterances fall back) and the round-3 form
         cf, gf = outs[form]
@@ -443,18 +440,15 @@ def test_fused_dense_softmax_output_layer_matches_float64(dtype):
         layer.kernel.mul_(20.0)                   # logits of order 1: a softmax that is not flat
         layer.bias.copy_(torch.randn(units, generator=g).to(dev) * 0.5)
     outs = {}
+    from qcnn_amd import _lib
     for fused in (True, False):
-        if not fused:
-            os.environ['QK_NO_FUSED_SOFTMAX'] = '1'
-        try:
+        with _lib.debug_flags(0 if fused else _lib.QK_DBG_NO_FUSED_SOFTMAX):
             xd = x.to(dev).requires_grad_(True)
             layer.zero_grad()
             y = layer(xd)
             loss = Fq.weighted_sum(y, tgt.to(dev)) if fused else (y.float() * tgt.to(dev)).sum()
             loss.backward()
             outs[fused] = [t.detach().double().cpu() for t in (y, loss, xd.grad, layer.kernel.grad, layer.bias.grad)]
-        finally:
-            os.environ.pop('QK_NO_FUSED_SOFTMAX', None)
     w64 = layer.kernel.detach().to(dtype).double().cpu().requires_grad_(True)      # the GEMMs multiply the 16-bit image of the kernel
     b64 = layer.bias.detach().double().cpu().requires_grad_(True)
     x64 = x.double().requires_grad_(True)
@@ -633,6 +627,17 @@ def test_real_branch_of_getTimitModel2D_builds_and_trains_on_cpu():
     loss = m.training_loss(x, labels, il, ll)
     loss.backward()
     assert torch.isfinite(loss) and all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+    # loss_scale (float16 training) moves GRADIENTS only, of the CTC term and of the l2 term alike: the value returned -- what a
+    # training loop logs -- is the unscaled loss (round-5 advisor: the regulariser used to be scaled in its value)
+    ps = list(m.parameters())
+    torch.manual_seed(5)
+    l1 = m.training_loss(x, labels, il, ll)
+    g1 = torch.autograd.grad(l1, ps)
+    torch.manual_seed(5)
+    l2 = m.training_loss(x, labels, il, ll, loss_scale=4096.0)
+    g2 = torch.autograd.grad(l2, ps)
+    assert float(l1) == float(l2) and float(m.regularization_loss()) > 0
+    assert all(torch.allclose(b, a * 4096.0, rtol=1e-4, atol=0) for a, b in zip(g1, g2))
     with pytest.raises(ValueError):
         getTimitModel2D(types.SimpleNamespace(model='complex', num_layers=2, start_filter=4, act='relu', aact='none', dropout=0.0))
 
