@@ -408,10 +408,27 @@ int qk_ctc_batch_cost(int32_t dtype, int32_t batch, int32_t frames, int32_t clas
  *   fwd   y = softmax(logits + bias)          logits: fp32 (the GEMM's fp32 output), bias: fp32 or NULL, y: `dtype`
  *   bwd   dlogits = y * (dy - sum_j dy_j y_j)   (dtype; the operand of the layer's two gradient GEMMs)
  *         dbias[j] += sum over rows of dlogits  (fp32, ACCUMULATED: the caller zeroes it or hands in a gradient buffer; NULL = skip)
- * The Dense(62) GEMMs themselves are plain library GEMMs; these two launches replace the ~25 elementwise / reduction
- * launches a framework spends around them. */
+ * (Round 6: the model's output layer runs qk_dense_softmax_fwd / _bwd below; these two remain for callers that bring their own
+ * logits -- the A/B composition behind QK_DBG_NO_FUSED_SOFTMAX.) */
 int qk_softmax_rows_fwd(int32_t dtype, int64_t rows, int32_t cols, const float *logits, const float *bias, void *y, void *stream);
 int qk_softmax_rows_bwd(int32_t dtype, int64_t rows, int32_t cols, const void *y, const void *dy, void *dlogits, float *dbias, void *stream);
+/* The whole output layer as ONE launch per direction (round 6; csrc/qk_out_layer.hip) -- keras Dense(units, activation='softmax') on
+ * the last axis of a (rows, in_dim) 16-bit matrix with fp32 master weights (models/interspeech_model.py:171-175 of the reference:
+ * TimeDistributed(Dense(62, activation='softmax')), 51 200 rows x 256 at B = 256):
+ *   fwd   y = softmax(x kernel + bias)                       x, y: `dtype` (QK_BF16 / QK_F16); kernel (in_dim, units), bias (units) fp32, bias may be NULL
+ *   bwd   dl = y * (dy - sum_j dy_j y_j);  dx = dl kernel^T  (dtype);
+ *         dkernel += x^T dl,  dbias += column sums of dl     (fp32, ACCUMULATED: the caller zeroes them or hands in gradient buffers; NULL = skip)
+ * The products run on v_mfma_f32_16x16x32 with fp32 accumulation on the 16-bit roundings of kernel and dl; the softmax sees fp32 logits.
+ * Supported: in_dim in {64, 128, 256}, 2 <= units <= 64 and even, 16-bit dtypes (qk_dense_softmax_supported; QK_ERR_UNSUPPORTED
+ * otherwise -- the caller composes the layer from its parts).  The backward's workspace (caller-owned, qk_dense_softmax_bwd_workspace_bytes
+ * for the CURRENT device; not needed when dkernel and dbias are both NULL) holds one slab of gradient partials per workgroup; a second
+ * small launch sums the slabs in a fixed order: no float atomics, bit-repeatable gradients without QK_DBG_DETERMINISTIC. */
+int qk_dense_softmax_supported(int32_t dtype, int64_t rows, int32_t in_dim, int32_t units);
+int qk_dense_softmax_fwd(int32_t dtype, int64_t rows, int32_t in_dim, int32_t units, const void *x, const float *kernel, const float *bias,
+                         void *y, void *stream);
+size_t qk_dense_softmax_bwd_workspace_bytes(int32_t dtype, int64_t rows, int32_t in_dim, int32_t units);
+int qk_dense_softmax_bwd(int32_t dtype, int64_t rows, int32_t in_dim, int32_t units, const void *x, const float *kernel, const void *y,
+                         const void *dy, void *dx, float *dkernel, float *dbias, void *workspace, size_t workspace_bytes, void *stream);
 /* *out += sum_i a[i] * w[i]  (a: `dtype`, w / out: fp32): a linear functional of the model output as one launch. */
 int qk_weighted_sum(int32_t dtype, int64_t n, const void *a, const float *w, float *out, void *stream);
 

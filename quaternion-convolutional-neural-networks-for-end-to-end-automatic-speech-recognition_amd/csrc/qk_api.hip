@@ -1075,6 +1075,40 @@ int qk_softmax_rows_bwd(int32_t dtype, int64_t rows, int32_t cols, const void *y
     return check_launch(launch_softmax_rows(dtype, true, y, dy, dlogits, dbias, rows, cols, (hipStream_t)stream), "qk_softmax_rows_bwd");
 }
 
+int qk_dense_softmax_supported(int32_t dtype, int64_t rows, int32_t in_dim, int32_t units)
+{
+    return dense_softmax_supported(dtype, rows, in_dim, units) ? 1 : 0;
+}
+
+int qk_dense_softmax_fwd(int32_t dtype, int64_t rows, int32_t in_dim, int32_t units, const void *x, const float *kernel, const float *bias,
+                         void *y, void *stream)
+{
+    if (!x || !kernel || !y || rows < 0) { set_error("qk_dense_softmax_fwd: NULL buffer or negative row count"); return QK_ERR_INVALID_ARG; }
+    if (!dense_softmax_supported(dtype, rows, in_dim, units)) { set_error("qk_dense_softmax_fwd: in_dim %d / units %d / dtype %d outside the kernel (in_dim 64, 128, 256; even units <= 64; 16-bit)", in_dim, units, dtype); return QK_ERR_UNSUPPORTED; }
+    if (!aligned(x, 16) || !aligned(y, 4) || !aligned(kernel, 4)) { set_error("qk_dense_softmax_fwd: x must be 16-byte aligned, y 4-byte"); return QK_ERR_INVALID_ARG; }
+    if (rows == 0) return QK_OK;
+    return check_launch(launch_dense_softmax_fwd(dtype, rows, in_dim, units, x, kernel, bias, y, (hipStream_t)stream), "qk_dense_softmax_fwd");
+}
+
+size_t qk_dense_softmax_bwd_workspace_bytes(int32_t dtype, int64_t rows, int32_t in_dim, int32_t units)
+{
+    return dense_softmax_bwd_workspace_bytes(dtype, rows, in_dim, units);
+}
+
+int qk_dense_softmax_bwd(int32_t dtype, int64_t rows, int32_t in_dim, int32_t units, const void *x, const float *kernel, const void *y,
+                         const void *dy, void *dx, float *dkernel, float *dbias, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!x || !kernel || !y || !dy || !dx || rows < 0) { set_error("qk_dense_softmax_bwd: NULL buffer or negative row count"); return QK_ERR_INVALID_ARG; }
+    if (!dense_softmax_supported(dtype, rows, in_dim, units)) { set_error("qk_dense_softmax_bwd: in_dim %d / units %d / dtype %d outside the kernel (in_dim 64, 128, 256; even units <= 64; 16-bit)", in_dim, units, dtype); return QK_ERR_UNSUPPORTED; }
+    if (!aligned(x, 16) || !aligned(dx, 16) || !aligned(y, 4) || !aligned(dy, 4)) { set_error("qk_dense_softmax_bwd: x / dx must be 16-byte aligned, y / dy 4-byte"); return QK_ERR_INVALID_ARG; }
+    if (rows == 0) return QK_OK;
+    if (dkernel || dbias) {
+        const size_t need = dense_softmax_bwd_workspace_bytes(dtype, rows, in_dim, units);
+        if (!workspace || workspace_bytes < need || !aligned(workspace, 16)) { set_error("qk_dense_softmax_bwd needs %zu workspace bytes (16-byte aligned), got %zu", need, workspace_bytes); return QK_ERR_WORKSPACE; }
+    }
+    return check_launch(launch_dense_softmax_bwd(dtype, rows, in_dim, units, x, kernel, y, dy, dx, dkernel, dbias, static_cast<float *>(workspace), (hipStream_t)stream), "qk_dense_softmax_bwd");
+}
+
 int qk_weighted_sum(int32_t dtype, int64_t n, const void *a, const float *w, float *out, void *stream)
 {
     if (!a || !w || !out || n < 0 || dtype < QK_F32 || dtype > QK_F16) { set_error("qk_weighted_sum: bad argument"); return QK_ERR_INVALID_ARG; }

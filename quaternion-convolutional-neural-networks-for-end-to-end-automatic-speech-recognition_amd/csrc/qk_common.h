@@ -338,6 +338,12 @@ int launch_postop(int dtype, bool backward, const void *pre, const void *dy, voi
 int launch_softmax_rows(int dtype, bool backward, const void *a, const void *b, void *out, float *dbias, long long rows, int cols,
                         hipStream_t stream);
 int launch_weighted_sum(int dtype, const void *a, const float *w, float *out, long long n, hipStream_t stream);
+// Dense(units, softmax) on a 16-bit (rows, K) matrix with fp32 master weights (qk_out_layer.hip)
+bool dense_softmax_supported(int dtype, long long rows, int K, int U);
+int launch_dense_softmax_fwd(int dtype, long long rows, int K, int U, const void *x, const float *w, const float *bias, void *y, hipStream_t stream);
+size_t dense_softmax_bwd_workspace_bytes(int dtype, long long rows, int K, int U);
+int launch_dense_softmax_bwd(int dtype, long long rows, int K, int U, const void *x, const float *w, const void *y, const void *dy, void *dx,
+                             float *dw, float *dbias, float *ws, hipStream_t stream);
 int launch_adam(float *p, float *g, float *m, float *v, const float *decay, size_t n, float lr, float b1,
                 float b2, float eps, int step, float gscale, bool zero_grad, hipStream_t stream, int *step_dev = nullptr);
 

@@ -1016,6 +1016,50 @@ def softmax_rows_bwd(y, dy, dbias=None):
     return dl
 
 
+def dense_softmax_supported(x, units):
+    """True when qk_dense_softmax_fwd / _bwd take softmax(x @ kernel + bias) for this 16-bit (rows, in_dim) device matrix."""
+    return (x.is_cuda and x.dim() == 2 and x.dtype in (torch.bfloat16, torch.float16) and x.is_contiguous()
+            and bool(L.lib().qk_dense_softmax_supported(_DTYPES[x.dtype], x.shape[0], x.shape[1], int(units))))
+
+
+def dense_softmax_fwd(x, kernel, bias):
+    """y = softmax(x @ kernel + bias) in ONE launch (include/qk.h: qk_dense_softmax_fwd): x (rows, in_dim) 16-bit, kernel (in_dim, units)
+    and bias (units) the fp32 master weights."""
+    _require_device(x, 'dense_softmax_fwd')
+    if kernel.dtype != torch.float32 or not kernel.is_contiguous() or kernel.dim() != 2 or kernel.shape[0] != x.shape[1] or kernel.device != x.device:
+        raise ValueError('dense_softmax_fwd: kernel must be a contiguous fp32 (in_dim, units) device tensor')
+    if bias is not None and (bias.dtype != torch.float32 or bias.numel() != kernel.shape[1] or not bias.is_contiguous() or bias.device != x.device):
+        raise ValueError('dense_softmax_fwd: bias must be a contiguous fp32 device tensor with one entry per unit')
+    x = x.contiguous()
+    y = torch.empty((x.shape[0], kernel.shape[1]), dtype=x.dtype, device=x.device)
+    with _on_device(x.device):
+        rc = L.lib().qk_dense_softmax_fwd(_DTYPES[x.dtype], x.shape[0], x.shape[1], kernel.shape[1], _ptr(x), _ptr(kernel), _ptr(bias), _ptr(y), _stream(x))
+    L.check(rc, 'qk_dense_softmax_fwd')
+    return y
+
+
+def dense_softmax_bwd(x, kernel, y, dy, dkernel, dbias):
+    """dx (returned) of y = softmax(x @ kernel + bias); the kernel / bias gradients are ADDED to the fp32 buffers `dkernel` /
+    `dbias` (None: not computed) -- qk_dense_softmax_bwd, one launch."""
+    _require_device(x, 'dense_softmax_bwd')
+    if dy.dtype != y.dtype or dy.shape != y.shape or y.dtype != x.dtype or y.device != x.device or dy.device != x.device:
+        raise ValueError('dense_softmax_bwd: y / dy must match each other and x in dtype and device')
+    for name, t, n in (('dkernel', dkernel, kernel.numel()), ('dbias', dbias, kernel.shape[1])):
+        if t is not None and (t.dtype != torch.float32 or t.numel() != n or not t.is_contiguous() or t.device != x.device):
+            raise ValueError('dense_softmax_bwd: %s must be a contiguous fp32 device tensor of %d elements' % (name, n))
+    x, y, dy = x.contiguous(), y.contiguous(), dy.contiguous()
+    dx = torch.empty_like(x)
+    with _on_device(x.device):
+        ws, n = None, 0
+        if dkernel is not None or dbias is not None:
+            n = int(L.lib().qk_dense_softmax_bwd_workspace_bytes(_DTYPES[x.dtype], x.shape[0], x.shape[1], kernel.shape[1]))
+            ws = torch.empty(n, dtype=torch.uint8, device=x.device)           # (the caching allocator hands the same block back every step)
+        rc = L.lib().qk_dense_softmax_bwd(_DTYPES[x.dtype], x.shape[0], x.shape[1], kernel.shape[1], _ptr(x), _ptr(kernel), _ptr(y), _ptr(dy),
+                                          _ptr(dx), _ptr(dkernel), _ptr(dbias), _ptr(ws), n, _stream(x))
+    L.check(rc, 'qk_dense_softmax_bwd')
+    return dx
+
+
 class _WeightedSumFn(torch.autograd.Function):
     """sum(a * w) for a 16-bit / fp32 device tensor `a` and a CONSTANT fp32 weight tensor `w` as one launch (qk_weighted_sum);
     the backward hands back w in a's dtype (cast once, kept on the weight tensor)."""

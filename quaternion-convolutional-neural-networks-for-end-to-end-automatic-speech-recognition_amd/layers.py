@@ -83,37 +83,57 @@ def _cast_cached(w, dtype):
 
 class _DenseSoftmaxFn(torch.autograd.Function):
     """softmax(x @ W + b) for MANY rows of a 16-bit device tensor and fp32 master weights -- the model's output layer,
-    TimeDistributed(Dense(62, activation='softmax')) on 51 200 rows (interspeech_model.py:171-175) -- in three launches
-    forward (kernel cast when stale, one library GEMM with fp32 output, qk_softmax_rows_fwd: bias + softmax from the fp32
-    logits) and four backward (qk_softmax_rows_bwd: d logits + the bias gradient, one GEMM for dx, the split GEMM + sum of
-    _TallDenseFn for the kernel gradient) instead of ~35 framework launches (16-bit bias add, softmax forward / backward,
-    reductions, fills).  The softmax sees fp32 logits (the unfused path rounds them to 16 bits first)."""
+    TimeDistributed(Dense(62, activation='softmax')) on 51 200 rows (interspeech_model.py:171-175) -- as ONE hand-written launch per
+    direction (round 6: qk_dense_softmax_fwd / _bwd, csrc/qk_out_layer.hip): forward reads the fp32 master kernel itself (no 16-bit
+    copy, no cast launch) and the softmax sees fp32 logits; backward forms d logits, d x, and ADDS the kernel and bias gradients
+    into fp32 buffers -- the parameters' own gradient views when they live in a dp.FlatParams buffer.  Until round 6: a library GEMM
+    with fp32 logits + qk_softmax_rows_fwd forward, qk_softmax_rows_bwd + two library GEMMs + a reduction backward (7 launches,
+    the last hipBLASLt kernels of the step); that composition remains for widths the kernel does not take."""
 
     @staticmethod
     def forward(ctx, x, w, b):
+        ctx.fused = Fq.dense_softmax_supported(x, w.shape[1]) and w.is_contiguous() and (b is None or b.is_contiguous())
+        ctx.params = (w, b)
+        if ctx.fused:
+            y = Fq.dense_softmax_fwd(x, w.detach(), b.detach() if b is not None else None)
+            ctx.save_for_backward(x, w, y)
+            return y
         w16 = _cast_cached(w, x.dtype)
         logits = torch.mm(x, w16, out_dtype=torch.float32)
         y = Fq.softmax_rows_fwd(logits, b, x.dtype)
         ctx.save_for_backward(x, w16, y)
-        ctx.bias = b
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, w16, y = ctx.saved_tensors
-        b = ctx.bias
+        x, wk, y = ctx.saved_tensors
+        w, b = ctx.params
+        want_w = ctx.needs_input_grad[1]
         want_b = b is not None and ctx.needs_input_grad[2]
-        direct = want_b and getattr(b, '_qk_direct_grad', False) and b.grad is not None and b.grad.dtype == torch.float32
+        if ctx.fused:
+            direct = Fq._direct_grad(w, b, want_w, want_b) if want_w and (b is None or want_b) else None
+            if direct is not None:
+                dw, db = direct
+            else:
+                dw = torch.zeros(w.shape, dtype=torch.float32, device=y.device) if want_w else None
+                db = torch.zeros(b.shape, dtype=torch.float32, device=y.device) if want_b else None
+            dx = Fq.dense_softmax_bwd(x, wk.detach(), y, dy, dw, db)
+            if direct is not None:
+                Fq._grad_ready(w, b)              # the kernel added both gradients into the flat buffer itself
+                dw = db = None
+            return (dx if ctx.needs_input_grad[0] else None), dw, db
+        w16 = wk
+        direct_b = want_b and getattr(b, '_qk_direct_grad', False) and b.grad is not None and b.grad.dtype == torch.float32
         db = None
         if want_b:
-            db = b.grad if direct else torch.zeros(b.shape, dtype=torch.float32, device=y.device)
+            db = b.grad if direct_b else torch.zeros(b.shape, dtype=torch.float32, device=y.device)
         dl = Fq.softmax_rows_bwd(y, dy.contiguous(), db)
         dx = dl @ w16.t() if ctx.needs_input_grad[0] else None
         dw = None
-        if ctx.needs_input_grad[1]:
+        if want_w:
             s = _TallDenseFn.SPLITS
             dw = torch.bmm(x.view(s, -1, x.shape[1]).transpose(1, 2), dl.view(s, -1, dl.shape[1]), out_dtype=torch.float32).sum(0)
-        if direct:
+        if direct_b:
             Fq._grad_ready(b)                 # the kernel added the bias gradient into the flat buffer itself
             db = None
         return dx, dw, db
@@ -146,10 +166,13 @@ class Dense(Layer):
         rows = inputs.numel() // max(inputs.shape[-1], 1)
         tall = (inputs.is_cuda and inputs.dtype in (torch.bfloat16, torch.float16) and self.kernel.dtype == torch.float32
                 and rows >= 8192 and rows % _TallDenseFn.SPLITS == 0 and inputs.is_contiguous())
-        if (tall and activations.serialize(self.activation) == 'softmax' and self.units <= 64
+        if (inputs.is_cuda and inputs.dtype in (torch.bfloat16, torch.float16) and self.kernel.dtype == torch.float32 and rows > 0
+                and inputs.is_contiguous() and activations.serialize(self.activation) == 'softmax' and self.units <= 64
                 and not L.dbg(L.QK_DBG_NO_FUSED_SOFTMAX)):
-            y = _DenseSoftmaxFn.apply(inputs.reshape(rows, inputs.shape[-1]), self.kernel, self.bias)
-            return y.reshape(tuple(inputs.shape[:-1]) + (self.units,))
+            x2 = inputs.reshape(rows, inputs.shape[-1])
+            if tall or Fq.dense_softmax_supported(x2, self.units):       # (any row count on the hand-written kernels; the composition needs `tall`)
+                y = _DenseSoftmaxFn.apply(x2, self.kernel, self.bias)
+                return y.reshape(tuple(inputs.shape[:-1]) + (self.units,))
         if tall:
             out = _TallDenseFn.apply(inputs.reshape(rows, inputs.shape[-1]), self.kernel, self.bias)
             return self.activation(out.reshape(tuple(inputs.shape[:-1]) + (self.units,)))
