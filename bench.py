@@ -66,6 +66,12 @@ WORKLOADS = {
     # BASELINE.json configs[4] body layer: Cq = F = 256, fp16, 32 samples per GPU
     'cfg5_body_qconv2d_b32_fp16': dict(kind='conv', rank=2, batch=32, spatial=(14, 200), cq=256, filters=256,
                                        kernel=(3, 5), dtype='fp16'),
+    # layer-level workloads for the counter passes (tools/gpu_traffic.sh): the start_filter = 16 model's body layers, and the TIMIT head
+    # (TimeDistributed(QuaternionDense(256)) on the (B, 14, T, 256) body output run as an (F, 1) 'valid' conj convolution)
+    'sf16_16to16_qconv2d_b256_bf16': dict(kind='conv', rank=2, batch=256, spatial=(14, 200), cq=16, filters=16, kernel=(3, 5), dtype='bf16'),
+    'sf16_16to32_qconv2d_b256_bf16': dict(kind='conv', rank=2, batch=256, spatial=(14, 200), cq=16, filters=32, kernel=(3, 5), dtype='bf16'),
+    'cfg3_head_qconv2d_b256_bf16': dict(kind='conv', rank=2, batch=256, spatial=(14, 200), cq=64, filters=64, kernel=(14, 1), dtype='bf16',
+                                        padding='valid', conj=True),
     # BASELINE.json configs[4] per-GPU stack: QuaternionConv2D 1 -> 256, 9 x (256 -> 256) (3,5) 'same' relu on (14, 200),
     # TimeDistributed(QuaternionDense(256)) head (in_q = 3584), fp16, 32 samples per GPU
     'cfg5_stack_b32_fp16': dict(kind='stack', batch=32, frames=200, freq=14, width=256, body=9, dtype='fp16'),
@@ -160,7 +166,7 @@ class ModelTrainStep(object):
     def _step_body(self):
         self.t += 1
         if self.loss == 'ctc':
-            loss = self.model.ctc_loss(self.x, self.labels, self.input_length, self.label_length).mean()
+            loss = self.model.ctc_mean_loss(self.x, self.labels, self.input_length, self.label_length)
         else:
             pred = self.model(self.x)
             loss = self.F.weighted_sum(pred, self.target)            # sum(pred * target): one launch each way
@@ -270,15 +276,16 @@ class LayerTrainStep(object):
         self.kernel, self.bias = kernel, bias
         self.m = torch.zeros_like(self.flat.param)
         self.v = torch.zeros_like(self.flat.param)
-        self.call = F.conv_call(tuple(self.x.shape), tuple(kernel.shape), dt, len(ks), 1, 'same',
-                                lay, 1, cfg.get('activation', 'relu'), True)
+        pad, conj = cfg.get('padding', 'same'), bool(cfg.get('conj', False))
+        self.call = F.conv_call(tuple(self.x.shape), tuple(kernel.shape), dt, len(ks), 1, pad,
+                                lay, 1, cfg.get('activation', 'relu'), True, conj)
         self.call.static_buffers = True
         # bwd-data on the masked gradient bwd-weight leaves behind (no second pass over y)
         self.relu = cfg.get('activation', 'relu') == 'relu'
         self.diag_mask_in_bwd_data = bool(os.environ.get('QK_DIAG_MASK_IN_BWD_DATA'))
         self.acc_grads = not os.environ.get('QK_BENCH_FILL_GRADS')     # diagnostic: the fill-per-step form
-        self.call_lin = F.conv_call(tuple(self.x.shape), tuple(kernel.shape), dt, len(ks), 1, 'same',
-                                    lay, 1, 'linear', True)
+        self.call_lin = F.conv_call(tuple(self.x.shape), tuple(kernel.shape), dt, len(ks), 1, pad,
+                                    lay, 1, 'linear', True, conj)
         self.call_lin.static_buffers = True
         self.y = torch.empty(self.call.y_shape, dtype=dt, device=dev)
         self.dy = torch.randn(self.call.y_shape, device=dev, generator=gen).to(dt)
@@ -287,7 +294,7 @@ class LayerTrainStep(object):
         self.dym = torch.empty(nb // self.dy.element_size(), dtype=dt, device=dev) if self.relu else None
         self.dw, self.db = self.flat.grad_view(0), self.flat.grad_view(1)
         self.t = 0
-        M = B * int(np.prod(sp))
+        M = int(np.prod(self.call.y_shape[:-1])) if not self.native else B * int(np.prod(sp))
         self.gemm = dict(M=M, N=4 * fq, K=int(np.prod(ks)) * 4 * cq)
         self.flops_per_kernel = 2.0 * M * 4 * fq * int(np.prod(ks)) * 4 * cq
 
@@ -626,8 +633,13 @@ def in_step_kernel_times(job, dev, peak, steps=3):
             # side tensor (3 bits per pooled element in 24-byte lane words: 7 tiles of 32 positions per 200-position line)
             pooled_rows = rows // 41 * 14
             nbytes = rows * 8 + pooled_rows * n * 2 + (pooled_rows + 199) // 200 * 7 * (n // 128) * 64 * 24
-            calls[-1].update({'hbm_bytes': nbytes, 'hbm_tb_s': nbytes / (mean * 1e-3) / 1e12, 'hbm_frac_of_8tb_s': nbytes / (mean * 1e-3) / 8e12,
-                              'bound': 'hbm (algorithmic bytes: x + pooled tensor + arg-max side tensor)'})
+            # round 6: the traffic the counters saw (profiles/pmc_traffic.json: FETCH_SIZE x 2 + WRITE_SIZE of the same kernel at this size,
+            # tools/gpu_traffic.sh FIRST=1) beside the algorithmic bytes; the HBM fraction is quoted on the COUNTER figure when there is one
+            ctr = pmc_traffic('first_layer', 'k_conv1_pool_fwd' if op == 'fwd' else 'k_conv1_pool_bwd') if (rows, n) == (256 * 41 * 200, 128) else None
+            used = ctr if ctr else nbytes
+            calls[-1].update({'hbm_bytes': nbytes, 'hbm_bytes_counters': ctr, 'hbm_tb_s': used / (mean * 1e-3) / 1e12,
+                              'hbm_frac_of_8tb_s': used / (mean * 1e-3) / 8e12,
+                              'bound': 'hbm (%s; algorithmic: x + pooled tensor + arg-max side tensor)' % ('bytes from FETCH_SIZE / WRITE_SIZE' if ctr else 'algorithmic bytes')})
     calls.sort(key=lambda c: -c['ms'] * c['calls_per_step'])
     return {'steps': steps, 'calls': calls, 'ms_per_step_in_calls': sum(c['ms'] * c['calls_per_step'] for c in calls),
             'timing': 'qk_prof_*: HIP events on the launch stream around each forward / backward-data / backward-weight call, '
@@ -1044,7 +1056,11 @@ def main():
                     t = k5['calls'][0]
                     blk['roofline'] = {'bound': 'mfma', 'kernel': '%s of the %d x %d x %d layer, in the step (%d calls per step x %.3f ms: largest share)'
                                                                    % (t['op'], t['rows'], t['n'], t['k'], t['calls_per_step'], t['ms']),
-                                       'achieved': t['tflops'], 'peak': PEAK_TFLOPS['fp16'], 'unit': 'TFLOP/s', 'frac': t['frac_of_peak'], 'traffic': None,
+                                       'achieved': t['tflops'], 'peak': PEAK_TFLOPS['fp16'], 'unit': 'TFLOP/s', 'frac': t['frac_of_peak'],
+                                       'traffic': pmc_traffic('cfg5_body_qconv2d_b32_fp16', {'fwd': 'fwd', 'bwd_weight': 'bwd_weight_chain', 'bwd_data': 'bwd_data_chain'}[t['op']])
+                                                  if (t['rows'], t['n'], t['k']) == (89600, 1024, 15360) else None,
+                                       'traffic_note': 'counter bytes of the 256 -> 256 layer kernel (8 x its 375 MB of algorithmic bytes: four column blocks and eight channel chunks '
+                                                       're-stream bands and kernel tiles through a 4 MB L2; the kernel stays MFMA-bound at 2.2 TB/s)',
                                        'flops_per_launch': 2.0 * t['rows'] * t['n'] * t['k'], 'avg_launch_ms': t['ms']}
                     if tele5 and tele5.get('mean_sclk_mhz'):
                         blk['roofline']['sustained_clock_mhz'] = tele5['mean_sclk_mhz']

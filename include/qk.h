@@ -416,7 +416,9 @@ int qk_softmax_rows_bwd(int32_t dtype, int64_t rows, int32_t cols, const void *y
  * the last axis of a (rows, in_dim) 16-bit matrix with fp32 master weights (models/interspeech_model.py:171-175 of the reference:
  * TimeDistributed(Dense(62, activation='softmax')), 51 200 rows x 256 at B = 256):
  *   fwd   y = softmax(x kernel + bias)                       x, y: `dtype` (QK_BF16 / QK_F16); kernel (in_dim, units), bias (units) fp32, bias may be NULL
- *   bwd   dl = y * (dy - sum_j dy_j y_j);  dx = dl kernel^T  (dtype);
+ *   bwd   dl = s * y * (dy - sum_j dy_j y_j);  dx = dl kernel^T  (dtype);   s = (dy_scale_dev ? *dy_scale_dev : 1) * dy_scale -- a DEVICE
+ *         scalar (fp32; NULL = 1) times a host factor: lets a loss node hand over an unscaled d loss / d y and its upstream gradient
+ *         separately (the batch mean of qk_ctc_batch_cost: no elementwise pass over dy in between); applied in fp32;
  *         dkernel += x^T dl,  dbias += column sums of dl     (fp32, ACCUMULATED: the caller zeroes them or hands in gradient buffers; NULL = skip)
  * The products run on v_mfma_f32_16x16x32 with fp32 accumulation on the 16-bit roundings of kernel and dl; the softmax sees fp32 logits.
  * Supported: in_dim in {64, 128, 256}, 2 <= units <= 64 and even, 16-bit dtypes (qk_dense_softmax_supported; QK_ERR_UNSUPPORTED
@@ -428,7 +430,8 @@ int qk_dense_softmax_fwd(int32_t dtype, int64_t rows, int32_t in_dim, int32_t un
                          void *y, void *stream);
 size_t qk_dense_softmax_bwd_workspace_bytes(int32_t dtype, int64_t rows, int32_t in_dim, int32_t units);
 int qk_dense_softmax_bwd(int32_t dtype, int64_t rows, int32_t in_dim, int32_t units, const void *x, const float *kernel, const void *y,
-                         const void *dy, void *dx, float *dkernel, float *dbias, void *workspace, size_t workspace_bytes, void *stream);
+                         const void *dy, void *dx, float *dkernel, float *dbias, const float *dy_scale_dev, float dy_scale,
+                         void *workspace, size_t workspace_bytes, void *stream);
 /* *out += sum_i a[i] * w[i]  (a: `dtype`, w / out: fp32): a linear functional of the model output as one launch. */
 int qk_weighted_sum(int32_t dtype, int64_t n, const void *a, const float *w, float *out, void *stream);
 

@@ -119,7 +119,7 @@ SYMBOLS = {
     'qk_dense_softmax_supported': (ctypes.c_int, [I32, ctypes.c_int64, I32, I32]),
     'qk_dense_softmax_fwd': (ctypes.c_int, [I32, ctypes.c_int64, I32, I32, _VP, _VP, _VP, _VP, _VP]),
     'qk_dense_softmax_bwd_workspace_bytes': (ctypes.c_size_t, [I32, ctypes.c_int64, I32, I32]),
-    'qk_dense_softmax_bwd': (ctypes.c_int, [I32, ctypes.c_int64, I32, I32, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _SZ, _VP]),
+    'qk_dense_softmax_bwd': (ctypes.c_int, [I32, ctypes.c_int64, I32, I32, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, ctypes.c_float, _VP, _SZ, _VP]),
     'qk_weighted_sum': (ctypes.c_int, [I32, ctypes.c_int64, _VP, _VP, _VP, _VP]),
     'qk_maxpool2d_fwd': (ctypes.c_int, [_PD, _VP, _VP, _VP]),
     'qk_maxpool2d_bwd': (ctypes.c_int, [_PD, _VP, _VP, _VP, _VP]),

@@ -1096,7 +1096,8 @@ size_t qk_dense_softmax_bwd_workspace_bytes(int32_t dtype, int64_t rows, int32_t
 }
 
 int qk_dense_softmax_bwd(int32_t dtype, int64_t rows, int32_t in_dim, int32_t units, const void *x, const float *kernel, const void *y,
-                         const void *dy, void *dx, float *dkernel, float *dbias, void *workspace, size_t workspace_bytes, void *stream)
+                         const void *dy, void *dx, float *dkernel, float *dbias, const float *dy_scale_dev, float dy_scale,
+                         void *workspace, size_t workspace_bytes, void *stream)
 {
     if (!x || !kernel || !y || !dy || !dx || rows < 0) { set_error("qk_dense_softmax_bwd: NULL buffer or negative row count"); return QK_ERR_INVALID_ARG; }
     if (!dense_softmax_supported(dtype, rows, in_dim, units)) { set_error("qk_dense_softmax_bwd: in_dim %d / units %d / dtype %d outside the kernel (in_dim 64, 128, 256; even units <= 64; 16-bit)", in_dim, units, dtype); return QK_ERR_UNSUPPORTED; }
@@ -1106,7 +1107,7 @@ int qk_dense_softmax_bwd(int32_t dtype, int64_t rows, int32_t in_dim, int32_t un
         const size_t need = dense_softmax_bwd_workspace_bytes(dtype, rows, in_dim, units);
         if (!workspace || workspace_bytes < need || !aligned(workspace, 16)) { set_error("qk_dense_softmax_bwd needs %zu workspace bytes (16-byte aligned), got %zu", need, workspace_bytes); return QK_ERR_WORKSPACE; }
     }
-    return check_launch(launch_dense_softmax_bwd(dtype, rows, in_dim, units, x, kernel, y, dy, dx, dkernel, dbias, static_cast<float *>(workspace), (hipStream_t)stream), "qk_dense_softmax_bwd");
+    return check_launch(launch_dense_softmax_bwd(dtype, rows, in_dim, units, x, kernel, y, dy, dx, dkernel, dbias, dy_scale_dev, dy_scale, static_cast<float *>(workspace), (hipStream_t)stream), "qk_dense_softmax_bwd");
 }
 
 int qk_weighted_sum(int32_t dtype, int64_t n, const void *a, const float *w, float *out, void *stream)

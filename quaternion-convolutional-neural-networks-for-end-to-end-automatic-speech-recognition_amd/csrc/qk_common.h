@@ -343,7 +343,7 @@ bool dense_softmax_supported(int dtype, long long rows, int K, int U);
 int launch_dense_softmax_fwd(int dtype, long long rows, int K, int U, const void *x, const float *w, const float *bias, void *y, hipStream_t stream);
 size_t dense_softmax_bwd_workspace_bytes(int dtype, long long rows, int K, int U);
 int launch_dense_softmax_bwd(int dtype, long long rows, int K, int U, const void *x, const float *w, const void *y, const void *dy, void *dx,
-                             float *dw, float *dbias, float *ws, hipStream_t stream);
+                             float *dw, float *dbias, const float *dy_scale_dev, float dy_scale, float *ws, hipStream_t stream);
 int launch_adam(float *p, float *g, float *m, float *v, const float *decay, size_t n, float lr, float b1,
                 float b2, float eps, int step, float gscale, bool zero_grad, hipStream_t stream, int *step_dev = nullptr);
 

@@ -650,7 +650,33 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
     // pass by pass, right behind each pass's decode, below).  A line whose positions inside the tile are all padding columns may
     // add a tap nobody uses: its loads read zeros, nothing else changes.
     unsigned tile_ot = 0;
-    {
+    // Round 6: WAVE-UNIFORM LINE STATE (as k_wgrad16_band3 decodes its rows).  A band of BAND rows touches at most two padded lines
+    // when BAND <= WP (every TIMIT layer: 68 / 128 rows against 204 positions per line): the two lines' sample / outer coordinates,
+    // base offsets and outer-tap masks are decoded ONCE, in scalar registers; a thread's row then costs a compare, two selects and a
+    // multiply-add instead of three divisions by multiply, the tap-range arithmetic and the offset polynomial (~ 55 VALU per row,
+    // four rows per thread: 3.1 - 3.6 k of a 32-filter tile's 33 k cycles sat between the kernel's first instruction and its first
+    // band load, profiles/r05_phase_stamps.txt).  Bands that span more lines (short inner axes) keep the per-row decode.
+#ifndef QK_BAND_LINE_STATE
+#define QK_BAND_LINE_STATE 1
+#endif
+    const bool two_lines = QK_BAND_LINE_STATE && BAND <= WP;
+    int lb0 = 0, lb1 = 0, p_l0 = 0, p_l1 = 0x7fffffff;
+    unsigned lm0 = 0, lm1 = 0;
+    if (two_lines) {
+        const int last_p = min(p0 + BAND - 1, total_p - 1);
+        const int line_lo = fastdiv(p0, g.dv_mul[0], g.dv_shr[0]);
+        auto line_state = [&](int line, int &lb, unsigned &lm) {
+            const int l2 = fastdiv(line, g.dv_mul[1], g.dv_shr[1]), o1 = line - l2 * g.osp[1];
+            const int n = fastdiv(l2, g.dv_mul[2], g.dv_shr[2]), o0 = l2 - n * g.osp[0];
+            const int q0 = o0 * g.pa[0] + g.pc[0], q1 = o1 * g.pa[1] + g.pc[1];
+            lb = __builtin_amdgcn_readfirstlane(n * (int)g.in_sn + q0 * (int)g.in_ss[0] + q1 * (int)g.in_ss[1]);
+            lm = __builtin_amdgcn_readfirstlane(outer_tap_mask(q0, q1, g));
+        };
+        p_l0 = line_lo * WP;
+        if (line_lo < g.b_nlines) line_state(line_lo, lb0, lm0);
+        if (last_p >= p_l0 + WP && line_lo + 1 < g.b_nlines) { p_l1 = p_l0 + WP; line_state(line_lo + 1, lb1, lm1); }
+        tile_ot = lm0 | lm1;
+    } else {
         const int last_p = min(p0 + BAND - 1, total_p - 1);
         const int line_lo = fastdiv(p0, g.dv_mul[0], g.dv_shr[0]);
         const int line_hi = min(fastdiv(last_p, g.dv_mul[0], g.dv_shr[0]), g.b_nlines - 1);
@@ -666,6 +692,16 @@ k_hgemm16_band(const T *__restrict__ in, const uint4 *__restrict__ wq, const T *
         const int j = s_row + r * RPP;
         base_off[r] = 0; omask[r] = 0;
         const int P = p0 + j;
+        if (two_lines) {
+            // (rows past the tensor's last line: p_l1 stays out of reach or lm1 = 0 -- no tap, the DMA lane reads zeros)
+            const bool in1 = P >= p_l1;
+            const int col = P - (in1 ? p_l1 : p_l0) + g.b_cshift;
+            if (j < BAND && col >= 0 && col < g.isp[2] && (in1 || P < p_l0 + WP)) {
+                base_off[r] = (in1 ? lb1 : lb0) + col * (int)g.in_ss[2];
+                omask[r] = in1 ? lm1 : lm0;
+            }
+            return;
+        }
         const int line = fastdiv(P, g.dv_mul[0], g.dv_shr[0]);
         const int col = P - line * WP + g.b_cshift;
         if (j < BAND && line < g.b_nlines && col >= 0 && col < g.isp[2]) {

@@ -172,7 +172,8 @@ k_dense_softmax_fwd(const T *__restrict__ x, const float *__restrict__ w, const 
 template <typename T, int NW>
 __global__ void __launch_bounds__(NW * 64)
 k_dense_softmax_bwd(const T *__restrict__ x, const float *__restrict__ w, const T *__restrict__ y, const T *__restrict__ dy,
-                    T *__restrict__ dx, float *__restrict__ part, const long long rows, const int U)
+                    T *__restrict__ dx, float *__restrict__ part, const long long rows, const int U,
+                    const float *__restrict__ dy_scale_dev, const float dy_scale)
 {
     constexpr int K = NW * 64, NTHR = NW * 64;
     constexpr int XP = K * 2 + 32;                   // x tile row pitch in bytes: K / 2 + 8 dwords = 8 (mod 64) x odd for K = 64, 128, 256
@@ -215,6 +216,10 @@ k_dense_softmax_bwd(const T *__restrict__ x, const float *__restrict__ w, const 
     for (int q = 0; q < 8; ++q) dbp[q] = 0.f;
 
     const __amdgpu_buffer_rsrc_t rx = rsrc_o(x, (unsigned long long)rows * K * sizeof(T));
+    // dy enters multiplied by one number: a device scalar (the upstream gradient of a loss node that hands over d loss / d y
+    // unscaled -- the mean over the batch of K.ctc_batch_cost, layers._DenseSoftmaxCtcMeanFn) times a host factor (1 / batch x loss scale);
+    // d logits is linear in dy: applied to d logits in fp32, in front of its one rounding
+    const float sc = (dy_scale_dev ? *dy_scale_dev : 1.f) * dy_scale;
     const int l8 = tid & 7;
     const int np = (U + 1) / 2;                      // column pairs per row (U even on this path: the launcher checks)
     const long long n_blocks = (rows + 31) / 32;
@@ -257,7 +262,7 @@ k_dense_softmax_bwd(const T *__restrict__ x, const float *__restrict__ w, const 
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int p = l8 + 8 * q;
-                const unsigned d2 = pack2o(T(), lo16(T(), yv[rr][q]) * (lo16(T(), gv[rr][q]) - dot), hi16(T(), yv[rr][q]) * (hi16(T(), gv[rr][q]) - dot));
+                const unsigned d2 = pack2o(T(), sc * lo16(T(), yv[rr][q]) * (lo16(T(), gv[rr][q]) - dot), sc * hi16(T(), yv[rr][q]) * (hi16(T(), gv[rr][q]) - dot));
                 *reinterpret_cast<unsigned *>(ds + lrow * DP + 4 * p) = p < np ? d2 : 0u;       // (pairs 31 .. : the zero padding of the 64-wide tile)
                 dbp[2 * q] += lo16(T(), d2);         // the bias gradient is the column sum of what the MFMAs see
                 dbp[2 * q + 1] += hi16(T(), d2);
@@ -444,12 +449,12 @@ size_t dense_softmax_bwd_workspace_bytes(int dtype, long long rows, int K, int U
 }
 
 int launch_dense_softmax_bwd(int dtype, long long rows, int K, int U, const void *x, const float *w, const void *y, const void *dy, void *dx,
-                             float *dw, float *dbias, float *ws, hipStream_t stream)
+                             float *dw, float *dbias, const float *dy_scale_dev, float dy_scale, float *ws, hipStream_t stream)
 {
     if (!dense_softmax_supported(dtype, rows, K, U)) return QK_ERR_UNSUPPORTED;
     const int blocks = dense_softmax_bwd_grid(rows, K);
     float *part = (dw || dbias) ? ws : nullptr;
-#define QK_GO(TT, NW) do { hipLaunchKernelGGL((k_dense_softmax_bwd<TT, NW>), dim3((unsigned)blocks), dim3(NW * 64), 0, stream, (const TT *)x, w, (const TT *)y, (const TT *)dy, (TT *)dx, part, rows, U); \
+#define QK_GO(TT, NW) do { hipLaunchKernelGGL((k_dense_softmax_bwd<TT, NW>), dim3((unsigned)blocks), dim3(NW * 64), 0, stream, (const TT *)x, w, (const TT *)y, (const TT *)dy, (TT *)dx, part, rows, U, dy_scale_dev, dy_scale); \
         if (part) hipLaunchKernelGGL((k_dense_softmax_reduce<NW>), dim3(NW * 64 + 1), dim3(1024), 0, stream, part, blocks, dw, dbias, U); } while (0)
     if (dtype == QK_BF16) { if (K == 256) QK_GO(bf16, 4); else if (K == 128) QK_GO(bf16, 2); else QK_GO(bf16, 1); }
     else { if (K == 256) QK_GO(f16, 4); else if (K == 128) QK_GO(f16, 2); else QK_GO(f16, 1); }

@@ -1038,9 +1038,12 @@ def dense_softmax_fwd(x, kernel, bias):
     return y
 
 
-def dense_softmax_bwd(x, kernel, y, dy, dkernel, dbias):
+def dense_softmax_bwd(x, kernel, y, dy, dkernel, dbias, dy_scale_dev=None, dy_scale=1.0):
     """dx (returned) of y = softmax(x @ kernel + bias); the kernel / bias gradients are ADDED to the fp32 buffers `dkernel` /
-    `dbias` (None: not computed) -- qk_dense_softmax_bwd, one launch."""
+    `dbias` (None: not computed) -- qk_dense_softmax_bwd, one launch (+ the slab reduction).  dy enters multiplied by
+    `dy_scale_dev` (a one-element fp32 DEVICE tensor or None) x `dy_scale` (a Python float)."""
+    if dy_scale_dev is not None and (dy_scale_dev.dtype != torch.float32 or dy_scale_dev.numel() != 1 or dy_scale_dev.device != x.device):
+        raise ValueError('dense_softmax_bwd: dy_scale_dev must be a one-element fp32 tensor on the device of x')
     _require_device(x, 'dense_softmax_bwd')
     if dy.dtype != y.dtype or dy.shape != y.shape or y.dtype != x.dtype or y.device != x.device or dy.device != x.device:
         raise ValueError('dense_softmax_bwd: y / dy must match each other and x in dtype and device')
@@ -1055,7 +1058,7 @@ def dense_softmax_bwd(x, kernel, y, dy, dkernel, dbias):
             n = int(L.lib().qk_dense_softmax_bwd_workspace_bytes(_DTYPES[x.dtype], x.shape[0], x.shape[1], kernel.shape[1]))
             ws = torch.empty(n, dtype=torch.uint8, device=x.device)           # (the caching allocator hands the same block back every step)
         rc = L.lib().qk_dense_softmax_bwd(_DTYPES[x.dtype], x.shape[0], x.shape[1], kernel.shape[1], _ptr(x), _ptr(kernel), _ptr(y), _ptr(dy),
-                                          _ptr(dx), _ptr(dkernel), _ptr(dbias), _ptr(ws), n, _stream(x))
+                                          _ptr(dx), _ptr(dkernel), _ptr(dbias), _ptr(dy_scale_dev), float(dy_scale), _ptr(ws), n, _stream(x))
     L.check(rc, 'qk_dense_softmax_bwd')
     return dx
 
@@ -1123,6 +1126,27 @@ class _CtcFn(torch.autograd.Function):
             # the product is formed in fp32 and rounded once: d cost / d y can be ~1 / y, dcost ~1 / batch
             return (dpred.float() * (dcost.reshape(-1, 1, 1).float() * ctx.loss_scale)).to(dpred.dtype), None, None, None, None
         return dpred * dcost.reshape(-1, 1, 1).to(dpred.dtype), None, None, None, None
+
+
+def ctc_cost_and_grad(y_pred, labels, input_length, label_length):
+    """(cost (B,), d cost / d y_pred) of qk_ctc_batch_cost as plain tensors (no autograd node): for callers that chain the gradient
+    themselves (layers._DenseSoftmaxCtcMeanFn)."""
+    _require_device(y_pred, 'ctc_cost_and_grad')
+    y_pred = y_pred.contiguous()
+    b, t, c = y_pred.shape
+    lab = labels.to(device=y_pred.device, dtype=torch.int32).contiguous()
+    il = input_length.reshape(-1).to(device=y_pred.device, dtype=torch.int32).contiguous()
+    ll = label_length.reshape(-1).to(device=y_pred.device, dtype=torch.int32).contiguous()
+    lmax = lab.shape[1] if lab.dim() == 2 else 0
+    cost = torch.empty(b, dtype=torch.float32, device=y_pred.device)
+    dpred = torch.empty_like(y_pred)
+    n = int(L.lib().qk_ctc_workspace_bytes(b, t, lmax))
+    ws = torch.empty(n, dtype=torch.uint8, device=y_pred.device)
+    with _on_device(y_pred.device):
+        rc = L.lib().qk_ctc_batch_cost(_DTYPES[y_pred.dtype], b, t, c, _ptr(y_pred), _ptr(lab), lmax, _ptr(il), _ptr(ll), _ptr(cost),
+                                       _ptr(dpred), _ptr(ws), n, _stream(y_pred))
+    L.check(rc, 'qk_ctc_batch_cost')
+    return cost, dpred
 
 
 def ctc_supported(y_pred, labels):

@@ -139,6 +139,59 @@ class _DenseSoftmaxFn(torch.autograd.Function):
         return dx, dw, db
 
 
+class _DenseSoftmaxCtcMeanFn(torch.autograd.Function):
+    """mean over the batch of K.ctc_batch_cost(labels, softmax(x @ W + b), ...) -- the quantity training the reference model
+    minimises (interspeech_model.py:37-39,171-178 under the usual `loss={'ctc': lambda y_true, y_pred: y_pred}` compile) -- as ONE
+    autograd node: forward = qk_dense_softmax_fwd, qk_ctc_batch_cost (cost AND d cost / d y_pred), one reduction for the mean;
+    backward = qk_dense_softmax_bwd on the stored gradient, the upstream scalar handed over as a DEVICE pointer and 1 / batch
+    x loss_scale as a host factor.  As separate nodes the mean's backward, the broadcast and the 3.2 M-element product with the
+    upstream gradient were four framework launches between the CTC kernel and the output layer's backward."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, labels, input_length, label_length, batch, loss_scale):
+        y = Fq.dense_softmax_fwd(x, w.detach(), b.detach() if b is not None else None)
+        cost, dpred = Fq.ctc_cost_and_grad(y.view(batch, -1, y.shape[1]), labels, input_length, label_length)
+        ctx.save_for_backward(x, w, y, dpred)
+        ctx.params, ctx.scale = (w, b), float(loss_scale) / batch
+        return cost.mean()
+
+    @staticmethod
+    def backward(ctx, g):
+        x, wk, y, dpred = ctx.saved_tensors
+        w, b = ctx.params
+        want_w, want_b = ctx.needs_input_grad[1], b is not None and ctx.needs_input_grad[2]
+        direct = Fq._direct_grad(w, b, want_w, want_b) if want_w and (b is None or want_b) else None
+        if direct is not None:
+            dw, db = direct
+        else:
+            dw = torch.zeros(w.shape, dtype=torch.float32, device=y.device) if want_w else None
+            db = torch.zeros(b.shape, dtype=torch.float32, device=y.device) if want_b else None
+        g = g.detach().reshape(1).float()
+        dx = Fq.dense_softmax_bwd(x, wk.detach(), y, dpred.view(y.shape), dw, db, dy_scale_dev=g, dy_scale=ctx.scale)
+        if direct is not None:
+            Fq._grad_ready(w, b)
+            dw = db = None
+        return (dx if ctx.needs_input_grad[0] else None), dw, db, None, None, None, None, None
+
+
+def dense_softmax_ctc_mean(features, dense, labels, input_length, label_length, loss_scale=1.0):
+    """mean_b K.ctc_batch_cost(labels, TimeDistributed(dense)(features), input_length, label_length) for `features` (B, T, in_dim) and
+    a built softmax `Dense` layer, through _DenseSoftmaxCtcMeanFn when the hand-written kernels take the shapes; None otherwise (the
+    caller composes it from dense(features), ctc_batch_cost and .mean()).  loss_scale multiplies the gradient only."""
+    if (not features.is_cuda or features.dim() != 3 or not dense.built or dense.kernel.dtype != torch.float32
+            or activations.serialize(dense.activation) != 'softmax' or L.dbg(L.QK_DBG_NO_FUSED_SOFTMAX | L.QK_DBG_NO_FUSED_CTC)):
+        return None
+    b, t, k = features.shape
+    x2 = features.reshape(b * t, k)
+    if not (b > 0 and x2.is_contiguous() and Fq.dense_softmax_supported(x2, dense.units) and dense.kernel.is_contiguous()
+            and (dense.bias is None or dense.bias.is_contiguous())):
+        return None
+    # (functional.ctc_supported on the posteriors this node will produce)
+    if not (labels.dim() == 2 and labels.shape[1] <= 127 and (t + 8 * labels.shape[1] + 4 + 2 * dense.units + 4) * 4 <= 64 * 1024):
+        return None
+    return _DenseSoftmaxCtcMeanFn.apply(x2, dense.kernel, dense.bias, labels, input_length, label_length, b, float(loss_scale))
+
+
 class Dense(Layer):
     """keras.layers.Dense on the last axis (kernel (in, units), glorot_uniform by default)."""
 

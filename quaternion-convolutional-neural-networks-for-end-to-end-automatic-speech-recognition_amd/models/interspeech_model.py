@@ -120,6 +120,13 @@ class TimitQCNN(torch.nn.Module):
             k += 1
             if i < 2:
                 o = self.drop(o)
+        return self._pred(o)
+
+    def _pred(self, o):
+        """The output layer on the (B, T, 256) features -- or the features themselves while ctc_mean_loss collects them for the fused
+        output-layer + cost node."""
+        if getattr(self, '_features_only', False):
+            return o
         return self.pred(o)
 
     def _first_layer_fused(self, x):
@@ -223,7 +230,7 @@ class TimitQCNN(torch.nn.Module):
                 layers.append((dn.r, dn.bias, dict(activation=None, post=self._post(k, (shape[0], shape[3], width), dropout=(i < 2)))))
                 k += 1
             y = Fq.quaternion_conv_chain(o.movedim(1, -1), layers)              # (B, 1, T, units)
-            return self.pred(y.reshape(y.shape[0], y.shape[2], y.shape[3]))
+            return self._pred(y.reshape(y.shape[0], y.shape[2], y.shape[3]))
         y = Fq.quaternion_conv_chain(o.movedim(1, -1), layers)                  # (B, 1, T, units)
         o = y.reshape(y.shape[0], y.shape[2], y.shape[3])
         for i in (1, 2):
@@ -239,7 +246,7 @@ class TimitQCNN(torch.nn.Module):
                 h = Fq.quaternion_dense(o.reshape(b * t, o.shape[2]), dn.r, dn.bias, activation=None).reshape(b, t, -1)
                 o = Fq.prelu_dropout(h, po['alpha'], po['alpha_axis'], po['rate'], po['seed'])
             k += 1
-        return self.pred(o)
+        return self._pred(o)
 
     def _head_kernel(self, o_shape, device):
         """The first dense layer's weight r[(cq*F + f), :] viewed as the (F, 1, Cq, units) kernel of the
@@ -312,6 +319,28 @@ class TimitQCNN(torch.nn.Module):
         not; divide it out in the optimiser (functional.adam_step(grad_scale=1 / (world * loss_scale)))."""
         return ctc_batch_cost(self(x), labels, input_length, label_length, loss_scale=loss_scale)
 
+    def ctc_mean_loss(self, x, labels, input_length, label_length, loss_scale=1.0):
+        """mean over the batch of ctc_loss(...): what training minimises (the reference compiles the model with
+        `loss={'ctc': lambda y_true, y_pred: y_pred}`, i.e. the mean of the per-sample costs of interspeech_model.py:178).  Same value
+        and gradients as `self.ctc_loss(...).mean()`; on the device the output layer, the CTC cost and the mean are ONE autograd node
+        (layers.dense_softmax_ctc_mean: no framework launch between the CTC kernel and the output layer's backward)."""
+        from ..layers import dense_softmax_ctc_mean
+        dense = self.pred.layer
+        if x.is_cuda and x.dtype in (torch.bfloat16, torch.float16) and hasattr(self, '_pred'):
+            self._features_only = True
+            try:
+                feats = self(x)
+            finally:
+                self._features_only = False
+            if not dense.built:
+                dense._build_device = x.device
+                dense.build((None, feats.shape[-1]))
+            loss = dense_softmax_ctc_mean(feats, dense, labels, input_length, label_length, loss_scale) if feats.dim() == 3 else None
+            if loss is not None:
+                return loss
+            return ctc_batch_cost(self.pred(feats), labels, input_length, label_length, loss_scale=loss_scale).mean()
+        return self.ctc_loss(x, labels, input_length, label_length, loss_scale=loss_scale).mean()
+
     def regularization_loss(self):
         """Sum of the kernel regularisers (l2(d.l2) on every conv / dense kernel, interspeech_model.py:63,68,173):
         the term Keras adds to the compiled model's loss on top of the CTC cost."""
@@ -329,7 +358,7 @@ class TimitQCNN(torch.nn.Module):
         if loss_scale != 1.0:
             from ..layers import _GradScale
             reg = _GradScale.apply(reg, float(loss_scale))
-        return self.ctc_loss(x, labels, input_length, label_length, loss_scale=loss_scale).mean() + reg
+        return self.ctc_mean_loss(x, labels, input_length, label_length, loss_scale=loss_scale) + reg
 
 
 class _RealConv2D(Layer):
@@ -402,6 +431,7 @@ class TimitRealCNN(torch.nn.Module):
         return self.pred(o)
 
     ctc_loss = TimitQCNN.ctc_loss
+    ctc_mean_loss = TimitQCNN.ctc_mean_loss
     regularization_loss = TimitQCNN.regularization_loss
     training_loss = TimitQCNN.training_loss
 

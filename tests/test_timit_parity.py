@@ -386,6 +386,56 @@ def test_fp16_timit_step_under_ctc_matches_fp32_with_loss_scaling_and_underflows
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16], ids=['bf16', 'fp16'])
+def test_ctc_mean_loss_is_one_node_with_the_values_and_gradients_of_the_composition(dtype):
+    """TimitQCNN.ctc_mean_loss (round 6): the output layer (qk_dense_softmax_fwd / _bwd), K.ctc_batch_cost and the mean over the batch
+    (interspeech_model.py:37-39,171-178: what training minimises) as ONE autograd node whose backward hands the upstream scalar to the
+    output layer's backward as a device pointer.  Against `ctc_loss(...).mean()` -- separate nodes, the same kernels: identical value;
+    gradients equal up to one 16-bit rounding of d cost / d y (the fused node scales in fp32 inside the kernel) -- with an upstream
+    factor and a loss scale; infeasible samples (cost +inf) send nothing back in either form."""
+    dev = _dev()
+    model, xt, _ = _build(dev, torch.float32, 32, 4, 'none', 4, 40, seed=29, fuse_head=True, chain_convs=True)
+    rng = np.random.RandomState(7)
+    labels = torch.tensor(rng.randint(0, 61, (4, 10)), device=dev, dtype=torch.int32)
+    il = torch.full((4, 1), 40, dtype=torch.int32, device=dev)
+    ll = torch.tensor([[10], [7], [9], [4]], dtype=torch.int32, device=dev)
+    x = xt.to(dtype)
+    up, scale = 0.37, (256.0 if dtype == torch.float16 else 1.0)
+
+    def run(fused):
+        for p in model.parameters():
+            p.grad = None
+        loss = model.ctc_mean_loss(x, labels, il, ll, loss_scale=scale) if fused else model.ctc_loss(x, labels, il, ll, loss_scale=scale).mean()
+        (loss * up).backward()
+        torch.cuda.synchronize()
+        return float(loss), {n: p.grad.double().cpu().numpy() / (up * scale) for n, p in model.named_parameters() if p.grad is not None}
+    import qcnn_amd.layers as lay
+    calls = []
+    orig = lay._DenseSoftmaxCtcMeanFn.apply
+    lay._DenseSoftmaxCtcMeanFn.apply = staticmethod(lambda *a: (calls.append(1), orig(*a))[1])
+    try:
+        lf, gf = run(True)
+    finally:
+        lay._DenseSoftmaxCtcMeanFn.apply = orig
+    assert calls, 'ctc_mean_loss did not take the fused node on a 16-bit device model'
+    lu, gu = run(False)
+    assert lf == lu and np.isfinite(lf)
+    assert set(gf) == set(gu) and len(gf) >= 10
+    for k, w in gu.items():
+        nw = np.linalg.norm(w)
+        if nw == 0:
+            continue
+        e = np.linalg.norm(gf[k] - w) / nw
+        assert np.isfinite(gf[k]).all() and e <= (2e-2 if dtype == torch.bfloat16 else 4e-3), '%s: %.3g' % (k, e)
+    # an infeasible sample: both forms give +inf for the mean and finite (zero-contribution) gradients for the feasible rest
+    ll_bad = ll.clone()
+    il_bad = il.clone()
+    il_bad[1, 0] = 3                                         # 7 labels in 3 frames
+    lb = model.ctc_mean_loss(x, labels, il_bad, ll_bad)
+    assert torch.isinf(lb) and lb > 0
+
+
+@pytest.mark.gpu
 def test_full_b256_bf16_model_in_the_bench_form_meets_the_oracle_at_sampled_frames():
     """Round-4 verdict: "whole-model bf16 at B = 256 never meets the oracle in one piece".  The bench's model -- n = 10, sf = 32,
     relu + Dropout(0.3) fused into the producing kernels, training mode, (256, 4, 41, 200) bf16 channels_first input -- runs
