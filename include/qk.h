@@ -57,7 +57,7 @@
 extern "C" {
 #endif
 
-#define QK_VERSION 102 /* major*10000 + minor*100 + patch */
+#define QK_VERSION 103 /* major*10000 + minor*100 + patch */
 
 typedef enum {
     QK_OK = 0,
@@ -93,7 +93,18 @@ typedef struct {
                               * kernel an earlier call with the same descriptor, the same operation class (forward |
                               * backward-data / fused backward) and UNCHANGED weights left there: the call skips that
                               * step (one small launch per call; 26 per TIMIT training step).  0 = always safe.    */
+    int32_t kernel_order;    /* memory order of the compact kernel w / dw.  0 (QK_KERNEL_TAPS_MAJOR): (*kernel_size, cq, 4 fq), the
+                              * layer's own layout (conv.py:165).  1 (QK_KERNEL_CHANNEL_MAJOR, round 6): (cq, *kernel_size, 4 fq) -- the
+                              * weight of a QuaternionDense applied to the flattened (channel, position) axes of a channels-first feature
+                              * map, read IN PLACE as the kernel of the equivalent 'valid' convolution (the TIMIT model's first
+                              * TimeDistributed dense layer, models/interspeech_model.py:140-149: row cq * F + f of the dense weight is tap f,
+                              * channel cq): no permuted copy of the parameter per step, and the kernel gradient is accumulated straight
+                              * into the parameter's own layout.  Served by the 16-bit matrix-core kernels only (channels_last,
+                              * cq % 32 == 0, fq % 32 == 0, not a band / small-channel shape for backward-weight): QK_ERR_UNSUPPORTED
+                              * otherwise -- never a silent mis-read. */
 } qk_conv_desc_t;
+#define QK_KERNEL_TAPS_MAJOR 0
+#define QK_KERNEL_CHANNEL_MAJOR 1
 
 /* One quaternion dense call (QuaternionDense state, dense.py:58-124). */
 typedef struct {

@@ -14,6 +14,7 @@ QK_F32, QK_BF16, QK_F16 = 0, 1, 2
 QK_CH_LAST, QK_CH_FIRST = 0, 1
 QK_ACT_LINEAR, QK_ACT_RELU = 0, 1
 QK_OP_FWD, QK_OP_BWD_DATA, QK_OP_BWD_WEIGHT, QK_OP_BWD = 0, 1, 2, 3
+QK_KERNEL_TAPS_MAJOR, QK_KERNEL_CHANNEL_MAJOR = 0, 1            # qk_conv_desc_t.kernel_order
 QK_BWD_MASK_DX, QK_BWD_DY_PREMASKED, QK_BWD_ACCUMULATE = 1, 2, 4      # flags of qk_*_bwd_chain
 QK_DBG_NO_MFMA16, QK_DBG_NO_BAND16, QK_DBG_NO_BAND32, QK_DBG_WGRAD16_ONE_TAP, QK_DBG_BAND16_8WAVES = 1, 2, 4, 8, 16   # qk_set_debug_flags
 QK_DBG_NO_WGRAD_BAND = 32
@@ -35,7 +36,7 @@ class ConvDesc(ctypes.Structure):
     _fields_ = [('rank', I32), ('batch', I32), ('in_spatial', I32 * 3), ('out_spatial', I32 * 3),
                 ('cq', I32), ('fq', I32), ('kernel', I32 * 3), ('stride', I32 * 3),
                 ('dilation', I32 * 3), ('pad_lo', I32 * 3), ('layout', I32), ('dtype', I32),
-                ('activation', I32), ('has_bias', I32), ('conj', I32), ('ws_has_kernel', I32)]
+                ('activation', I32), ('has_bias', I32), ('conj', I32), ('ws_has_kernel', I32), ('kernel_order', I32)]
 
 
 class DenseDesc(ctypes.Structure):

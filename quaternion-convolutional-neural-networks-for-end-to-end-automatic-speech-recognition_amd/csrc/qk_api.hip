@@ -209,7 +209,20 @@ int validate(const qk_conv_desc_t *d, bool allow_rank0)
     if (d->layout != QK_CH_LAST && d->layout != QK_CH_FIRST) { set_error("bad layout %d", d->layout); return QK_ERR_INVALID_ARG; }
     if (d->dtype != QK_F32 && d->dtype != QK_BF16 && d->dtype != QK_F16) { set_error("bad dtype %d", d->dtype); return QK_ERR_INVALID_ARG; }
     if (d->activation != QK_ACT_LINEAR && d->activation != QK_ACT_RELU) { set_error("bad activation %d", d->activation); return QK_ERR_INVALID_ARG; }
+    if (d->kernel_order != QK_KERNEL_TAPS_MAJOR && d->kernel_order != QK_KERNEL_CHANNEL_MAJOR) { set_error("bad kernel_order %d", d->kernel_order); return QK_ERR_INVALID_ARG; }
+    if (d->kernel_order == QK_KERNEL_CHANNEL_MAJOR && (d->dtype == QK_F32 || d->layout != QK_CH_LAST || d->cq % 32 || d->fq % 32)) {
+        set_error("kernel_order = QK_KERNEL_CHANNEL_MAJOR is served by the 16-bit matrix-core kernels only (16-bit dtype, channels_last, cq and fq multiples of 32)");
+        return QK_ERR_UNSUPPORTED;
+    }
     return 0;
+}
+
+// a channel-major kernel (qk_conv_desc_t.kernel_order) that the 16-bit kernels declined must not fall through to kernels that read taps-major
+int refuse_ch_major(const qk_conv_desc_t *d, const char *what)
+{
+    if (d->kernel_order != QK_KERNEL_CHANNEL_MAJOR) return 0;
+    set_error("%s: kernel_order = QK_KERNEL_CHANNEL_MAJOR, but the 16-bit matrix-core path did not take this shape (workspace, alignment or a diagnostic switch)", what);
+    return QK_ERR_UNSUPPORTED;
 }
 
 struct Strides { long long sn, ss[3], sc; long long flat_ss; };
@@ -343,7 +356,7 @@ size_t ws_bytes_impl(const qk_conv_desc_t *d, int op)
             GemmGeom sg, sbg;
             Small16 sm;
             prep_geom(d, bwd_data, &sg);
-            if (small16_shape(sg, &sbg, &sm)) n += small16_region_bytes(sm);
+            if (d->kernel_order != QK_KERNEL_CHANNEL_MAJOR && small16_shape(sg, &sbg, &sm)) n += small16_region_bytes(sm);
         }
     }
     if (op == QK_OP_BWD && d->activation == QK_ACT_RELU) n = (n + 255) / 256 * 256 + dy_bytes(d);
@@ -418,6 +431,7 @@ int conv_fwd_impl(const qk_conv_desc_t *d, const void *x, const float *w, const 
     g.has_bias = d->has_bias ? 1 : 0;
     g.has_mask = 0;
     g.w_prepped = d->ws_has_kernel ? 1 : 0;
+    g.w_ch_major = d->kernel_order == QK_KERNEL_CHANNEL_MAJOR;
     const bool with_post = post && post->kind;
     if (d->dtype != QK_F32) {
         if (with_post && d->layout == QK_CH_LAST && aligned(pre, 16) && aligned(y, 16) &&
@@ -428,6 +442,7 @@ int conv_fwd_impl(const qk_conv_desc_t *d, const void *x, const float *w, const 
         if (r != 0) return r < 0 ? r : 0;
         g.post.kind = 0; g.post_fwd = 0; g.pre_out = nullptr;
     }
+    if (int rc = refuse_ch_major(d, "forward")) return rc;
     const bool vec = d->layout == QK_CH_LAST && d->cq % 4 == 0 && d->fq % 4 == 0 &&
                      vec_aligned(x, d->dtype) && aligned(w, 16);
     note_path(QK_PATH_FP32_MFMA);
@@ -483,6 +498,7 @@ int conv_bwd_data_impl(const qk_conv_desc_t *d, const void *dy, const void *y, c
     g.sign_tbl = d->conj ? kSignConv : kSignConj;   // transposed table
     g.relu = 0; g.has_bias = 0; g.has_mask = mask ? 1 : 0;
     g.w_prepped = d->ws_has_kernel ? 1 : 0;
+    g.w_ch_major = d->kernel_order == QK_KERNEL_CHANNEL_MAJOR;
     if (d->dtype != QK_F32) {
         // the 16-bit kernels apply an epilogue mask themselves (needs 16-byte aligned rows of dx_mask)
         g.ep_mask = (dx_mask && aligned(dx_mask, 16)) ? dx_mask : nullptr;
@@ -499,6 +515,7 @@ int conv_bwd_data_impl(const qk_conv_desc_t *d, const void *dy, const void *y, c
         }
         g.ep_mask = nullptr; g.post.kind = 0; g.dalpha = nullptr;
     }
+    if (int rc = refuse_ch_major(d, "backward-data")) return rc;
     // the fp32-MFMA kernel stages the compact kernel in place with the channel/filter roles swapped
     g.w_swapped = 1;
     const bool vec = d->layout == QK_CH_LAST && d->cq % 4 == 0 && d->fq % 4 == 0 && aligned(w, 16) &&
@@ -554,6 +571,7 @@ int conv_bwd_weight_impl(const qk_conv_desc_t *d, const void *x, const void *dy,
     g.has_mask = mask ? 1 : 0;
     g.want_dbias = (d->has_bias && dbias) ? 1 : 0;
     g.dym = mask ? dy_masked_out : nullptr;
+    g.w_ch_major = d->kernel_order == QK_KERNEL_CHANNEL_MAJOR;
     // dw / dbias are accumulated atomically: zero them first (one fill when they are adjacent, as in
     // a flat gradient buffer)
     const size_t dwb = w_floats(d) * sizeof(float), dbb = 4 * (size_t)d->fq * sizeof(float);
@@ -571,10 +589,11 @@ int conv_bwd_weight_impl(const qk_conv_desc_t *d, const void *x, const void *dy,
         if (g.want_dbias && hipMemsetAsync(dbias, 0, dbb, stream) != hipSuccess) { set_error("memset dbias failed"); return QK_ERR_LAUNCH; }
     }
     if (d->dtype != QK_F32) {
-        int r = try_wgrad_band_16(d->dtype, x, dy, mask ? y : nullptr, dw, dbias, g, stream);
+        int r = g.w_ch_major ? 0 : try_wgrad_band_16(d->dtype, x, dy, mask ? y : nullptr, dw, dbias, g, stream);     // (the band kernels write taps-major only)
         if (r == 0) r = try_wgrad_16(d->dtype, x, dy, mask ? y : nullptr, dw, dbias, g, stream);
         if (r != 0) return r < 0 ? r : 0;
     }
+    if (int rc = refuse_ch_major(d, "backward-weight")) return rc;
     const bool vec = d->layout == QK_CH_LAST && d->cq % 4 == 0 && d->fq % 4 == 0 &&
                      vec_aligned(x, d->dtype) && vec_aligned(dy, d->dtype) && (!mask || vec_aligned(y, d->dtype));
     note_path(QK_PATH_FP32_MFMA);
@@ -1137,13 +1156,14 @@ int qk_conv_prep_kernels(int32_t n, const qk_conv_desc_t *const *descs, const in
                 j.w = w[i]; j.wq = workspaces[i]; j.taps = taps_of(d); j.cq = d->cq; j.fq = d->fq;
                 j.transposed = bwd ? 1 : 0;
                 j.small = 0; j.kin = 0; j.n_ot = 0;
+                j.ch_major = d->kernel_order == QK_KERNEL_CHANNEL_MAJOR;
                 j.neg_ijk = bwd ? (d->conj ? 1 : 0) : (d->conj ? 0 : 1);       // the sign table go16 folds into the kernel
                 {   // 16 / 32-channel layers: a second job writes the fragment layout of k_hconv16_small into the region behind the band
                     // layout (the shape alone decides that the region exists, exactly as go16 and qk_conv_workspace_bytes see it)
                     GemmGeom sg, sbg;
                     Small16 sm;
                     prep_geom(d, bwd, &sg);
-                    if (d->layout == QK_CH_LAST && small16_shape(sg, &sbg, &sm)) {
+                    if (d->layout == QK_CH_LAST && !j.ch_major && small16_shape(sg, &sbg, &sm)) {
                         PrepJob &k = jobs.j[m++];
                         k = j;
                         k.wq = static_cast<char *>(workspaces[i]) + (size_t)j.taps * pad32(d->cq) * 4 * pad32(d->fq) * 2 + 256;

@@ -89,6 +89,7 @@ struct GemmGeom {
     // alone and every 128-row tile uses exactly one tap instead of the two a line boundary inside the tile brings.
     int o0_major;
     unsigned b_in_bytes, b_w_bytes;      // extents of the input tensor and of the re-laid-out kernel (buffer resources)
+    int w_ch_major;     // qk_conv_desc_t.kernel_order == QK_KERNEL_CHANNEL_MAJOR: the compact kernel lies as (cq, taps, 4 fq); honoured by the 16-bit re-layout only
 };
 
 // Backward-weight geometry:  dW[t, c, p, f] = sum_{a^b=p} sgn(a,b) sum_m x_a[pos(m,t), c] * dy_b[m, f]
@@ -198,6 +199,7 @@ struct WgradGeom {
     // band variant (qk_wgrad_band_bf16mfma.hip): positions run over padded lines of the innermost axis (b_wp per
     // line, b_nlines lines); band row j of a tile holds input column (padded position + b_cshift)
     int b_wp, b_nlines, b_cshift;
+    int w_ch_major;     // dw lies as (cq, taps, 4 fq) (qk_conv_desc_t.kernel_order): k_wgrad16 only
     void *dym;          // optional output: dy with the relu mask applied (same layout/dtype as dy), or NULL;
                         // written by the blocks of tap 0 / channel chunk 0, which see every (row, filter) once
 };
@@ -295,7 +297,7 @@ int launch_fold_taps(int dtype, const void *x, void *xcol, const GemmGeom &g, in
 int launch_mask_gt0(int dtype, void *data, const void *mask, size_t n, hipStream_t stream);   // data *= (mask > 0)
 // batched 16-bit re-layout of compact kernels (qk_conv_prep_kernels): up to 32 jobs per launch, passed by value
 struct PrepJob { const float *w; void *wq; int taps, cq, fq, transposed, neg_ijk;
-                 int small, kin, n_ot; };      // small != 0: the fragment layout of k_hconv16_small (qk_hconv16_small.hip) -- kin inner taps, n_ot outer taps
+                 int small, kin, n_ot, ch_major; };      // small != 0: the fragment layout of k_hconv16_small (qk_hconv16_small.hip) -- kin inner taps, n_ot outer taps
 struct PrepJobs { PrepJob j[32]; };
 int launch_prep_w16_batch(int dtype, const PrepJobs &jobs, int n, hipStream_t stream);
 // Small-channel 16-bit layers (Q, J in {16, 32}, not both 32: start_filter = 16 models) -- qk_hconv16_small.hip.

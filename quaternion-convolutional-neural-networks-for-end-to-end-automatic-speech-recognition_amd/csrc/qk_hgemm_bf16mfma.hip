@@ -79,8 +79,9 @@ __device__ __forceinline__ uint4 mask8(const uint4 &v, const uint4 &m)
 // ---------------------------------------------------------------------------------------
 template <typename T>
 __global__ void __launch_bounds__(256)
-k_prep_w16(const float *__restrict__ w, T *__restrict__ wq, int taps, int Cq, int F, int transposed, int neg_ijk)
+k_prep_w16(const float *__restrict__ w, T *__restrict__ wq, int taps, int Cq, int F, int transposed, int neg_ijk, int ch_major)
 {
+    // ch_major (qk_conv_desc_t.kernel_order): the compact kernel lies as (cq, taps, 4 fq) -- row (c, t) instead of (t, c)
     // (Q, J multiples of 16: the layout is written for the 32-channel granule of the kernels, zero beyond the real extents --
     //  round 5, channel counts that are multiples of 16 only)
     const int Qr = transposed ? F : Cq, Jr = transposed ? Cq : F;
@@ -97,7 +98,7 @@ k_prep_w16(const float *__restrict__ w, T *__restrict__ wq, int taps, int Cq, in
         const int k = kc * 32 + slot * 8 + e;
         const int c = transposed ? j : k;
         const int f = transposed ? k : j;
-        const float v = (k < Qr && j < Jr) ? w[((long long)(t * Cq + c) * 4 + p) * F + f] : 0.f;
+        const float v = (k < Qr && j < Jr) ? w[((long long)(ch_major ? c * taps + t : t * Cq + c) * 4 + p) * F + f] : 0.f;
         wq[idx] = from_f32<T>(neg_ijk && p ? -v : v);
     }
     if (blockIdx.x == 0 && threadIdx.x < 128) wq[total + threadIdx.x] = from_f32<T>(0.f);   // zero line for padding rows
@@ -113,7 +114,7 @@ k_prep_w16_batch(const PrepJobs jobs)
     const PrepJob &jb = jobs.j[blockIdx.y];
     const float *__restrict__ w = jb.w;
     T *__restrict__ wq = static_cast<T *>(jb.wq);
-    const int Cq = jb.cq, F = jb.fq, transposed = jb.transposed, neg_ijk = jb.neg_ijk;
+    const int Cq = jb.cq, F = jb.fq, transposed = jb.transposed, neg_ijk = jb.neg_ijk, ch_major = jb.ch_major, taps = jb.taps;
     if (jb.small) {                                   // the fragment layout of k_hconv16_small (qk_hconv16_small.hip)
         const int Qs = transposed ? F : Cq, Js = transposed ? Cq : F;
         const int q32 = Qs == 32, fb_n = Js / 16, kso = q32 ? jb.kin : (jb.kin + 1) / 2;
@@ -125,7 +126,7 @@ k_prep_w16_batch(const PrepJobs jobs)
     }
     const int Qr = transposed ? F : Cq, Jr = transposed ? Cq : F;
     const int Q = (Qr + 31) / 32 * 32, J = (Jr + 31) / 32 * 32;                  // (zero-padded to the 32-channel granule, see k_prep_w16)
-    const long long total = (long long)jb.taps * Q * 4 * J;
+    const long long total = (long long)taps * Q * 4 * J;
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
         long long r = idx;
         const int e = r % 8; r /= 8;
@@ -137,7 +138,7 @@ k_prep_w16_batch(const PrepJobs jobs)
         const int k = kc * 32 + slot * 8 + e;
         const int c = transposed ? j : k;
         const int f = transposed ? k : j;
-        const float v = (k < Qr && j < Jr) ? w[((long long)(t * Cq + c) * 4 + p) * F + f] : 0.f;
+        const float v = (k < Qr && j < Jr) ? w[((long long)(ch_major ? c * taps + t : t * Cq + c) * 4 + p) * F + f] : 0.f;
         wq[idx] = from_f32<T>(neg_ijk && p ? -v : v);
     }
     if (blockIdx.x == 0 && threadIdx.x < 128) wq[total + threadIdx.x] = from_f32<T>(0.f);
@@ -1413,12 +1414,12 @@ int go16(const void *in, const void *mask, const float *w, const float *bias, vo
         // (a caller that sized it by hand for the band form) runs the band form.
         Small16 sm;
         const size_t band_bytes = (size_t)g.taps * g.Qp * 4 * g.Jp * 2 + 256;
-        if (small16_shape(g, &bg, &sm) && ws_bytes >= band_bytes + small16_region_bytes(sm)) {
+        if (!g.w_ch_major && small16_shape(g, &bg, &sm) && ws_bytes >= band_bytes + small16_region_bytes(sm)) {
             T *wqs = reinterpret_cast<T *>(static_cast<char *>(ws) + band_bytes);
             if (!g.w_prepped) {                       // a cache miss fills BOTH regions: the caller may flag the buffer as prepped from now on
                 if (int rc = launch_prep_small16(std::is_same<T, bf16>::value ? QK_BF16 : QK_F16, w, wqs, Cq, F, transposed ? 1 : 0, neg_ijk ? 1 : 0, sm, stream)) return rc;
                 const long long tot = (long long)g.taps * g.Qp * 4 * g.Jp;
-                hipLaunchKernelGGL((k_prep_w16<T>), dim3((unsigned)((tot + 255) / 256 > 2048 ? 2048 : (tot + 255) / 256)), dim3(256), 0, stream, w, wq, g.taps, Cq, F, transposed ? 1 : 0, neg_ijk ? 1 : 0);
+                hipLaunchKernelGGL((k_prep_w16<T>), dim3((unsigned)((tot + 255) / 256 > 2048 ? 2048 : (tot + 255) / 256)), dim3(256), 0, stream, w, wq, g.taps, Cq, F, transposed ? 1 : 0, neg_ijk ? 1 : 0, 0);
                 if (hipGetLastError() != hipSuccess) return QK_ERR_LAUNCH;
                 g.w_prepped = 1;
             }
@@ -1441,7 +1442,7 @@ int go16(const void *in, const void *mask, const float *w, const float *bias, vo
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     if (!g.w_prepped) {                              // (the caller vouches for the workspace: qk_conv_desc_t.ws_has_kernel)
-        hipLaunchKernelGGL((k_prep_w16<T>), dim3(blocks), dim3(256), 0, stream, w, wq, g.taps, Cq, F, transposed ? 1 : 0, neg_ijk ? 1 : 0);
+        hipLaunchKernelGGL((k_prep_w16<T>), dim3(blocks), dim3(256), 0, stream, w, wq, g.taps, Cq, F, transposed ? 1 : 0, neg_ijk ? 1 : 0, g.w_ch_major);
         if (hipGetLastError() != hipSuccess) return QK_ERR_LAUNCH;
     }
     const uint4 *wq4 = reinterpret_cast<const uint4 *>(wq);

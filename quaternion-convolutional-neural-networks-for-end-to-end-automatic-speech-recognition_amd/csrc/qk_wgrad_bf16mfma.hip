@@ -377,7 +377,7 @@ k_wgrad16(const T *__restrict__ x, const T *__restrict__ dy, const T *__restrict
         const int cv = e / (4 * BF);                                    // virtual channel: member * BCQ + cc
         const int tm = t * TG + cv / BCQ;
         if (tm < g.taps && !(g.ablate & 2))
-            atomicAdd(dw + ((tm * g.Cq + c0 + cv % BCQ) * 4 + p) * g.F + f0 + ff, slab[e]);
+            atomicAdd(dw + ((g.w_ch_major ? (c0 + cv % BCQ) * g.taps + tm : tm * g.Cq + c0 + cv % BCQ) * 4 + p) * g.F + f0 + ff, slab[e]);
     }
     if (bias_blk && tid < 4 * BF) {
         const int b = tid / BF, ff = tid % BF;

@@ -467,8 +467,10 @@ def _check_weights(w, bias, n_out):
 
 
 def conv_call(x_shape, w_shape, dtype, rank, strides=1, padding='valid', layout='channels_last',
-              dilation_rate=1, activation=None, use_bias=True, conj=False):
-    """Descriptor for one conv call on a PHYSICAL layout (`layout` describes the buffer)."""
+              dilation_rate=1, activation=None, use_bias=True, conj=False, kernel_order=0):
+    """Descriptor for one conv call on a PHYSICAL layout (`layout` describes the buffer).  kernel_order =
+    L.QK_KERNEL_CHANNEL_MAJOR: the kernel buffer lies as (cq, *kernel_size, 4 fq) -- a QuaternionDense weight read in place as
+    the kernel of the equivalent convolution (include/qk.h); w_shape stays the logical (*kernel_size, cq, 4 fq)."""
     st = normalize_tuple(strides, rank, 'strides')
     dl = normalize_tuple(dilation_rate, rank, 'dilation_rate')
     if len(x_shape) != rank + 2 or len(w_shape) != rank + 2:
@@ -505,6 +507,7 @@ def conv_call(x_shape, w_shape, dtype, rank, strides=1, padding='valid', layout=
         y_shape = (x_shape[0], 4 * fq) + tuple(out_sp)
     else:
         y_shape = (x_shape[0],) + tuple(out_sp) + (4 * fq,)
+    d.kernel_order = int(kernel_order)
     return _Call(d, ('qk_conv_fwd', 'qk_conv_bwd_data', 'qk_conv_bwd_weight'),
                  'qk_conv_workspace_bytes', tuple(x_shape), y_shape, tuple(w_shape),
                  d.activation == L.QK_ACT_RELU)
@@ -960,7 +963,21 @@ def quaternion_conv_chain(x, layers):
     calls, ws, bs, posts, alphas = [], [], [], [], []
     shape = tuple(xp.shape)
     for kernel, bias, kw in layers:
-        if kernel.dim() == 2:
+        order = 0
+        if kernel.dim() == 2 and kw.get('dense_kernel_size') is not None:
+            # a QuaternionDense weight over the FLATTENED (channel, *kernel_size) axes of the feature map (the TIMIT model's first
+            # TimeDistributed dense layer: row cq * F + f of the weight is tap f, channel cq of an (F, 1) 'valid' convolution,
+            # interspeech_model.py:140-149): the parameter is read in place as a CHANNEL-MAJOR kernel (qk_conv_desc_t.kernel_order)
+            # -- no permuted copy per step, cached 16-bit re-layout, kernel gradient straight into the parameter's own layout
+            ksz = tuple(int(v) for v in kw['dense_kernel_size'])
+            rank = len(ksz)
+            taps = int(math.prod(ksz))
+            if kernel.shape[0] % taps:
+                raise ValueError('dense kernel rows %d are not a multiple of the %d taps' % (kernel.shape[0], taps))
+            kw = dict(kw, conj=True, strides=1, padding='valid', dilation_rate=1)
+            w_shape = ksz + (kernel.shape[0] // taps, kernel.shape[1])
+            order = L.QK_KERNEL_CHANNEL_MAJOR
+        elif kernel.dim() == 2:
             # a QuaternionDense weight (in_q, 4 * units): the layer applied to every position of the channels-last tensor is
             # the 1 x ... x 1 conj-convolution with that weight as its single tap (dense.py:139-143 builds the transposed
             # table).  The PARAMETER itself is passed on (same memory as the (1, ..., in_q, 4 units) kernel): its cached
@@ -977,7 +994,7 @@ def quaternion_conv_chain(x, layers):
             raise ValueError('a layer with a post-op must be linear (the post-op is its activation)')
         call = conv_call(shape, w_shape, xp.dtype, rank, kw.get('strides', 1), kw.get('padding', 'valid'),
                          'channels_last', kw.get('dilation_rate', 1), kw.get('activation'), bias is not None,
-                         bool(kw.get('conj', False)))
+                         bool(kw.get('conj', False)), order)
         calls.append(call)
         ws.append(kernel.contiguous())
         bs.append(bias)

@@ -210,10 +210,13 @@ class TimitQCNN(torch.nn.Module):
             layers.append((cv.kernel, cv.bias, dict(strides=cv.strides, padding=cv.padding, dilation_rate=cv.dilation_rate,
                                                     activation=None, post=self._post(1 + i, shape))))
         k = 1 + len(self.convs)
-        dl, w = self._head_kernel(shape, x.device)
+        d0 = self.dense[0].layer
+        if not d0.built:
+            d0._build_device = x.device
+            d0.build((None, shape[1] * shape[2]))
+        dl, link = self._head_link(shape, x.device, o.dtype, activation=None, post=self._post(k, (shape[0], shape[3], d0.r.shape[-1])))
         head_shape = (shape[0], dl.r.shape[-1], shape[3])                       # (B, units, T): TimeDistributed output, channels_first view
-        layers.append((w, dl.bias, dict(strides=1, padding='valid', dilation_rate=1, activation=None, conj=True,
-                                        post=self._post(k, (shape[0], shape[3], dl.r.shape[-1])))))
+        layers.append(link)
         k += 1
         if relu_form and not L.dbg(L.QK_DBG_NO_DENSE_IN_CHAIN):
             # aact == 'none': the second and third TimeDistributed(QuaternionDense(256)) (interspeech_model.py:150-166) are links
@@ -258,6 +261,24 @@ class TimitQCNN(torch.nn.Module):
             dl.build((None, c * f))
         return dl, dl.r.view(c // 4, f, dl.r.shape[-1]).permute(1, 0, 2).unsqueeze(1).contiguous()
 
+    def _head_link(self, o_shape, device, dtype, **kw):
+        """The head as a chain link (kernel, bias, kwargs).  16-bit device tensors with matrix-core widths: the dense PARAMETER
+        itself, read in place as a channel-major kernel (functional.quaternion_conv_chain: dense_kernel_size) -- the permuted
+        copy of `_head_kernel`, its re-layout launches and the permuted gradient accumulation (8 small launches per step)
+        go away; anything else: the (F, 1, Cq, units) copy."""
+        dl, w = None, None
+        b, c, f, t = o_shape
+        d0 = self.dense[0].layer
+        if not d0.built:
+            d0._build_device = device
+            d0.build((None, c * f))
+        cq, fq = c // 4, d0.r.shape[-1] // 4
+        if (dtype in (torch.bfloat16, torch.float16) and str(device).startswith('cuda') and cq % 32 == 0 and fq % 32 == 0
+                and d0.r.is_contiguous()):
+            return d0, (d0.r, d0.bias, dict(kw, conj=True, dense_kernel_size=(f, 1)))
+        dl, w = self._head_kernel(o_shape, device)
+        return dl, (w, dl.bias, dict(kw, strides=1, padding='valid', dilation_rate=1, conj=True))
+
     def _convs_as_chain(self, o):
         """The n body convolutions (interspeech_model.py:105-137 with no advanced activation and no active
         dropout) through functional.quaternion_conv_chain: same values and gradients as calling the layers
@@ -281,10 +302,10 @@ class TimitQCNN(torch.nn.Module):
                                                   dilation_rate=c.dilation_rate, activation=name)))
         with_head = False
         if self.fuse_head:
-            dl, w = self._head_kernel(shape, o.device)
-            name = activations.serialize(dl.activation)
+            name = activations.serialize(self.dense[0].layer.activation)
             if name in ('linear', 'relu'):
-                layers.append((w, dl.bias, dict(strides=1, padding='valid', dilation_rate=1, activation=name, conj=True)))
+                dl, link = self._head_link(shape, o.device, o.dtype, activation=name)
+                layers.append(link)
                 with_head = True
         y = Fq.quaternion_conv_chain(o.movedim(1, -1), layers)       # (B, F, T, C) channels-last buffer
         if with_head:

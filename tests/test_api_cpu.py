@@ -34,7 +34,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert declared == set(_lib.SYMBOLS), (declared ^ set(_lib.SYMBOLS))
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.qk_version() == 102
+    assert lib.qk_version() == 103
 
 
 def test_descriptor_struct_matches_header_field_order():
@@ -42,7 +42,7 @@ def test_descriptor_struct_matches_header_field_order():
     body = header[header.index('typedef struct {'):header.index('} qk_conv_desc_t;')]
     fields = re.findall(r'int32_t\s+([a-z_]+)', body)
     assert fields == [f[0] for f in _lib.ConvDesc._fields_]
-    assert ctypes.sizeof(_lib.ConvDesc) == 4 * (2 + 6 + 2 + 12 + 6)
+    assert ctypes.sizeof(_lib.ConvDesc) == 4 * (2 + 6 + 2 + 12 + 7)
     body = header[header.index('} qk_conv_desc_t;'):header.index('} qk_dense_desc_t;')]
     fields = re.findall(r'int32_t\s+([a-z_]+)', body)
     assert fields == [f[0] for f in _lib.DenseDesc._fields_]

@@ -280,6 +280,50 @@ def test_sixteen_channel_layers_run_on_the_matrix_cores(dtype):
         assert rel(dw, dw0) <= 1e-4 and rel(db, db0) <= 1e-4, (cq, fq, rel(dw, dw0), rel(db, db0))
 
 
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16], ids=['bf16', 'fp16'])
+def test_dense_weight_read_in_place_as_a_channel_major_kernel(dtype):
+    """qk_conv_desc_t.kernel_order = QK_KERNEL_CHANNEL_MAJOR (round 6): the TIMIT model's first TimeDistributed(QuaternionDense) on
+    the (B, C, F, T) body output (interspeech_model.py:140-149) is an (F, 1) 'valid' conj-convolution whose kernel is the dense weight
+    with rows (cq, f) instead of (f, cq).  Reading the PARAMETER in place must give exactly what the permuted copy gives -- forward,
+    backward-data, and the kernel gradient written straight in the parameter's own layout -- and everything outside the 16-bit
+    matrix-core kernels must refuse the order instead of mis-reading it."""
+    import qcnn_amd
+    from qcnn_amd import _lib
+    F = qcnn_amd.functional
+    dev = _dev()
+    g = torch.Generator(device=dev).manual_seed(21)
+    B, Fr, T, cq, units = 3, 14, 37, 64, 256
+    x = torch.randn(B, Fr, T, 4 * cq, device=dev, generator=g).to(dtype)
+    r = torch.nn.Parameter(torch.randn(cq * Fr, units, device=dev, generator=g) / 40)            # dense weight: row cq_i * Fr + f
+    b = torch.nn.Parameter(torch.randn(units, device=dev, generator=g) / 10)
+    w_copy = r.detach().view(cq, Fr, units).permute(1, 0, 2).unsqueeze(1).contiguous().requires_grad_(True)   # (Fr, 1, cq, units)
+    b2 = b.detach().clone().requires_grad_(True)
+    dy = torch.randn(B, 1, T, units, device=dev, generator=g).to(dtype)
+    with _lib.debug_flags(_lib.QK_DBG_DETERMINISTIC):          # one addition per gradient element: the two layouts must agree bit for bit
+        xa = x.clone().requires_grad_(True)
+        ya = F.quaternion_conv_chain(xa, [(r, b, dict(activation='relu', dense_kernel_size=(Fr, 1)))])
+        pa = _lib.last_path()
+        ya.backward(dy)
+        xb = x.clone().requires_grad_(True)
+        yb = F.quaternion_conv_chain(xb, [(w_copy, b2, dict(strides=1, padding='valid', dilation_rate=1, activation='relu', conj=True))])
+        yb.backward(dy)
+        torch.cuda.synchronize()
+    assert tuple(ya.shape) == (B, 1, T, units) and torch.equal(ya, yb) and torch.equal(xa.grad, xb.grad)
+    assert r.grad.shape == r.shape
+    want = w_copy.grad.squeeze(1).permute(1, 0, 2).reshape(r.shape)
+    assert torch.equal(r.grad, want) and torch.equal(b.grad, b2.grad) and float(r.grad.abs().max()) > 0
+    assert '_qk_prep' in r.__dict__ and len(r._qk_prep) >= 1                         # the parameter carries the cached re-layout
+    # fp32 descriptors, channel counts off the matrix-core path: refused, never mis-read
+    call = F.conv_call(tuple(x.shape), (Fr, 1, cq, units), torch.float32, 2, 1, 'valid', 'channels_last', 1, None, True, True,
+                       kernel_order=_lib.QK_KERNEL_CHANNEL_MAJOR)
+    with pytest.raises(RuntimeError, match='kernel_order'):
+        call.fwd(x.float(), r.detach(), b.detach())
+    call = F.conv_call((B, Fr, T, 4 * 24), (Fr, 1, 24, units), dtype, 2, 1, 'valid', 'channels_last', 1, None, True, True,
+                       kernel_order=_lib.QK_KERNEL_CHANNEL_MAJOR)
+    with pytest.raises(RuntimeError, match='kernel_order'):
+        call.fwd(x[..., :96].contiguous(), r.detach()[:24 * Fr].contiguous(), b.detach())
+
+
 @pytest.mark.parametrize('cq,fq', [(16, 16), (32, 16)], ids=['16to16', '32to16'])
 def test_cached_workspace_of_a_small_channel_layer_serves_both_kernels_in_any_order(cq, fq):
     """Round-5 advisor: a 16 / 32-channel layer's cached 16-bit kernel held ONE of two layouts (k_hconv16_small's fragments or the
