@@ -83,6 +83,7 @@ struct GemmGeom {
     void *pre_out;                       // forward, kind 1: where the pre-activation goes (kind 2 writes y only)
     float *dalpha;
     int b_wp, b_nlines, b_cshift, b_rev;
+    int b_tile_rows;    // k_hgemm_band (fp32 MFMA): rows a workgroup OWNS of its BM-row tile (<= BM; set by the launcher, 0 = BM)
     // k_hgemm16 row order: 0 = rows run over (n, o0, o1, o2); batch = rows run over (o0, n, o1, o2) (dv_*[2] then divides
     // by batch).  Chosen when the gathered tensor has ONE position along axis 0 under a multi-tap kernel axis (the
     // backward-data of the (F, 1) 'valid' head convolution): the single valid tap of a row is then a function of o0
@@ -202,7 +203,21 @@ struct WgradGeom {
     int w_ch_major;     // dw lies as (cq, taps, 4 fq) (qk_conv_desc_t.kernel_order): k_wgrad16 only
     void *dym;          // optional output: dy with the relu mask applied (same layout/dtype as dy), or NULL;
                         // written by the blocks of tap 0 / channel chunk 0, which see every (row, filter) once
+    unsigned fd_mul[4], fd_sh[4];   // k_wgrad (fp32 MFMA): exact division of a row index by osp[2], osp[1], osp[0], S (make_fastdiv; set by the launcher)
 };
+
+// floor(n / d) for 0 <= n < 2^31 as one 32 x 32 -> 64 multiplication: mul = ceil(2^(31 + sh) / d), sh = ceil(log2 d)
+inline void make_fastdiv(unsigned d, unsigned *mul, unsigned *sh)
+{
+    unsigned s = 0;
+    while ((1ull << s) < d) ++s;
+    *mul = (unsigned)(((1ull << (31 + s)) + d - 1) / d);
+    *sh = s;
+}
+__device__ __forceinline__ int fast_div(int n, unsigned mul, unsigned sh)
+{
+    return (int)(((unsigned long long)(unsigned)n * mul) >> (31 + sh));
+}
 
 // ---------------------------------------------------------------------------------------
 // Element types in HBM.  Accumulation is always fp32.
