@@ -1,3 +1,2 @@
-mkdir -p gpurun_out/c2
-python tools/ablate_cfg2.py > gpurun_out/c2/tr1.txt 2>&1; cat gpurun_out/c2/tr1.txt | head -7
-python -m pytest tests/test_gpu_parity.py tests/test_fullsize_oracle_parity.py -x -q -m gpu -k "cfg2 or fp32 or f32" 2>&1 | tail -2
+python -m pytest tests -x -q -m gpu 2>&1 | tail -4
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
