@@ -1,2 +1,1 @@
-python -m pytest tests -x -q -m gpu 2>&1 | tail -4
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+python -m pytest tests/test_gpu_parity.py tests/test_fullsize_oracle_parity.py tests/test_models.py -x -q -m gpu 2>&1 | tail -2
