@@ -300,6 +300,42 @@ def test_body_layer_relu_and_chain_flag_forms_match_sampled_oracle_at_full_size(
     print(case[0], form, rep)
 
 
+FP32_BODY = [('cfg3_64to64_b64_fp32', 64, 64, 64, (3, 5)),       # 32 channels per group, full 64-filter column blocks
+             ('c32to32_b64_fp32', 64, 32, 32, (3, 5)),           # 32 channels per group, HALF-empty column block (32 filters of 64)
+             ('c16to48_b64_fp32', 64, 16, 48, (3, 5)),           # 16 channels per group, ragged column block
+             ('c24to64_b64_fp32_k3', 64, 24, 64, (3, 3))]        # 8 channels per group, three inner taps
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', FP32_BODY, ids=[c[0] for c in FP32_BODY])
+def test_fp32_layer_on_the_big_tile_band_kernel_matches_sampled_oracle(case):
+    """Round 6: the fp32 band kernel's K-contiguous form (csrc/qk_hgemm_f32mfma.inc k_hgemm_band: ds_read_b128 fragments, sign
+    blocks with negated accumulators, 128 x 256 tiles) only runs for launches of >= 1024 such tiles -- no small oracle case
+    reaches it.  A relu layer at M = 179 200 rows, forward + fused masked backward (k_wgrad<float> with the register fold, the
+    band kernel again for backward-data), against the sampled float64 oracle at the fp32 tolerance of the north star (1e-4)."""
+    import qcnn_amd
+    from qcnn_amd import _lib
+    F = qcnn_amd.functional
+    dev = _dev()
+    _, B, cq, fq, ks = case
+    xs, ws = (B, 14, 200, 4 * cq), (ks[0], ks[1], cq, 4 * fq)
+    g = torch.Generator(device=dev).manual_seed(21)
+    x = torch.randn(xs, device=dev, generator=g)
+    fan = float(np.prod(ws[:-1])) * 4.0
+    w = torch.randn(ws, device=dev, generator=g) / fan ** 0.5
+    b = torch.randn(ws[-1], device=dev, generator=g) / 10
+    call = F.conv_call(xs, ws, torch.float32, 2, 1, 'same', 'channels_last', 1, 'relu', True)
+    y = call.fwd(x, w, b)
+    assert _lib.last_path() == 'fp32_mfma', _lib.last_path()
+    dy = torch.randn(call.y_shape, device=dev, generator=g)
+    dx, dw, db = call.bwd(x, dy, y, w, True)
+    torch.cuda.synchronize()
+    chk = LayerCheck(2, dict(padding='same'), _host(x), w.cpu().double().numpy(), b.cpu().double().numpy(), _host(y), _host(dy),
+                     _host(dx), dw.cpu().numpy(), db.cpu().numpy(), 'relu', None, None)
+    rep = chk.check(np.random.RandomState(5), 1e-4, 1e-4)
+    print(case[0], rep)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('dtype', [torch.bfloat16], ids=['bf16'])
 def test_head_convolution_in_the_bench_form_matches_sampled_oracle_at_full_size(dtype):
