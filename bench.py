@@ -1083,6 +1083,23 @@ def main():
                 out['cfg2_layer'] = {'workload': 'cfg2_qconv1d_timit_b64_fp32', 'dtype': 'fp32', 'gemm_view': j2.gemm,
                                      'steps': 300, 'warmup': 30, 'pre_warmup_steps': 8, 'ms_per_step': 1e3 * el / 300,
                                      'samples_per_s': c2['batch'] * 300 / el, 'peak_tflops': PEAK_TFLOPS['fp32'], 'kernels': k2}
+                # the clock and power these 40-us launches run at: the three kernels back to back for ~70 ms under the 10 ms sampler
+                # (measured: 2.38 GHz at 0.98 kW -- fp32 MFMA work is not clock-starved the way the bf16 body kernels are)
+                try:
+                    t2 = GpuTelemetry(dev)
+                    t2.start()
+                    ta = time.perf_counter()
+                    for _ in range(600):
+                        j2.k_fwd(); j2.k_bwd_weight(); j2.k_bwd_data()
+                    torch.cuda.synchronize()
+                    tele2 = t2.summary(ta, time.perf_counter())
+                    if tele2 and tele2.get('mean_sclk_mhz'):
+                        out['cfg2_layer']['sustained_clock_mhz'] = tele2['mean_sclk_mhz']
+                        out['cfg2_layer']['mean_socket_w'] = tele2.get('mean_socket_w')
+                        for name in k2:
+                            k2[name]['frac_at_sustained_clock'] = k2[name]['tflops'] / (PEAK_TFLOPS['fp32'] * tele2['mean_sclk_mhz'] / NOMINAL_SCLK_MHZ)
+                except Exception:
+                    pass
                 del j2
             except Exception as e:
                 out['cfg2_layer'] = {'error': repr(e)}

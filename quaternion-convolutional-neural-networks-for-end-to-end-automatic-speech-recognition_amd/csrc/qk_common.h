@@ -83,7 +83,6 @@ struct GemmGeom {
     void *pre_out;                       // forward, kind 1: where the pre-activation goes (kind 2 writes y only)
     float *dalpha;
     int b_wp, b_nlines, b_cshift, b_rev;
-    int b_tile_rows;    // k_hgemm_band (fp32 MFMA): rows a workgroup OWNS of its BM-row tile (<= BM; set by the launcher, 0 = BM)
     // k_hgemm16 row order: 0 = rows run over (n, o0, o1, o2); batch = rows run over (o0, n, o1, o2) (dv_*[2] then divides
     // by batch).  Chosen when the gathered tensor has ONE position along axis 0 under a multi-tap kernel axis (the
     // backward-data of the (F, 1) 'valid' head convolution): the single valid tap of a row is then a function of o0
