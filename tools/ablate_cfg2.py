@@ -12,7 +12,7 @@ from ab_layers import timeit
 
 dev = torch.device('cuda:0')
 job = bench.LayerTrainStep(dict(bench.WORKLOADS['cfg2_qconv1d_timit_b64_fp32'], activation='relu'), dev, 0, 1)
-for name, fn, abl in (('fwd', job.k_fwd, (0, 4, 8, 12)), ('bwd_data', job.k_bwd_data, (0, 4, 8, 12, 32)), ('bwd_weight', job.k_bwd_weight, (0, 1, 2))):
+for name, fn, abl in (('fwd', job.k_fwd, (0, 16, 4, 8, 12)), ('bwd_data', job.k_bwd_data, (0, 16, 4, 8, 12, 32)), ('bwd_weight', job.k_bwd_weight, (0, 1, 2))):
     for a in abl:
         with _lib.debug_flags(0, ablate=a):
             fn(); torch.cuda.synchronize()
