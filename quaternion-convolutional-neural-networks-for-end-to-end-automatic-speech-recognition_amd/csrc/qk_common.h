@@ -213,7 +213,7 @@ inline void make_fastdiv(unsigned d, unsigned *mul, unsigned *sh)
     *mul = (unsigned)(((1ull << (31 + s)) + d - 1) / d);
     *sh = s;
 }
-__device__ __forceinline__ int fast_div(int n, unsigned mul, unsigned sh)
+__host__ __device__ __forceinline__ int fast_div(int n, unsigned mul, unsigned sh)
 {
     return (int)(((unsigned long long)(unsigned)n * mul) >> (31 + sh));
 }

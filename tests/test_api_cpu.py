@@ -351,3 +351,20 @@ def test_profiler_entry_points_without_a_gpu():
     with _lib.profile() as p:
         assert p.records() == []
     assert lib.qk_prof_enable(0) == 0
+
+
+def test_fast_division_of_the_row_decode_is_exact(tmp_path):
+    """csrc/qk_common.h make_fastdiv / fast_div (one 32 x 32 -> 64 multiplication per division in k_wgrad's per-step row decode):
+    tests/fastdiv_check.cpp compares it with n / d on 7 M (d, n) pairs incl. every edge; built with hipcc (host code only)."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(hipcc):
+        pytest.skip('no hipcc')
+    here = os.path.dirname(os.path.abspath(__file__))
+    pkg = os.path.join(os.path.dirname(here), 'quaternion-convolutional-neural-networks-for-end-to-end-automatic-speech-recognition_amd', 'csrc')
+    exe = str(tmp_path / 'fastdiv_check')
+    subprocess.run([hipcc, '-O2', '-std=c++17', '--offload-arch=gfx950', '-I' + pkg, '-x', 'hip', os.path.join(here, 'fastdiv_check.cpp'), '-o', exe],
+                   check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    out = subprocess.run([exe], stdout=subprocess.PIPE, text=True)
+    assert out.returncode == 0 and 'bad 0' in out.stdout, out.stdout
