@@ -316,7 +316,7 @@ int qk_postop_bwd(const qk_conv_desc_t *t, const qk_postop_t *post, const void *
  * one-hot "window row 0 / 1 / 2 held the maximum and relu let it through", all clear = nothing flows back -- in the
  * kernels' register order), the backward reads x, the pooled gradient and aux and returns dw / dbias (overwritten) -- the
  * 537 MB pre-pool activation of the B = 256 model never exists.  Supported: rank 2, QK_CH_LAST, bf16 / fp16, cq == 1, kernel
- * (3,5), unit stride / dilation, pad_lo (1,2), activation RELU, conj 0, fq % 32 == 0, pool == 3, H % 3 != 1 (the
+ * (3,5), unit stride / dilation, pad_lo (1,2), activation RELU, conj 0, fq % 8 == 0, pool == 3, H % 3 != 1 (the
  * kernel's windows are rows [3o, 3o + 2]; TensorFlow's 'same' rule pads one row on the LOW side when H % 3 == 1, so
  * for those heights the windows would start at row -1: not this kernel's -- 41 bins are fine); anything else returns
  * QK_ERR_UNSUPPORTED (qk_conv_relu_pool_aux_bytes: 0) and the caller runs qk_conv_fwd + qk_maxpool2d_* instead.

@@ -894,7 +894,7 @@ static bool conv1_pool_ok(const qk_conv_desc_t *d, int32_t pool, int act = QK_AC
     return d->rank == 2 && (d->dtype == QK_BF16 || d->dtype == QK_F16) && d->cq == 1 &&
            d->kernel[0] == 3 && d->kernel[1] == 5 && d->stride[0] == 1 && d->stride[1] == 1 && d->dilation[0] == 1 &&
            d->dilation[1] == 1 && d->pad_lo[0] == 1 && d->pad_lo[1] == 2 && d->out_spatial[0] == d->in_spatial[0] &&
-           d->out_spatial[1] == d->in_spatial[1] && d->activation == act && d->conj == 0 && d->fq % 32 == 0 && pool == 3 &&
+           d->out_spatial[1] == d->in_spatial[1] && d->activation == act && d->conj == 0 && d->fq % 8 == 0 && pool == 3 &&        // (fq: 16-byte runs of filters per component; blocks of 32, the last one partly used)
            // the kernel's windows are rows [3o, 3o + 2]: TensorFlow's 'same' pooling (window = stride = 3) pads one row
            // on the LOW side when H % 3 == 1 (total pad 2 -> 1 + 1), so those heights are not this kernel's
            d->in_spatial[0] % 3 != 1 &&

@@ -213,8 +213,8 @@ struct C1 {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int k0 = 8 * lh + 2 * j, k1 = k0 + 1;
-                const float a = k0 < TAPS ? w[(k0 * 4 + p) * F + f] : 0.f;
-                const float b = k1 < TAPS ? w[(k1 * 4 + p) * F + f] : 0.f;
+                const float a = (k0 < TAPS && f < F) ? w[(k0 * 4 + p) * F + f] : 0.f;      // (f >= F: the block's unused filters, round 6 -- F a multiple of 8)
+                const float b = (k1 < TAPS && f < F) ? w[(k1 * 4 + p) * F + f] : 0.f;
                 d[j] = c1_pack(T(), a, b);
             }
             B[p] = make_uint4(d[0], d[1], d[2], d[3]);
@@ -307,7 +307,7 @@ k_conv1_pool_fwd(const T *__restrict__ x, const float *__restrict__ w, const flo
     for (int i = 0; i < 8; ++i) toff[i] = K::tap_off(8 * lh + i);
     float bia4[4];
 #pragma unroll
-    for (int b = 0; b < 4; ++b) bia4[b] = g.has_bias ? bias[b * g.F + j0 + lr] : 0.f;
+    for (int b = 0; b < 4; ++b) bia4[b] = (g.has_bias && j0 + lr < g.F) ? bias[b * g.F + j0 + lr] : 0.f;
     // The output's way from [filter = lane][positions in registers] to 16-byte runs of filters per position: every lane writes its
     // filter's row of the wave's slab ([filter][32 positions], 64-byte rows, 8 bytes of skew per four rows: the 8-byte writes and
     // the transposing reads both cover all banks) and ds_read_b64_tr_b16 hands a lane four FILTERS of one position -- 4 + 4 LDS
@@ -317,6 +317,9 @@ k_conv1_pool_fwd(const T *__restrict__ x, const float *__restrict__ w, const flo
     const int ep_fr = 8 * (lane & 3) + ((lane & 15) >> 2);        // the filter row this lane ADDRESSES in a transposing read (it receives filters 8 (i >> 2) + 0 .. 3)
     const int ep_r = ep_fr * 64 + (ep_fr >> 2) * 8 + (lane >> 4) * 8;        // + 32 pass: positions 16 pass + 4 (lane >> 4) .. + 3
     const int e_row = 4 * (lane >> 4) + (lane & 3), e_chunk = (lane & 15) >> 2;      // what it receives: position e_row (+ 16 pass), filters 8 e_chunk .. + 7
+    // Round 6: F need not fill the 32-filter block (start_filter = 16 models): a lane whose 8 filters lie past F sends its stores past the
+    // line's buffer bound, where they are dropped like the rows past W (was: kernel zero-padded to 32 filters + slice / pad passes in torch)
+    const bool e_live = j0 + 8 * e_chunk < g.F;
 
 #pragma unroll 1
     for (int it = 0; item < g.n_lines; ++it, item += (int)gridDim.x) {
@@ -430,7 +433,8 @@ k_conv1_pool_fwd(const T *__restrict__ x, const float *__restrict__ w, const flo
                         const uint2 lo = __builtin_bit_cast(uint2, f03), hi = __builtin_bit_cast(uint2, f47);
                         typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
                         const u32x4_t vv = {lo.x, lo.y, hi.x, hi.y};
-                        __builtin_amdgcn_raw_buffer_store_b128(vv, which ? pre_rs : out_rs, (int)(((tw + e_row + 16 * pass) * (4 * g.F) + b * g.F + e_chunk * 8) * 2), 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(vv, which ? pre_rs : out_rs,
+                                                               e_live ? (int)(((tw + e_row + 16 * pass) * (4 * g.F) + b * g.F + e_chunk * 8) * 2) : 0x7ffffff0, 0, 0);
                     }
                 }
             };
@@ -584,7 +588,7 @@ k_conv1_pool_bwd(const T *__restrict__ x, const T *__restrict__ dout, const T *_
             const int u = lane + 64 * u0;
             const int row = u >> 4, q = u & 15, b = q >> 2, sub = (q & 3) * 8;
             pre_dp[u0] = make_uint4(0u, 0u, 0u, 0u);               // rows past W are zero
-            if (tw + row < g.W) pre_dp[u0] = *reinterpret_cast<const uint4 *>(line_in + (unsigned)((tw + row) * (4 * g.F) + b * g.F + sub));
+            if (tw + row < g.W && j0 + sub < g.F) pre_dp[u0] = *reinterpret_cast<const uint4 *>(line_in + (unsigned)((tw + row) * (4 * g.F) + b * g.F + sub));
         }
     };
     if (!PRELU && (int)blockIdx.x < g.n_lines) load_item(blockIdx.x);
@@ -629,7 +633,7 @@ k_conv1_pool_bwd(const T *__restrict__ x, const T *__restrict__ dout, const T *_
             const int row = u >> 4, q = u & 15, b = q >> 2, sub = (q & 3) * 8;
             uint4 v = pre_dp[u0];
             if constexpr (PRELU) {
-                if (tw + row < g.W) {
+                if (tw + row < g.W && j0 + sub < g.F) {
                     const uint4 pv = *reinterpret_cast<const uint4 *>(line_pre + (unsigned)((tw + row) * (4 * g.F) + b * g.F + sub));
                     // element (row, filter sub + e) sits in lane (sub + e) + 32 lh', register r' of the accumulator layout
                     const int rr = (row & 3) + 4 * (row >> 3);
@@ -752,14 +756,14 @@ k_conv1_pool_bwd(const T *__restrict__ x, const T *__restrict__ dout, const T *_
         float v = 0.f;
 #pragma unroll
         for (int wv = 0; wv < 7; ++wv) v += all[wv * SLAB + e];
-        if (tap < K::TAPS && v != 0.f) atomicAdd(dw + (tap * 4 + p) * g.F + j0 + f, v);
+        if (tap < K::TAPS && j0 + f < g.F && v != 0.f) atomicAdd(dw + (tap * 4 + p) * g.F + j0 + f, v);
     }
     if (dbias && tid < 128) {
         const int b = tid >> 5, f = tid & 31;
         float v = 0.f;
 #pragma unroll
         for (int wv = 0; wv < 7; ++wv) v += all[wv * SLAB + 4 * 16 * 32 + b * 64 + f];
-        atomicAdd(dbias + b * g.F + j0 + f, v);
+        if (j0 + f < g.F) atomicAdd(dbias + b * g.F + j0 + f, v);
     }
 }
 
@@ -770,14 +774,14 @@ int run_conv1_pool(bool backward, const void *x, const float *w, const float *bi
     if (!backward) {
         int blocks = device_cu_count();                            // persistent, 159 - 239 registers: one 7-wave workgroup per CU
         if (blocks > g.n_lines) blocks = g.n_lines;
-        dim3 grid((unsigned)blocks, (unsigned)(g.F / 32), 1);
+        dim3 grid((unsigned)blocks, (unsigned)((g.F + 31) / 32), 1);
         hipLaunchKernelGGL((k_conv1_pool_fwd<T, 3, 5, 3, PRELU>), grid, dim3(512), 0, stream, (const T *)x, w, bias, (T *)const_cast<void *>(io),
                            (T *)const_cast<void *>(pre), (uint2 *)argbits, g);
     } else {
         int blocks = device_cu_count();                            // persistent, > 200 registers: one 7-wave workgroup per CU
         if (blocks > g.n_lines) blocks = g.n_lines;
         if (debug_flags() & kDbgDeterministic) blocks = 1;         // one flush per gradient element: no order-dependent sums
-        dim3 grid((unsigned)blocks, (unsigned)(g.F / 32), 1);
+        dim3 grid((unsigned)blocks, (unsigned)((g.F + 31) / 32), 1);
         hipLaunchKernelGGL((k_conv1_pool_bwd<T, 3, 5, 3, PRELU>), grid, dim3(448), 0, stream, (const T *)x, (const T *)io, (const T *)pre,
                            (const uint2 *)argbits, dw, dbias, dalpha, g);
     }
@@ -793,7 +797,7 @@ int run_conv1_pool(bool backward, const void *x, const float *w, const float *bi
 size_t conv1_pool_argbits_bytes(int N, int H, int W, int F)
 {
     const long long lines = (long long)N * ((H + 2) / 3) * ((W + C1_TW - 1) / C1_TW);
-    return (size_t)(lines * (F / 32) * 7 * 64 * 24);
+    return (size_t)(lines * ((F + 31) / 32) * 7 * 64 * 24);
 }
 
 int launch_conv1_pool(int dtype, bool backward, const void *x, const float *w, const float *bias, const void *io, void *argbits,

@@ -763,7 +763,7 @@ def _first_layer_call(x, kernel, activation, use_bias, x_layout):
 def conv_relu_pool_supported(x, kernel, pool, x_layout='channels_last'):
     """True when relu(QuaternionConv2D(kernel, 'same')(x)) followed by MaxPooling over the first spatial axis (window =
     stride = pool, 'same') can run as the fused first-layer kernels: x a contiguous channels_last (N, H, W, 4) 16-bit
-    device tensor that needs no gradient, kernel (3, 5, 1, 4F) with F % 32 == 0, pool == 3, and a height whose
+    device tensor that needs no gradient, kernel (3, 5, 1, 4F) with F % 8 == 0, pool == 3, and a height whose
     TensorFlow 'same' pooling pads on the high side only (H % 3 != 1: the kernel's windows start at row 0).  The
     answer is the C side's (qk_conv_relu_pool_aux_bytes is non-zero exactly for the geometries it takes), so the
     two predicates cannot drift apart."""

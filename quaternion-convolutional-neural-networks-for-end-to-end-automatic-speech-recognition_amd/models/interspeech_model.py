@@ -144,15 +144,7 @@ class TimitQCNN(torch.nn.Module):
         # a plain channels_first buffer (how the reference's callers hold the features) is read plane by plane by the
         # kernel itself; a channels-last buffer behind a channels_first view (an upstream engine layer) is taken as it is
         xl, lay = (x, 'channels_first') if x.is_contiguous() else (x.movedim(1, -1), 'channels_last')
-        kernel, bias, f = c.kernel, c.bias, c.kernel.shape[-1] // 4
-        fp = (f + 31) // 32 * 32
-        if fp != f and f >= 16 and x.dtype in (torch.bfloat16, torch.float16):
-            # start_filter = 16 (interspeech_model.py:46-50): the fused kernels work on 32-filter blocks -- run them on the kernel
-            # zero-padded to 32 filters per component and keep the real ones (two small copies; the unfused route of this layer
-            # was 1.8 ms of the sf = 16 step on the fp32-MFMA kernels: K = 60, 2.1 M rows)
-            import torch.nn.functional as tF
-            kernel = tF.pad(kernel.reshape(kernel.shape[:3] + (4, f)), (0, fp - f)).reshape(kernel.shape[:3] + (4 * fp,))
-            bias = tF.pad(bias.reshape(4, f), (0, fp - f)).reshape(4 * fp) if bias is not None else None
+        kernel, bias = c.kernel, c.bias            # (any filter count that is a multiple of 8: start_filter = 16 runs the 32-filter blocks half used)
         ok = (activations.serialize(c.activation) == 'relu' and c.padding == 'same' and c.strides == (1, 1) and
               c.dilation_rate == (1, 1) and c.internal_layout == 'channels_last' and pl.pool_size == (1, 3) and
               pl.strides == (1, 3) and pl.padding == 'same' and pl.data_format == 'channels_last' and
@@ -160,8 +152,6 @@ class TimitQCNN(torch.nn.Module):
         if not ok:
             return None
         y = Fq.conv_relu_pool(xl, kernel, bias, 3, lay)
-        if kernel is not c.kernel:
-            y = y.reshape(y.shape[:3] + (4, fp))[..., :f].reshape(y.shape[:3] + (4 * f,))
         return y.movedim(-1, 1)
 
     def _forward_fused_post(self, x):

@@ -1450,8 +1450,11 @@ def _np_pool_h_same(y, pool=3):
 
 @pytest.mark.parametrize('planes', [False, True], ids=['x_channels_last', 'x_component_planes'])
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16], ids=['bf16', 'fp16'])
-@pytest.mark.parametrize('shape,F', [((3, 41, 50, 4), 32), ((2, 9, 230, 4), 64), ((1, 8, 19, 4), 32)],
-                         ids=['timit_small', 'two_chunks_two_column_tiles', 'partial_window_odd_width'])
+@pytest.mark.parametrize('shape,F', [((3, 41, 50, 4), 32), ((2, 9, 230, 4), 64), ((1, 8, 19, 4), 32),
+                                     # round 6: filter counts that do not fill the kernel's 32-filter blocks (start_filter = 16 models)
+                                     ((3, 41, 50, 4), 16), ((2, 9, 230, 4), 40), ((1, 8, 19, 4), 8)],
+                         ids=['timit_small', 'two_chunks_two_column_tiles', 'partial_window_odd_width',
+                              'sf16_half_block', 'f40_full_plus_quarter_block', 'f8_quarter_block'])
 def test_fused_first_layer_conv_relu_pool_matches_oracle(shape, F, dtype, planes):
     """qk_conv_relu_pool_fwd / _bwd (conv (3,5) 'same' + relu + max-pool (3,1) 'same' over H, one kernel per direction,
     no pre-pool tensor) against oracle conv + numpy pooling: pooled values, d kernel, d bias.  Widths beyond one
@@ -1492,8 +1495,9 @@ def test_fused_first_layer_conv_relu_pool_matches_oracle(shape, F, dtype, planes
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16], ids=['bf16', 'fp16'])
-@pytest.mark.parametrize('shape,F,per_row', [((3, 41, 50, 4), 32, True), ((2, 8, 230, 4), 64, True), ((2, 11, 33, 4), 32, False)],
-                         ids=['41x50_f32', '8x230_f64', '11x33_scalar'])
+@pytest.mark.parametrize('shape,F,per_row', [((3, 41, 50, 4), 32, True), ((2, 8, 230, 4), 64, True), ((2, 11, 33, 4), 32, False),
+                                             ((3, 41, 50, 4), 16, True), ((2, 11, 33, 4), 40, False)],
+                         ids=['41x50_f32', '8x230_f64', '11x33_scalar', '41x50_f16_half_block', '11x33_f40_scalar'])
 @pytest.mark.parametrize('planes', [False, True], ids=['x_channels_last', 'x_component_planes'])
 def test_fused_first_layer_conv_prelu_pool_matches_oracle(shape, F, per_row, dtype, planes):
     """qk_conv_prelu_pool_fwd / _bwd (linear conv (3,5) 'same' + PReLU with one slope per frequency row, or one slope +
