@@ -1725,3 +1725,39 @@ def test_library_profiler_times_every_call_of_a_backward():
         assert (r['rows'], r['n'], r['k']) == (4 * 14 * 40, 128, 3 * 5 * 128) and r['ms'] > 0 and r['path'].startswith('mfma16')
     F.quaternion_conv(x, w, None, padding='same', activation='relu')
     assert _lib.lib().qk_prof_count() == 3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', [((6, 200, 160), (3, 40, 256)), ((2, 9, 31, 96), (3, 5, 24, 64))], ids=['conv1d_cfg2_small_batch', 'conv2d_24to16'])
+def test_fp32_backward_weight_is_bit_repeatable_in_deterministic_mode(shape):
+    """Round 6: k_wgrad<float> folds the 16 expanded blocks onto the 4 parts with a register reduce-scatter (DPP / ds_swizzle) and
+    takes the bias sums from the staged registers -- both in a fixed order; with QK_DBG_DETERMINISTIC (one split of M, one owner per
+    bias column) two runs must agree bit for bit, and the default (split, atomic) run with them to fp32 rounding."""
+    import qcnn_amd
+    from qcnn_amd import _lib
+    F = qcnn_amd.functional
+    dev = _dev()
+    xs, ws = shape
+    rank = len(xs) - 2
+    g = torch.Generator(device=dev).manual_seed(5)
+    x = torch.randn(xs, device=dev, generator=g)
+    w = torch.randn(ws, device=dev, generator=g) / 20
+    b = torch.randn(ws[-1], device=dev, generator=g) / 10
+    call = F.conv_call(xs, ws, torch.float32, rank, 1, 'same', 'channels_last', 1, 'relu', True)
+    y = call.fwd(x, w, b)
+    dy = torch.randn(call.y_shape, device=dev, generator=g)
+
+    def run(flags):
+        with _lib.debug_flags(flags):
+            dx, dw, db = call.bwd(x, dy, y, w, True)
+            torch.cuda.synchronize()
+        return dx, dw, db
+    a = run(_lib.QK_DBG_DETERMINISTIC)
+    c = run(_lib.QK_DBG_DETERMINISTIC)
+    d = run(0)
+    assert _lib.last_path() == 'fp32_mfma'
+    for u, v in zip(a, c):
+        assert torch.equal(u, v)
+    for u, v in zip(a, d):
+        assert float((u - v).abs().max()) <= 2e-5 * float(u.abs().max())
+    assert float(a[1].abs().max()) > 0 and float(a[2].abs().max()) > 0
